@@ -1,0 +1,124 @@
+// hevc_tables.h — host-side construction of the constant tables (struct Tables) and of the stream headers.
+// Everything here is generated from the standard's defining data rather than stored as big literals:
+//   * transform matrices from the 32 first-column values of the 32-point core transform (reference :431-464);
+//   * scan orders (reference :1126-1150) from the up-right-diagonal / horizontal / vertical rules;
+//   * CABAC probability tables (reference :700-714) from H.265 rangeTabLps / transIdxLps.
+#pragma once
+#include <string.h>
+#include "hevc_core.h"
+
+namespace imcvt {
+
+static const i8 kCos32[32] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                               64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4 };
+static const i8 kDst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+static const u8 kRangeLps[256] = {
+    128,176,208,240, 128,167,197,227, 128,158,187,216, 123,150,178,205, 116,142,169,195, 111,135,160,185, 105,128,152,175, 100,122,144,166,
+     95,116,137,158,  90,110,130,150,  85,104,123,142,  81, 99,117,135,  77, 94,111,128,  73, 89,105,122,  69, 85,100,116,  66, 80, 95,110,
+     62, 76, 90,104,  59, 72, 86, 99,  56, 69, 81, 94,  53, 65, 77, 89,  51, 62, 73, 85,  48, 59, 69, 80,  46, 56, 66, 76,  43, 53, 63, 72,
+     41, 50, 59, 69,  39, 48, 56, 65,  37, 45, 54, 62,  35, 43, 51, 59,  33, 41, 48, 56,  32, 39, 46, 53,  30, 37, 43, 50,  29, 35, 41, 48,
+     27, 33, 39, 45,  26, 31, 37, 43,  24, 30, 35, 41,  23, 28, 33, 39,  22, 27, 32, 37,  21, 26, 30, 35,  20, 24, 29, 33,  19, 23, 27, 31,
+     18, 22, 26, 30,  17, 21, 25, 28,  16, 20, 23, 27,  15, 19, 22, 25,  14, 18, 21, 24,  14, 17, 20, 23,  13, 16, 19, 22,  12, 15, 18, 21,
+     12, 14, 17, 20,  11, 14, 16, 19,  11, 13, 15, 18,  10, 12, 15, 17,  10, 12, 14, 16,   9, 11, 13, 15,   9, 11, 12, 14,   8, 10, 12, 14,
+      8,  9, 11, 13,   7,  9, 11, 12,   7,  9, 10, 12,   7,  8, 10, 11,   6,  8,  9, 11,   6,  7,  9, 10,   6,  7,  8,  9,   2,  2,  2,  2 };
+static const u8 kTransLps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22,
+    23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
+static const u8 kCtxInit[NCTX] = {   // I-slice initValues in the CX_* order of hevc_core.h (reference :762-776)
+    139, 141, 157,  184,  184,  63,  153, 138, 138,  111, 141,  94,
+    110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79,
+    110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79,
+    91, 171,
+    111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
+    140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152,
+    138, 153, 136, 167 };
+static const i8 kAng[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                             -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const u16 kInvAng[35] = { 0, 0, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482, 390, 315, 256,
+                                 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+
+inline int dct_entry(int n, int i, int j) {
+    if (i == 0) return 64;
+    int m = (i * (32 / n) * (2 * j + 1)) & 127;
+    if (m > 64) m = 128 - m;
+    return (m > 32) ? -kCos32[64 - m] : kCos32[m];
+}
+
+inline void build_tables(Tables &T) {
+    memset(&T, 0, sizeof(T));
+    for (int s = 0; s < 4; s++) {
+        const int n = 4 << s, off = s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336;
+        for (int i = 0; i < n; i++) for (int k = 0; k < n; k++) {
+            const int v = (s == 0) ? kDst4[i * 4 + k] : dct_entry(n, i, k);
+            T.C[off + i * n + k] = (i8)v; T.CT[off + k * n + i] = (i8)v;
+        }
+    }
+    // in-group 4x4 patterns: up-right diagonal, horizontal, vertical
+    int n = 0;
+    for (int d = 0; d < 7; d++) for (int y = (d < 3 ? d : 3); y >= 0; y--) { const int x = d - y; if (x > 3) continue; T.incg[0][n++] = (u8)((y << 2) | x); }
+    for (int k = 0; k < 16; k++) { T.incg[1][k] = (u8)(((k >> 2) << 2) | (k & 3)); T.incg[2][k] = (u8)(((k & 3) << 2) | (k >> 2)); }
+    for (int t = 0; t < 3; t++) for (int k = 0; k < 16; k++) T.incg_rank[t][T.incg[t][k]] = (u8)k;
+    // group orders
+    for (int t = 0; t < 3; t++) for (int s = 0; s < 4; s++) {
+        const int ncg = 1 << s; int m = 0;
+        if (t == 0) { for (int d = 0; d < 2 * ncg - 1; d++) for (int y = (d < ncg - 1 ? d : ncg - 1); y >= 0; y--) { const int x = d - y; if (x >= ncg) continue; T.cgpos[t][s][m++] = (u8)((y << 3) | x); } }
+        else if (t == 1) { for (int y = 0; y < ncg; y++) for (int x = 0; x < ncg; x++) T.cgpos[t][s][m++] = (u8)((y << 3) | x); }
+        else { for (int x = 0; x < ncg; x++) for (int y = 0; y < ncg; y++) T.cgpos[t][s][m++] = (u8)((y << 3) | x); }
+        for (int g = 0; g < m; g++) T.cgrank[t][s][T.cgpos[t][s][g]] = (u8)g;     // index (gy<<3)|gx == gy*8+gx
+    }
+    // CABAC
+    for (int st = 0; st < 64; st++) {
+        T.lps4[st] = (u32)kRangeLps[st * 4] | (u32)kRangeLps[st * 4 + 1] << 8 | (u32)kRangeLps[st * 4 + 2] << 16 | (u32)kRangeLps[st * 4 + 3] << 24;
+        for (int mps = 0; mps < 2; mps++) T.nextlps[st * 2 + mps] = (u8)(st == 0 ? (1 - mps) : ((kTransLps[st] << 1) | mps));
+    }
+    // sig_coeff_flag context increments per in-group scan position (reference :1115-1120)
+    for (int pat = 0; pat < 4; pat++) for (int t = 0; t < 3; t++) {
+        u32 w = 0;
+        for (int k = 0; k < 16; k++) {
+            const int yi = T.incg[t][k] >> 2, xi = T.incg[t][k] & 3; int v;
+            if (pat == 0) { const int sum = yi + xi; v = sum == 0 ? 2 : sum < 3 ? 1 : 0; }
+            else if (pat == 1) v = yi == 0 ? 2 : yi == 1 ? 1 : 0;
+            else if (pat == 2) v = xi == 0 ? 2 : xi == 1 ? 1 : 0;
+            else v = 2;
+            w |= (u32)v << (2 * k);
+        }
+        T.posadd[pat][t] = w;
+    }
+    static const u8 c4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };     // reference :1092
+    for (int t = 0; t < 3; t++) { u64 w = 0; for (int k = 0; k < 16; k++) w |= (u64)c4[T.incg[t][k]] << (4 * k); T.c4tab[t] = w; }
+    for (int q = 0; q < 5; q++) {
+        const int qp = q * 6 + 4;
+        for (int i = 0; i < NCTX; i++) {
+            const int v = kCtxInit[i];
+            int st = ((((v >> 4) * 5 - 45) * qp) >> 4) + ((v & 15) << 3) - 16;
+            st = st < 1 ? 1 : st > 126 ? 126 : st;
+            T.ctx_init[q][i] = (st >= 64) ? (u8)(((st - 64) << 1) | 1) : (u8)((63 - st) << 1);
+        }
+    }
+    for (int m = 0; m < 35; m++) { T.ang[m] = (u8)(kAng[m] + 32); T.iang[m] = kInvAng[m]; }
+}
+
+// VPS | SPS(+dims) | PPS | slice header (reference :664-690).  Returns the number of bytes written (<= 96).
+inline int build_headers(u8 *out, int q, int hp, int wp) {
+    static const u8 vps[27] = { 0, 0, 1, 0x40, 1, 0x0C, 1, 0xFF, 0xFF, 3, 0x10, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0xB4, 0xF0, 0x24 };
+    static const u8 sps[22] = { 0, 0, 1, 0x42, 1, 1, 3, 0x10, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0xB4 };
+    static const u8 pps[11] = { 0, 0, 1, 0x44, 1, 0xC0, 0x90, 0x91, 0x81, 0xD9, 0x20 };
+    static const u8 slice_qp[5][2] = { {0x16, 0xDE}, {0x10, 0xDE}, {0x2B, 0x78}, {0x4D, 0xE0}, {0x97, 0x80} };
+    static const u8 slice[6] = { 0, 0, 1, 0x26, 1, 0xAC };
+    u8 *p = out;
+    memcpy(p, vps, 27); p += 27; memcpy(p, sps, 22); p += 22;
+    // MSB-first bit writer
+    u64 acc = 0; int nb = 0;
+    auto put = [&](u32 v, int n) { for (int i = n - 1; i >= 0; i--) { acc = (acc << 1) | ((v >> i) & 1); if (++nb == 8) { *p++ = (u8)acc; acc = 0; nb = 0; } } };
+    auto ue_like = [&](int v) {             // the reference's ue(v) variant, length from v+2 (:641-647)
+        int len = 1; v++;
+        for (int t = v + 1; t != 1; t >>= 1) len += 2;
+        put((u32)(v & ((1 << ((len + 1) >> 1)) - 1)), (len >> 1) + ((len + 1) >> 1));
+    };
+    put(0xA, 4); ue_like(wp); ue_like(hp); put(0x197EE4, 22); put(0x681ED1, 24);
+    if (nb) { *p++ = (u8)(acc << (8 - nb)); }
+    memcpy(p, pps, 11); p += 11; memcpy(p, slice, 6); p += 6;
+    *p++ = slice_qp[q][0]; *p++ = slice_qp[q][1];
+    return (int)(p - out);
+}
+
+}  // namespace imcvt
