@@ -16,7 +16,7 @@
 typedef uint8_t u8;  typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
 typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
 
-#define NWAVES 4
+#define NWAVES 3
 #define WG_THREADS (NWAVES * 64)
 #define NMODE 35
 #define I32MAX 0x7fffffff

@@ -293,13 +293,13 @@ HD void encode_ctu(Shm &S, FrameCtx &F) {
             S.org[y][x] = J.img[(size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1)];
         }
         if (tid < 32) S.rec[tid + 1][0] = J.rcon[(size_t)clip3(cy + tid, 0, J.hp - 1) * J.wp + clip3(cx - 1, 0, J.wp - 1)];
-        if (tid >= 64 && tid < 64 + 65) {
-            const int j = tid - 64 - 1;
+        if (tid >= 32 && tid < 32 + 65) {
+            const int j = tid - 32 - 1;
             S.rec[0][j + 1] = J.rcon[(size_t)clip3(cy - 1, 0, J.hp - 1) * J.wp + clip3(cx + j, 0, J.wp - 1)];
         }
         // neighbour-map aprons: above row keeps sizes but forgets modes (:1633-1636); left column comes from the previous CTU
-        if (tid >= 192 && tid < 192 + 10) {
-            const int j = tid - 192;      // apron column index 0..9 <-> unit x = j-1
+        if (tid >= 100 && tid < 100 + 10) {
+            const int j = tid - 100;      // apron column index 0..9 <-> unit x = j-1
             S.mapsz[0][j] = (u8)((cy > 0 && j >= 1 && j <= 8) ? F.sc.above_sz[(cx >> 2) + j - 1] : 32);
             S.mapmode[0][j] = 1;
             if (cx == 0 && j < 9) { S.mapsz[j + 1][0] = 32; S.mapmode[j + 1][0] = 1; }

@@ -1,0 +1,234 @@
+// hevc_hip.hip — gfx950 kernel entry and the C-ABI host shim of libimcvt_hevc.so (include/imcvt_hevc.h).
+//
+// One persistent workgroup per frame slot: workgroups pull frame indices from an atomic counter, so any
+// batch size runs on a grid sized to the device (2 workgroups per CU by default).  The frame's CTUs are a
+// strict serial chain (the RD rate is the live CABAC position), so parallelism is candidates x pixels
+// inside a workgroup and frames across workgroups / GPUs.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "hevc_frame.h"
+#include "hevc_tables.h"
+#include "../../include/imcvt_hevc.h"
+
+#define HDR_MAX 96
+
+__global__ __launch_bounds__(WG_THREADS) void hevc_encode_frames(const Tables *gT, const FrameJob *jobs, const u8 *hdrs, int njobs,
+                                                                 const Scratch *scr, int *counter, i32 *trace, int trace_cap) {
+    __shared__ Shm S;
+    __shared__ int next_frame;
+    for (;;) {
+        if (threadIdx.x == 0) next_frame = atomicAdd(counter, 1);
+        __syncthreads();
+        const int f = next_frame;
+        __syncthreads();
+        if (f >= njobs) break;
+        Scratch sc = scr[blockIdx.x];
+        sc.trace = (f == 0) ? trace : (i32 *)0;
+        sc.trace_cap = trace_cap;
+        encode_frame(S, gT, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct imcvt_hevc_ctx {
+    int device = 0, max_wg = 0;
+    Tables *d_tables = nullptr;
+    Scratch *d_scratch = nullptr;
+    void *d_pool = nullptr;            // backing store of all per-workgroup scratch
+    int *d_counter = nullptr;
+    FrameJob *d_jobs = nullptr; u8 *d_hdrs = nullptr; int jobs_cap = 0;
+    FrameJob *h_jobs = nullptr; u8 *h_hdrs = nullptr;      // pinned staging
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+    int *d_trace = nullptr; int trace_cap = 0;
+};
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
+
+static bool have_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fprintf(stderr, "imcvt_hevc: no HIP device visible — this library has no CPU fallback\n");
+        return false;
+    }
+    return true;
+}
+
+extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r1 (wg=" "192" ", frame-per-workgroup)"; }
+extern "C" int imcvt_hevc_padded(int v) { return ((v < 8192 ? v : 8192) + 31) / 32 * 32; }
+extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 32) * (h + 32) + 65536; }
+
+static const size_t kLvBytes = (size_t)NWAVES * LV_PER_WAVE * sizeof(i16);
+static const size_t kTrialBytes = (size_t)NWAVES * NMODE * TRIAL_BYTES;
+static const size_t kAboveBytes = 8192 / 4 + 64;
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
+    if (!have_device()) return nullptr;
+    imcvt_hevc_ctx *c = new imcvt_hevc_ctx();
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return nullptr; }
+    c->max_wg = max_workgroups > 0 ? max_workgroups : 2 * prop.multiProcessorCount;
+    Tables *T = new Tables();
+    imcvt::build_tables(*T);
+    const size_t per_wg = align256(kLvBytes) + align256(kTrialBytes) + align256(kAboveBytes);
+    bool ok = hipMalloc(&c->d_tables, sizeof(Tables)) == hipSuccess
+           && hipMemcpy(c->d_tables, T, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess
+           && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
+           && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
+           && hipMalloc(&c->d_counter, sizeof(int)) == hipSuccess
+           && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    delete T;
+    if (ok) {
+        std::vector<Scratch> hs(c->max_wg);
+        for (int i = 0; i < c->max_wg; i++) {
+            u8 *base = (u8 *)c->d_pool + per_wg * i;
+            hs[i].lv = (i16 *)base;
+            hs[i].bytes = base + align256(kLvBytes);
+            hs[i].above_sz = hs[i].bytes + align256(kTrialBytes);
+            hs[i].trace = nullptr; hs[i].trace_cap = 0;
+        }
+        ok = hipMemcpy(c->d_scratch, hs.data(), sizeof(Scratch) * c->max_wg, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { fprintf(stderr, "imcvt_hevc: context allocation failed\n"); imcvt_hevc_destroy(c); return nullptr; }
+    return c;
+}
+
+extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
+    if (!c) return;
+    hipFree(c->d_tables); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter);
+    hipFree(c->d_jobs); hipFree(c->d_hdrs);
+    if (c->h_jobs) hipHostFree(c->h_jobs);
+    if (c->h_hdrs) hipHostFree(c->h_hdrs);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    delete c;
+}
+
+extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
+
+extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
+    if (!c || n < 0 || (n > 0 && !frames)) return IMCVT_ERR_ARG;
+    if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n > c->jobs_cap) {
+        hipFree(c->d_jobs); hipFree(c->d_hdrs);
+        if (c->h_jobs) hipHostFree(c->h_jobs);
+        if (c->h_hdrs) hipHostFree(c->h_hdrs);
+        c->d_jobs = nullptr; c->d_hdrs = nullptr; c->h_jobs = nullptr; c->h_hdrs = nullptr; c->jobs_cap = 0;
+        HIPCHK(hipMalloc(&c->d_jobs, sizeof(FrameJob) * n));
+        HIPCHK(hipMalloc(&c->d_hdrs, (size_t)HDR_MAX * n));
+        HIPCHK(hipHostMalloc(&c->h_jobs, sizeof(FrameJob) * n));
+        HIPCHK(hipHostMalloc(&c->h_hdrs, (size_t)HDR_MAX * n));
+        c->jobs_cap = n;
+    } else {
+        HIPCHK(hipStreamSynchronize(stream));      // the pinned staging of the previous launch must have been consumed
+    }
+    for (int i = 0; i < n; i++) {
+        const imcvt_hevc_frame &f = frames[i];
+        if (f.qpd6 < 0 || f.qpd6 > 4 || f.h < 1 || f.w < 1 || !f.d_img || !f.d_out || !f.d_rcon || !f.d_len) return IMCVT_ERR_ARG;
+        FrameJob &j = c->h_jobs[i];
+        j.img = f.d_img; j.out = f.d_out; j.rcon = f.d_rcon; j.out_len = f.d_len;
+        j.h = f.h; j.w = f.w; j.hp = imcvt_hevc_padded(f.h); j.wp = imcvt_hevc_padded(f.w); j.q = f.qpd6;
+        j.hdr_len = imcvt::build_headers(c->h_hdrs + (size_t)HDR_MAX * i, f.qpd6, j.hp, j.wp);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(int), stream));
+    const int grid = n < c->max_wg ? n : c->max_wg;
+    HIPCHK(hipEventRecord(c->ev0, stream));
+    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream,
+                       c->d_tables, c->d_jobs, c->d_hdrs, n, c->d_scratch, c->d_counter, c->d_trace, c->trace_cap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return 0;
+}
+
+extern "C" float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *c) {
+    if (!c || !c->timed) return -1.f;
+    float ms = -1.f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess || hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host-pointer entry points (the reference's own interface)
+// ---------------------------------------------------------------------------------------------------
+static std::mutex g_lock;
+static imcvt_hevc_ctx *g_ctx = nullptr;
+
+extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
+                                     unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len) {
+    if (n < 0 || (n > 0 && (!pbuffers || !imgs || !rcons || !ysz || !xsz || !qpd6 || !out_len))) return IMCVT_ERR_ARG;
+    for (int i = 0; i < n; i++) if (qpd6[i] < 0 || qpd6[i] > 4 || ysz[i] < 1 || xsz[i] < 1) return IMCVT_ERR_ARG;
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (!g_ctx) { g_ctx = imcvt_hevc_create(0); if (!g_ctx) return IMCVT_ERR_NO_DEVICE; }
+    if (n == 0) return 0;
+    // one device slab: [img | out | rcon | len] per frame
+    std::vector<size_t> off_img(n), off_out(n), off_rc(n), off_len(n);
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        // the reference indexes img with the ORIGINAL stride but only up to the padded (<=8192) extent (:1621)
+        const int hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
+        off_img[i] = total; total += align256((size_t)ysz[i] * xsz[i]);
+        off_out[i] = total; total += align256((size_t)imcvt_hevc_stream_bound(ysz[i], xsz[i]));
+        off_rc[i] = total;  total += align256((size_t)hp * wp);
+        off_len[i] = total; total += 256;
+    }
+    u8 *slab = nullptr;
+    HIPCHK(hipMalloc(&slab, total));
+    std::vector<imcvt_hevc_frame> fr(n);
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; i++) {
+        if (hipMemcpyAsync(slab + off_img[i], imgs[i], (size_t)ysz[i] * xsz[i], hipMemcpyHostToDevice, 0) != hipSuccess) rc = IMCVT_ERR_HIP;
+        fr[i].d_img = slab + off_img[i]; fr[i].d_out = slab + off_out[i]; fr[i].d_rcon = slab + off_rc[i];
+        fr[i].d_len = (int *)(slab + off_len[i]); fr[i].h = ysz[i]; fr[i].w = xsz[i]; fr[i].qpd6 = qpd6[i];
+    }
+    if (rc == 0) rc = imcvt_hevc_encode_device(g_ctx, n, fr.data(), nullptr);
+    if (rc == 0 && hipStreamSynchronize(0) != hipSuccess) rc = IMCVT_ERR_HIP;
+    for (int i = 0; i < n && rc == 0; i++) {
+        const int hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
+        int len = 0;
+        if (hipMemcpy(&len, fr[i].d_len, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
+        if (hipMemcpy(pbuffers[i], fr[i].d_out, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
+        if (hipMemcpy(rcons[i], fr[i].d_rcon, (size_t)hp * wp, hipMemcpyDeviceToHost) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
+        out_len[i] = len; ysz[i] = hp; xsz[i] = wp;
+    }
+    hipFree(slab);
+    return rc;
+}
+
+extern "C" int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
+                                int *ysz, int *xsz, const int qpd6) {
+    if (!pbuffer || !img || !img_rcon || !ysz || !xsz) return IMCVT_ERR_ARG;
+    int len = 0;
+    unsigned char *pb[1] = { pbuffer }; const unsigned char *im[1] = { img }; unsigned char *rc_[1] = { img_rcon };
+    int q[1] = { qpd6 };
+    const int rc = HEVCImageEncoderBatch(1, pb, im, rc_, ysz, xsz, q, &len);
+    return rc < 0 ? rc : len;
+}
+
+extern "C" int writeHEVCImageFile(const char *p_filename, const uint8_t *p_buf, int is_rgb, uint32_t height, uint32_t width, int qpd6) {
+    const size_t npx = (size_t)height * width;
+    const size_t n_out = (size_t)imcvt_hevc_stream_bound((int)height, (int)width), n_img = (size_t)(width + 32) * (height + 32) + 1048576;
+    unsigned char *slab = (unsigned char *)malloc(n_out + 2 * n_img);
+    if (!slab) return 1;
+    unsigned char *orig = slab + n_out, *rcon = orig + n_img;
+    if (is_rgb) {
+        printf("   warning: this HEVCencoder currently only support gray 8-bit image instead of RGB image. Only compress the green channel of this image.\n");
+        for (size_t i = 0; i < npx; i++) orig[i] = p_buf[i * 3 + 1];
+    } else memcpy(orig, p_buf, npx);
+    int h = (int)height, w = (int)width, failed = 1;
+    const int len = HEVCImageEncoder(slab, orig, rcon, &h, &w, qpd6);
+    if (len > 0 && h > 0 && w > 0) {
+        FILE *fp = fopen(p_filename, "wb");
+        if (fp) { failed = ((size_t)len != fwrite(slab, 1, (size_t)len, fp)); fclose(fp); }
+    }
+    free(slab);
+    return failed;
+}

@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference's H.265 interface over libimcvt_hevc.so (C ABI: include/imcvt_hevc.h).
+
+Names, argument meaning and error behaviour follow the reference:
+
+  HEVCImageEncoder(img, qpd6)            <- src/HEVCe/HEVCe.h:5-12  (returns stream, reconstruction, padded size)
+  writeHEVCImageFile(path, buf, ...)     <- src/imageio.h:21 / src/imageio_hevc.c:9 (0 = ok, 1 = failed)
+  HEVCImageEncoderBatch(imgs, qpd6)      <- new: the batch seam at src/main.c:162
+
+The compute path is the HIP library only.  If it is missing, or no gfx950 device is visible, these
+functions raise — there is no CPU fallback and nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libimcvt_hevc.so")
+
+_u8p = C.POINTER(C.c_ubyte)
+_ip = C.POINTER(C.c_int)
+
+ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error", -3: "bad argument"}
+
+# every symbol include/imcvt_hevc.h declares
+EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
+           "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
+           "imcvt_hevc_set_trace", "imcvt_hevc_version")
+
+
+class imcvt_hevc_frame(C.Structure):
+    _fields_ = [("d_img", C.c_void_p), ("d_out", C.c_void_p), ("d_rcon", C.c_void_p), ("d_len", C.c_void_p),
+                ("h", C.c_int), ("w", C.c_int), ("qpd6", C.c_int)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libimcvt_hevc.so (built by __graft_entry__.build() / imcvt_amd.build).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is mandatory; there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.HEVCImageEncoder.restype = C.c_int
+    lib.HEVCImageEncoder.argtypes = [_u8p, _u8p, _u8p, _ip, _ip, C.c_int]
+    lib.writeHEVCImageFile.restype = C.c_int
+    lib.writeHEVCImageFile.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
+    lib.HEVCImageEncoderBatch.restype = C.c_int
+    lib.HEVCImageEncoderBatch.argtypes = [C.c_int, C.POINTER(_u8p), C.POINTER(_u8p), C.POINTER(_u8p), _ip, _ip, _ip, _ip]
+    lib.imcvt_hevc_create.restype = C.c_void_p
+    lib.imcvt_hevc_create.argtypes = [C.c_int]
+    lib.imcvt_hevc_destroy.restype = None
+    lib.imcvt_hevc_destroy.argtypes = [C.c_void_p]
+    lib.imcvt_hevc_stream_bound.restype = C.c_longlong
+    lib.imcvt_hevc_stream_bound.argtypes = [C.c_int, C.c_int]
+    lib.imcvt_hevc_padded.restype = C.c_int
+    lib.imcvt_hevc_padded.argtypes = [C.c_int]
+    lib.imcvt_hevc_encode_device.restype = C.c_int
+    lib.imcvt_hevc_encode_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(imcvt_hevc_frame), C.c_void_p]
+    lib.imcvt_hevc_last_kernel_ms.restype = C.c_float
+    lib.imcvt_hevc_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.imcvt_hevc_set_trace.restype = None
+    lib.imcvt_hevc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.imcvt_hevc_version.restype = C.c_char_p
+    lib.imcvt_hevc_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+    return rc
+
+
+def padded(v: int) -> int:
+    return (min(v, 8192) + 31) // 32 * 32
+
+
+def stream_bound(h: int, w: int) -> int:
+    return 2 * (w + 32) * (h + 32) + 65536
+
+
+def HEVCImageEncoder(img: np.ndarray, qpd6: int = 0):
+    """Encode one gray8 frame.  Returns (stream bytes, reconstruction[yszn, xszn] uint8, (yszn, xszn))."""
+    lib = load_library()
+    assert img.dtype == np.uint8 and img.ndim == 2
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    hp, wp = padded(h), padded(w)
+    out = np.empty(stream_bound(h, w), dtype=np.uint8)
+    rcon = np.empty(hp * wp, dtype=np.uint8)
+    ys, xs = C.c_int(h), C.c_int(w)
+    n = _check(lib.HEVCImageEncoder(out.ctypes.data_as(_u8p), img.ctypes.data_as(_u8p), rcon.ctypes.data_as(_u8p),
+                                    C.byref(ys), C.byref(xs), int(qpd6)), "HEVCImageEncoder")
+    return out[:n].tobytes(), rcon.reshape(ys.value, xs.value), (ys.value, xs.value)
+
+
+def HEVCImageEncoderBatch(imgs, qpd6=0):
+    """Encode independent gray8 frames concurrently (one workgroup per frame).  qpd6: int or per-frame list.
+    Returns a list of (stream bytes, reconstruction, (yszn, xszn))."""
+    lib = load_library()
+    n = len(imgs)
+    if n == 0:
+        return []
+    qs = [int(qpd6)] * n if np.isscalar(qpd6) else [int(q) for q in qpd6]
+    imgs = [np.ascontiguousarray(a) for a in imgs]
+    for a in imgs:
+        assert a.dtype == np.uint8 and a.ndim == 2
+    outs = [np.empty(stream_bound(*a.shape), dtype=np.uint8) for a in imgs]
+    rcons = [np.empty(padded(a.shape[0]) * padded(a.shape[1]), dtype=np.uint8) for a in imgs]
+    P = _u8p * n
+    ys = (C.c_int * n)(*[a.shape[0] for a in imgs])
+    xs = (C.c_int * n)(*[a.shape[1] for a in imgs])
+    qv = (C.c_int * n)(*qs)
+    lens = (C.c_int * n)()
+    _check(lib.HEVCImageEncoderBatch(n, P(*[o.ctypes.data_as(_u8p) for o in outs]), P(*[a.ctypes.data_as(_u8p) for a in imgs]),
+                                     P(*[r.ctypes.data_as(_u8p) for r in rcons]), ys, xs, qv, lens), "HEVCImageEncoderBatch")
+    return [(outs[i][:lens[i]].tobytes(), rcons[i].reshape(ys[i], xs[i]), (ys[i], xs[i])) for i in range(n)]
+
+
+def writeHEVCImageFile(filename: str, buf: np.ndarray, is_rgb: bool, height: int, width: int, qpd6: int = 0) -> int:
+    """Reference semantics: 0 = success, 1 = failed (src/imageio_hevc.c:9-53)."""
+    lib = load_library()
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    return lib.writeHEVCImageFile(filename.encode(), buf.ctypes.data_as(_u8p), int(bool(is_rgb)), height, width, int(qpd6))
+
+
+class DeviceEncoder:
+    """Device-resident batch encoder: inputs/outputs stay in HBM (torch tensors supply the memory)."""
+
+    def __init__(self, max_workgroups: int = 0):
+        self.lib = load_library()
+        self.ctx = self.lib.imcvt_hevc_create(int(max_workgroups))
+        if not self.ctx:
+            raise RuntimeError("imcvt_hevc_create failed: " + ERRORS[-1])
+
+    def close(self):
+        if self.ctx:
+            self.lib.imcvt_hevc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def make_batch(self, imgs_dev, qpd6=0):
+        """imgs_dev: list of 2-D uint8 CUDA tensors.  Allocates outputs (torch) and the descriptor array."""
+        import torch
+        n = len(imgs_dev)
+        qs = [int(qpd6)] * n if np.isscalar(qpd6) else [int(q) for q in qpd6]
+        dev = imgs_dev[0].device
+        outs, rcons = [], []
+        lens = torch.zeros(n, dtype=torch.int32, device=dev)
+        arr = (imcvt_hevc_frame * n)()
+        for i, t in enumerate(imgs_dev):
+            assert t.dtype == torch.uint8 and t.dim() == 2 and t.is_contiguous() and t.is_cuda
+            h, w = t.shape
+            o = torch.empty(stream_bound(h, w), dtype=torch.uint8, device=dev)
+            r = torch.empty((padded(h), padded(w)), dtype=torch.uint8, device=dev)
+            outs.append(o)
+            rcons.append(r)
+            arr[i] = imcvt_hevc_frame(t.data_ptr(), o.data_ptr(), r.data_ptr(), lens.data_ptr() + 4 * i, h, w, qs[i])
+        return dict(n=n, frames=arr, imgs=imgs_dev, outs=outs, rcons=rcons, lens=lens)
+
+    def encode(self, batch, stream=None):
+        """Asynchronous launch on `stream` (a torch.cuda.Stream or None for the current stream)."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        _check(self.lib.imcvt_hevc_encode_device(self.ctx, batch["n"], batch["frames"], C.c_void_p(s.cuda_stream)),
+               "imcvt_hevc_encode_device")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.imcvt_hevc_last_kernel_ms(self.ctx))
+
+    def results(self, batch):
+        import torch
+        torch.cuda.synchronize()
+        lens = batch["lens"].cpu().tolist()
+        return [(batch["outs"][i][:lens[i]].cpu().numpy().tobytes(), batch["rcons"][i].cpu().numpy()) for i in range(batch["n"])]

@@ -1,0 +1,100 @@
+/*
+ * imcvt_hevc.h — C ABI of libimcvt_hevc.so, the MI355X (gfx950) implementation of ImCvt's H.265 intra
+ * encode hot path.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Section 1 is the reference's own interface for this path, symbol for symbol, so the reference's
+ * main.c / imageio_hevc.c link against this library unchanged.
+ * Section 2 is the batch / device-resident surface the reference does not have (its file loop,
+ * src/main.c:162, is the seam it plugs into).
+ *
+ * Every entry point needs a visible gfx950 device.  There is no CPU fallback: without a device the
+ * encoders return IMCVT_ERR_NO_DEVICE (<0) after printing one line to stderr.
+ */
+#ifndef IMCVT_HEVC_H
+#define IMCVT_HEVC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMCVT_ERR_NO_DEVICE  (-1)
+#define IMCVT_ERR_HIP        (-2)
+#define IMCVT_ERR_ARG        (-3)
+
+/* ---------------------------------------------------------------------------------------------------
+ * 1. Drop-in replacements
+ * --------------------------------------------------------------------------------------------------- */
+
+/* Replaces HEVCImageEncoder — reference src/HEVCe/HEVCe.h:5-12, defined src/HEVCe/HEVCe.c:1569-1646.
+ * Same arguments, same ownership (caller owns every buffer, all HOST pointers), same results:
+ *   pbuffer   out: the .h265 byte stream (caller sizes it as src/imageio_hevc.c:14 does)
+ *   img       in : ysz*xsz gray8, tightly packed
+ *   img_rcon  out: reconstruction, yszn*xszn bytes with the PADDED stride xszn
+ *   ysz,xsz   in : true size; out: size padded to a multiple of 32 (capped at 8192, :1580-1581)
+ *   qpd6      0..4 (not validated by the reference; this library returns IMCVT_ERR_ARG outside 0..4)
+ * Returns the stream length in bytes (>0), or a negative IMCVT_ERR_* (the reference's caller treats
+ * <=0 as failure, src/imageio_hevc.c:38).  Thread-safe (internally serialised). */
+int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
+                     int *ysz, int *xsz, const int qpd6);
+
+/* Replaces writeHEVCImageFile — reference src/imageio.h:21, defined src/imageio_hevc.c:9-53.
+ * RGB input: prints the reference's warning and encodes the green channel (:21-27).
+ * Returns 0 on success, 1 on failure (allocation, encoder, fopen, short write). */
+int writeHEVCImageFile(const char *p_filename, const uint8_t *p_buf, int is_rgb,
+                       uint32_t height, uint32_t width, int qpd6);
+
+/* ---------------------------------------------------------------------------------------------------
+ * 2. Batch surface (new; per-frame semantics identical to HEVCImageEncoder)
+ * --------------------------------------------------------------------------------------------------- */
+
+/* n independent frames with HOST pointers: frames are copied to the device, encoded concurrently (one
+ * workgroup per frame) and copied back.  ysz[i]/xsz[i] are updated to the padded sizes, out_len[i]
+ * receives each stream length.  Returns 0, or a negative IMCVT_ERR_*.   */
+int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
+                          unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len);
+
+/* One frame of a device-resident batch.  All pointers are DEVICE pointers (hipMalloc / torch). */
+typedef struct imcvt_hevc_frame {
+    const unsigned char *d_img;    /* h*w gray8                                              */
+    unsigned char       *d_out;    /* stream buffer, >= imcvt_hevc_stream_bound(h,w) bytes   */
+    unsigned char       *d_rcon;   /* hp*wp reconstruction (padded stride)                   */
+    int                 *d_len;    /* receives the stream length                             */
+    int                  h, w;     /* true size                                              */
+    int                  qpd6;     /* 0..4                                                   */
+} imcvt_hevc_frame;
+
+typedef struct imcvt_hevc_ctx imcvt_hevc_ctx;
+
+/* Creates an encoder context on the current HIP device: uploads the constant tables and allocates the
+ * per-workgroup scratch for up to max_workgroups concurrent frames (0 = 2 per compute unit).
+ * Returns NULL when no device is present. */
+imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups);
+void            imcvt_hevc_destroy(imcvt_hevc_ctx *ctx);
+
+/* Worst-case stream bytes for an h x w frame (the reference's own bound, src/imageio_hevc.c:14). */
+long long imcvt_hevc_stream_bound(int h, int w);
+/* Padded dimension ((min(v,8192)+31)/32*32, reference :1580-1581). */
+int imcvt_hevc_padded(int v);
+
+/* Encodes n device-resident frames on `stream` (a hipStream_t, may be NULL for the default stream).
+ * Asynchronous: returns after the launch; results are valid once the stream has been synchronised.
+ * Returns 0 or a negative IMCVT_ERR_*. */
+int imcvt_hevc_encode_device(imcvt_hevc_ctx *ctx, int n, const imcvt_hevc_frame *frames, void *stream);
+
+/* Kernel-only time of the last imcvt_hevc_encode_device call on this context, in milliseconds, from HIP
+ * events recorded on the launch stream (synchronises that stream).  <0 if nothing was launched. */
+float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *ctx);
+
+/* Debug aid: decision trace of frame 0 of the next launch (8 ints per CU: y, x, size, kind, mode(s), cost, 0, 0)
+ * into a device buffer of cap ints; pass NULL to disable. */
+void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
+
+/* Library / build information, e.g. "imcvt_hevc gfx950 r1". */
+const char *imcvt_hevc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
