@@ -22,6 +22,7 @@ typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
 #define I32MAX 0x7fffffff
 
 #ifdef IMCVT_HOSTEMU
+  struct uint2 { uint32_t x, y; }; struct int4 { int32_t x, y, z, w; };
   #define HD static inline
   #define HDN static
   #define LANES(l) for (int l = 0; l < 64; ++l)
@@ -47,6 +48,31 @@ typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
   HD int clz32(u32 v) { return __clz((int)v); }
 #endif
 
+#if defined(IMCVT_HOSTEMU)
+#define SCHED_FENCE() do {} while (0)
+#define NOUNROLL
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define NOUNROLL _Pragma("unroll 1")
+#endif
+struct alignas(16) U4 { u32 x, y, z, w; };
+// Global-memory accessors.  Pointers that come out of structs are generic ("flat") to the compiler, and FLAT
+// instructions count against lgkmcnt — every LDS wait would then also wait for a global round trip.
+// These force address space 1 (global_* instructions, vmcnt only).
+#ifdef IMCVT_HOSTEMU
+HD void g_st8(u8 *p, int v) { *p = (u8)v; }
+HD void g_st16(i16 *p, int v) { *p = (i16)v; }
+HD u8 g_ld8(const u8 *p) { return *p; }
+HD i16 g_ld16(const i16 *p) { return *p; }
+HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
+#else
+#define GAS __attribute__((address_space(1)))
+HD void g_st8(u8 *p, int v) { *(GAS u8 *)p = (u8)v; }
+HD void g_st16(i16 *p, int v) { *(GAS i16 *)p = (i16)v; }
+HD u8 g_ld8(const u8 *p) { return *(const GAS u8 *)p; }
+HD i16 g_ld16(const i16 *p) { return *(const GAS i16 *)p; }
+HD U4 g_ld128(const void *p) { const GAS U4 *g = (const GAS U4 *)p; U4 r; r.x = g->x; r.y = g->y; r.z = g->z; r.w = g->w; return r; }
+#endif
 HD int iabs(int v) { return v < 0 ? -v : v; }
 HD int imin(int a, int b) { return a < b ? a : b; }
 HD int imax(int a, int b) { return a > b ? a : b; }
@@ -71,6 +97,7 @@ struct Tables {
     u8  incg_rank[3][16];  // inverse: [type][yi*4+xi] -> n
     u32 lps4[64];          // rangeTabLps rows packed little-endian                                       (:703-712)
     u8  nextlps[128];      // packed-state transition on LPS                                              (:701)
+    uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8        (:700-712)
     u32 posadd[4][3];      // sig_coeff ctx increment per in-group scan position, 2 bits each [pattern][type]  (:1115-1120)
     u64 c4tab[3];          // 4x4-TU sig_coeff ctx per scan position, 4 bits each [type]                  (:1092)
     u8  ctx_init[5][CTX_STRIDE];   // initial context states per qpd6                                    (:726-784)
@@ -82,15 +109,128 @@ HD int mat_off(int s) { return s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336; }
 // ---------------------------------------------------------------------------------------------------
 // Arithmetic coder state (:796-805) — `cnt` counts bytes of the current CTU already pushed.
 // ---------------------------------------------------------------------------------------------------
+enum { PF_BORDER = 0, PF_P1_32, PF_P1_16, PF_P1_8, PF_P1_4, PF_P2_32, PF_P2_16, PF_P2_8, PF_P2_PU, PF_P2_NXN, PF_SYNC, PF_DECIDE, PF_RECON, PF_CTUIO, PF_T_SETUP, PF_T_HDR, PF_T_GEN, PF_T_DRAIN, PF_T_NDRAIN, PF_T_NTOK, PF_N };
 struct Arith { i32 range, low, nbits, nbytes, bufbyte, zeros, cnt; };
 HD void arith_reset(Arith &a) { a.range = 510; a.low = 0; a.nbits = 23; a.nbytes = 0; a.bufbyte = 0xFF; a.zeros = 0; a.cnt = 0; }
 HD int arith_len(const Arith &a) { return 8 * (a.cnt + a.nbytes) + 23 - a.nbits; }      // :834
 
+// ---------------------------------------------------------------------------------------------------
+// Workgroup memory
+// ---------------------------------------------------------------------------------------------------
+#define RS 68            // reconstruction tile stride: 1 border column + 64, padded
+#define FIFO_CAP 36
+#define FIFO_STRIDE 38   // u16 units per lane (odd dword stride: conflict-free when lanes read the same slot)
+
+struct Border {          // prediction references of one block (:196-257): unfiltered / [1 2 1]-filtered
+    u8 uc, fc; i16 dc;
+    u8 ul[68], ua[68], fl[68], fa[68];
+};
+struct BorderS {         // same for blocks <= 16 (the four-TU shape keeps one per mode)
+    u8 uc, fc; i16 dc;
+    u8 ul[36], ua[36], fl[36], fa[36];
+};
+
+struct alignas(16) WaveMem {
+    union alignas(16) {
+        struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                 // one pipeline pass
+        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) i16 lvl[NMODE][16]; } p2;                      // trial coders
+    } u;
+    Border  bsh;                 // border shared by all modes of a block
+    u8  rec4[NMODE][16];         // 4x4 PU candidates' reconstructions
+    i32 last[4][NMODE];          // per TU: last significant scan position (-1: none)
+    u32 cgm[4][NMODE][2];        // per TU: significant-group bitmap, bit gy*8+gx
+    i32 sse[NMODE];
+    i32 cost[NMODE];
+    Arith fin[NMODE];            // coder state each trial ended in
+    // NxN bookkeeping (PU wave)
+    i32 pu_mode[4], pu_sse[4], pu_last[4];
+    i32 nxn_cost;
+};
+
+// Per-frame job and per-workgroup scratch (global memory)
+struct FrameJob {
+    const u8 *img;   // h*w gray8
+    u8 *out;         // stream buffer
+    u8 *rcon;        // hp*wp reconstruction
+    i32 h, w, hp, wp, q;
+    i32 hdr_len;     // header bytes already placed at out[0..hdr_len)
+    i32 *out_len;    // result
+};
+struct Scratch {
+    i16 *lv;         // [NWAVES][NMODE*1024] quantised levels in scan order
+    u8  *bytes;      // [NWAVES][NMODE][TRIAL_BYTES] bytes emitted by trial coders
+    u8  *above_sz;   // [wp/4] CU sizes of the CTU row above (:1633-1636)
+    i32 *trace;      // optional decision trace (8 ints per CU), or null
+    unsigned long long *prof;   // optional [NWAVES][PF_N] cycle totals (IMCVT_PROF builds), or null
+    i32 trace_cap;
+};
+#define TRIAL_BYTES 3584
+#define LV_PER_WAVE (NMODE * 1024)
+
+struct FrameCtx {
+    FrameJob job;
+    Scratch sc;
+    i32 out_pos;        // bytes of finished CTUs (incl. headers)
+    i32 ctu_y, ctu_x;   // pixel origin of the current CTU
+    i32 trace_n;
+};
+
+struct FourTU {                  // state of the four-TU shape (one wave evaluates it at a time)
+    BorderS bc[NMODE];           // per-mode borders of TUs 1..3
+    u8  t3row[NMODE][4][16];     // per mode: bottom row / right column of each reconstructed TU
+    u8  t3col[NMODE][4][16];
+};
+
+struct alignas(16) Shm {
+    alignas(16) Tables T;
+    FrameCtx F;                  // per-frame context (kept in LDS so that callees read it with ds_* ops)
+    alignas(16) u8 org[32][32];
+    alignas(16) u8 rec[33][RS];             // rec[y+1][x+1]; row 0 / column 0 are the neighbours
+    u8  cx[CTX_STRIDE];          // live contexts
+    Arith live;
+    Arith entry_a[3];            // coder + contexts on entry to the CU of depth 0/1/2
+    u8  entry_cx[3][CTX_STRIDE];
+    u8  mapsz[10][12], mapmode[10][12];   // 4x4-unit neighbour maps of this CTU with a 1-cell apron (:1591-1599)
+    i32 split_cost[3];
+    i32 win_kind, win_mode;      // decision broadcast
+    i32 red[NWAVES];             // small reductions
+#ifdef IMCVT_PROF
+    unsigned long long prof[NWAVES][PF_N];
+#endif
+    FourTU X;
+    WaveMem W[NWAVES];
+};
+
+// The workgroup's LDS image is one file-scope object, so non-inlined callees still address it with ds_* ops.
+#ifdef IMCVT_HOSTEMU
+static Shm *g_shm_host;
+#define SM (*g_shm_host)
+#else
+__shared__ Shm g_shm;
+#define SM g_shm
+#endif
+
+// Optional cycle accounting per wave (build with -DIMCVT_PROF): category -> accumulated shader clocks
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+HD long long prof_now() { return clock64(); }
+HD void prof_add(int cat, long long t0) { if ((threadIdx.x & 63u) == 0) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)(clock64() - t0); }
+#else
+HD long long prof_now() { return 0; }
+HD void prof_add(int, long long) {}
+#endif
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)n; }
+#else
+HD void prof_cnt(int, int) {}
+#endif
+// workgroup barrier whose wait time is booked under PF_SYNC
+HD void wg_sync_p() { const long long t = prof_now(); wg_sync(); prof_add(PF_SYNC, t); }
+
 // sink[a.cnt] is where the next byte goes
 HD void emit_byte(Arith &a, u8 *sink, int v) {                                             // :820-831
     v &= 0xFF;
-    if (a.zeros >= 2 && v <= 3) { sink[a.cnt++] = 3; a.zeros = 0; }
-    sink[a.cnt++] = (u8)v;
+    if (a.zeros >= 2 && v <= 3) { g_st8(sink + a.cnt++, 3); a.zeros = 0; }
+    g_st8(sink + a.cnt++, v);
     a.zeros = v ? 0 : a.zeros + 1;
 }
 HD void carry_out(Arith &a, u8 *sink) {                                                    // :858-878
@@ -108,7 +248,8 @@ HD void carry_out(Arith &a, u8 *sink) {                                         
         } else { a.nbytes = 1; a.bufbyte = lead; }
     }
 }
-HD void code_bin(Arith &a, u8 *cx, const Tables &T, u8 *sink, int ci, int bin) {          // :913-932
+HD void code_bin(Arith &a, u8 *cx, u8 *sink, int ci, int bin) {
+    const Tables &T = SM.T;          // :913-932
     const int p = cx[ci];
     const int lps = (int)((T.lps4[p >> 1] >> (((a.range >> 6) & 3) * 8)) & 0xFF);
     a.range -= lps;
@@ -162,76 +303,6 @@ HD int level_rate(int level) {
     return 92000 + ((4 + 2 * i) << 15);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Workgroup memory
-// ---------------------------------------------------------------------------------------------------
-#define RS 68            // reconstruction tile stride: 1 border column + 64, padded
-#define FIFO_CAP 64
-#define FIFO_STRIDE 66   // u16 units per lane (odd dword stride: conflict-free when lanes read the same slot)
-
-struct Border {          // prediction references of one block (:196-257): unfiltered / [1 2 1]-filtered
-    u8 uc, fc; i16 dc;
-    u8 ul[68], ua[68], fl[68], fa[68];
-};
-struct BorderS {         // same for blocks <= 16 (the four-TU shape keeps one per mode)
-    u8 uc, fc; i16 dc;
-    u8 ul[36], ua[36], fl[36], fa[36];
-};
-
-struct WaveMem {
-    union {
-        struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                 // one pipeline pass
-        struct { u8 cx[NMODE][CTX_STRIDE]; u16 fifo[NMODE][FIFO_STRIDE]; i16 mag[NMODE][16]; } p2;   // trial coders
-    } u;
-    Border  bsh;                 // border shared by all modes of a block
-    BorderS bc[NMODE];           // per-mode borders (four-TU shape, TUs 1..3)
-    u8  t3row[NMODE][4][16];     // per mode: bottom row / right column of each reconstructed TU
-    u8  t3col[NMODE][4][16];
-    u8  rec4[NMODE][16];         // 4x4 PU candidates' reconstructions
-    i32 last[4][NMODE];          // per TU: last significant scan position (-1: none)
-    u32 cgm[4][NMODE][2];        // per TU: significant-group bitmap, bit gy*8+gx
-    i32 sse[NMODE];
-    i32 cost[NMODE];
-    Arith fin[NMODE];            // coder state each trial ended in
-    // NxN bookkeeping (PU wave)
-    i32 pu_mode[4], pu_sse[4], pu_last[4];
-    i16 pu_lv[4][16];
-    i32 nxn_cost;
-};
-
-struct Shm {
-    Tables T;
-    u8  org[32][32];
-    u8  rec[33][RS];             // rec[y+1][x+1]; row 0 / column 0 are the neighbours
-    u8  cx[CTX_STRIDE];          // live contexts
-    Arith live;
-    Arith entry_a[3];            // coder + contexts on entry to the CU of depth 0/1/2
-    u8  entry_cx[3][CTX_STRIDE];
-    u8  mapsz[10][12], mapmode[10][12];   // 4x4-unit neighbour maps of this CTU with a 1-cell apron (:1591-1599)
-    i32 split_cost[3];
-    i32 win_kind, win_mode;      // decision broadcast
-    i32 red[NWAVES];             // small reductions
-    WaveMem W[NWAVES];
-};
-
-// Per-frame job and per-workgroup scratch (global memory)
-struct FrameJob {
-    const u8 *img;   // h*w gray8
-    u8 *out;         // stream buffer
-    u8 *rcon;        // hp*wp reconstruction
-    i32 h, w, hp, wp, q;
-    i32 hdr_len;     // header bytes already placed at out[0..hdr_len)
-    i32 *out_len;    // result
-};
-struct Scratch {
-    i16 *lv;         // [NWAVES][NMODE*1024] quantised levels in scan order
-    u8  *bytes;      // [NWAVES][NMODE][TRIAL_BYTES] bytes emitted by trial coders
-    u8  *above_sz;   // [wp/4] CU sizes of the CTU row above (:1633-1636)
-    i32 *trace;      // optional decision trace (8 ints per CU), or null
-    i32 trace_cap;
-};
-#define TRIAL_BYTES 3584
-#define LV_PER_WAVE (NMODE * 1024)
 
 // ---------------------------------------------------------------------------------------------------
 // Prediction (:262-381), evaluated per pixel
@@ -243,8 +314,8 @@ HD int uses_filtered(int N, int mode) {            // :274-280 as a distance-to-
     return d > (N == 8 ? 7 : N == 16 ? 1 : 0);
 }
 
-template <class B>
-HD int pred_px(const Tables &T, const B &b, int N, int lg, int mode, int y, int x) {
+struct BorderRef { const u8 *ul, *ua, *fl, *fa; int uc, fc, dc; };
+HD int pred_px(const Tables &T, const BorderRef &b, int N, int lg, int mode, int y, int x) {
     const int f = uses_filtered(N, mode);
     const u8 *L = f ? b.fl : b.ul, *A = f ? b.fa : b.ua;
     const int corner = f ? b.fc : b.uc;
@@ -279,11 +350,12 @@ HD int pred_px(const Tables &T, const B &b, int N, int lg, int mode, int y, int 
 // Border assembly
 // ---------------------------------------------------------------------------------------------------
 // Shared border of the block at (y0,x0) from the reconstruction tile.  Wave-uniform call.
-HD void border_from_tile(Shm &S, WaveMem &W, int N, int y0, int x0, int hl, int hbl, int ha, int har) {
+HDN void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int ha, int har) {
+    WaveMem &W = SM.W[wave];
     Border &b = W.bsh;
     const int n2 = 2 * N;
     LANES(l) {
-        const u8 *t = &S.rec[y0 + 1][x0 + 1];
+        const u8 *t = &SM.rec[y0 + 1][x0 + 1];
         int uc = (hl && ha) ? t[-RS - 1] : hl ? t[-1] : ha ? t[-RS] : 128;
         if (l < n2) {
             int lv_, av_;
@@ -317,28 +389,29 @@ HD void border_from_tile(Shm &S, WaveMem &W, int N, int y0, int x0, int hl, int 
 
 // Per-mode borders of TU k (1..3) of the four-TU shape of the CU at (y0,x0,N): samples inside the CU come
 // from that mode's own reconstruction of TUs < k (:1459,1466), the rest from the tile.
-HD void border_tu_split(Shm &S, WaveMem &W, int N, int y0, int x0, int k, int hl, int hbl, int ha, int har) {
+HDN void border_tu_split(int wave, int N, int y0, int x0, int k, int hl, int hbl, int ha, int har) {
+    WaveMem &W = SM.W[wave];
     const int h = N / 2, n2 = N;   // 2*h entries per side
     LANES(l) {
         for (int e = l; e < NMODE * n2; e += 64) {
             const int c = e / n2, i = e - c * n2;
-            BorderS &b = W.bc[c];
+            BorderS &b = SM.X.bc[c];
             int uc, lv_, av_;
             if (k == 1) {
-                const u8 *col0 = W.t3col[c][0];
-                const u8 *ab = &S.rec[y0][x0 + h + 1];                     // row y0-1, starting at column x0+h
+                const u8 *col0 = SM.X.t3col[c][0];
+                const u8 *ab = &SM.rec[y0][x0 + h + 1];                     // row y0-1, starting at column x0+h
                 uc = ha ? ab[-1] : col0[0];
                 lv_ = (i < h) ? col0[i] : col0[h - 1];
                 av_ = (i < h) ? (ha ? ab[i] : uc) : (har ? ab[i] : (ha ? ab[h - 1] : uc));
             } else if (k == 2) {
-                const u8 *lf = &S.rec[y0 + h + 1][x0];                     // column x0-1, starting at row y0+h
-                const u8 *row0 = W.t3row[c][0], *row1 = W.t3row[c][1];
+                const u8 *lf = &SM.rec[y0 + h + 1][x0];                     // column x0-1, starting at row y0+h
+                const u8 *row0 = SM.X.t3row[c][0], *row1 = SM.X.t3row[c][1];
                 uc = hl ? lf[-RS] : row0[0];
                 lv_ = (i < h) ? (hl ? lf[i * RS] : uc) : (hbl ? lf[i * RS] : (hl ? lf[(h - 1) * RS] : uc));
                 av_ = (i < h) ? row0[i] : row1[i - h];
             } else {
-                const u8 *col2 = W.t3col[c][2], *row1 = W.t3row[c][1];
-                uc = W.t3row[c][0][h - 1];
+                const u8 *col2 = SM.X.t3col[c][2], *row1 = SM.X.t3row[c][1];
+                uc = SM.X.t3row[c][0][h - 1];
                 lv_ = (i < h) ? col2[i] : col2[h - 1];
                 av_ = (i < h) ? row1[i] : row1[h - 1];
             }
@@ -350,7 +423,7 @@ HD void border_tu_split(Shm &S, WaveMem &W, int N, int y0, int x0, int k, int hl
     LANES(l) {
         for (int e = l; e < NMODE * n2; e += 64) {
             const int c = e / n2, i = e - c * n2;
-            BorderS &b = W.bc[c];
+            BorderS &b = SM.X.bc[c];
             int fl_, fa_;
             if (i == 0) { fl_ = (2 + 2 * b.ul[0] + b.ul[1] + b.uc) >> 2; fa_ = (2 + 2 * b.ua[0] + b.ua[1] + b.uc) >> 2; }
             else if (i == n2 - 1) { fl_ = b.ul[i]; fa_ = b.ua[i]; }
@@ -358,7 +431,7 @@ HD void border_tu_split(Shm &S, WaveMem &W, int N, int y0, int x0, int k, int hl
             b.fl[i] = (u8)fl_; b.fa[i] = (u8)fa_;
         }
         if (l < NMODE) {
-            BorderS &b = W.bc[l];
+            BorderS &b = SM.X.bc[l];
             int dc = h;
             for (int i = 0; i < h; i++) dc += b.ul[i] + b.ua[i];
             b.dc = (i16)(dc / (2 * h));
@@ -378,162 +451,217 @@ enum { OUT_NONE = 0, OUT_REC4 = 1, OUT_T3SIDE = 2, OUT_TILE = 3 };
 struct P1Args {
     int N, y0, x0;       // block inside the CTU
     int k;               // TU slot for last/cgm/levels
-    int per_mode_border; // 0: W.bsh, 1: W.bc[c]
+    int per_mode_border; // 0: W.bsh, 1: SM.X.bc[c]
     int out_kind;        // what to keep of the reconstruction
     int only_mode;       // -1: all 35 modes, else just this one (winner reconstruction)
     i16 *lv;             // global levels base for this TU: [c][N*N], scan order (may be null for only_mode)
     int q;
 };
 
-HD void p1_run(Shm &S, WaveMem &W, const P1Args &P) {
-    const Tables &T = S.T;
-    const int N = P.N, lg = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5, s = lg - 2;
-    const int nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
+// sign-extended byte kk of a packed word / i16 halves of a packed word
+HD int sx8(u32 w, int kk) { return (int)(i8)(w >> (8 * kk)); }
+HD int lo16(u32 w) { return (int)(i16)(w & 0xFFFFu); }
+HD int hi16(u32 w) { return (int)w >> 16; }
+
+// acc[r][c] += sum_kk M[row0+r][k0+kk] * X[k0+kk][col0+c]      (M: i8 matrix rows, X: i16 rows of stride N)
+template <int N>
+HD void mac_MX(int acc[4][4], const i8 *M, const i16 *X, int row0, int col0) {
+    NOUNROLL
+    for (int k0 = 0; k0 < N; k0 += 4) {
+        u32 mw[4];
+        for (int r = 0; r < 4; r++) mw[r] = *(const u32 *)(M + (row0 + r) * N + k0);
+        for (int kk = 0; kk < 4; kk++) {
+            const uint2 xw = *(const uint2 *)(X + (k0 + kk) * N + col0);
+            const int x0 = lo16(xw.x), x1 = hi16(xw.x), x2 = lo16(xw.y), x3 = hi16(xw.y);
+            for (int r = 0; r < 4; r++) {
+                const int m = sx8(mw[r], kk);
+                acc[r][0] += m * x0; acc[r][1] += m * x1; acc[r][2] += m * x2; acc[r][3] += m * x3;
+            }
+        }
+    }
+}
+// acc[r][c] += sum_kk Y[row0+r][k0+kk] * M[col0+c][k0+kk]      (Y: i32 rows of stride N)
+template <int N>
+HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0) {
+    NOUNROLL
+    for (int k0 = 0; k0 < N; k0 += 4) {
+        u32 mw[4];
+        for (int c = 0; c < 4; c++) mw[c] = *(const u32 *)(M + (col0 + c) * N + k0);
+        for (int r = 0; r < 4; r++) {
+            const int4 y = *(const int4 *)(Y + (row0 + r) * N + k0);
+            for (int c = 0; c < 4; c++)
+                acc[r][c] += y.x * sx8(mw[c], 0) + y.y * sx8(mw[c], 1) + y.z * sx8(mw[c], 2) + y.w * sx8(mw[c], 3);
+        }
+    }
+}
+// same with i16 rows
+template <int N>
+HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *M, int row0, int col0) {
+    NOUNROLL
+    for (int k0 = 0; k0 < N; k0 += 4) {
+        u32 mw[4];
+        for (int c = 0; c < 4; c++) mw[c] = *(const u32 *)(M + (col0 + c) * N + k0);
+        for (int r = 0; r < 4; r++) {
+            const uint2 yw = *(const uint2 *)(Y + (row0 + r) * N + k0);
+            const int y0 = lo16(yw.x), y1 = hi16(yw.x), y2 = lo16(yw.y), y3 = hi16(yw.y);
+            for (int c = 0; c < 4; c++)
+                acc[r][c] += y0 * sx8(mw[c], 0) + y1 * sx8(mw[c], 1) + y2 * sx8(mw[c], 2) + y3 * sx8(mw[c], 3);
+        }
+    }
+}
+
+template <int LG>
+HDN void p1_run_t(int wave, const P1Args P) {
+    constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
+    WaveMem &W = SM.W[wave];
+    const Tables &T = SM.T;
     const i8 *C = T.C + mat_off(s), *CT = T.CT + mat_off(s);
     const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
     const int q = P.q;
     // quantiser constants (:546-554)
-    const int a1 = s + 1, b1 = a1 + 7, ra = 1 << a1 >> 1, rb = 1 << b1 >> 1;
-    const int dsh = 8 - s, sh = 19 - s + q, add = 1 << sh >> 1, dmax = I32MAX - add, thr = 9 << sh >> 2;
+    constexpr int a1 = s + 1, b1 = a1 + 7, ra = 1 << a1 >> 1, rb = 1 << b1 >> 1, dsh = 8 - s;
+    const int sh = 19 - s + q, add = 1 << sh >> 1, dmax = I32MAX - add, thr = 9 << sh >> 2;
     const int dq = 1 << (5 - s + q);
     const RdW rw = rd_weights(q);
 
+    NOUNROLL
     for (int c0 = 0; c0 < ncand; c0 += G) {
         // ---- step 1: prediction and residual
         LANES(l) {
-            const int sl = l / lpc, blk = l - sl * lpc, by = blk / nb, bx = blk - by * nb, c = c0 + sl;
+            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
             if (c < ncand) {
                 const int mode = (P.only_mode >= 0) ? P.only_mode : c;
                 u8 *pp = W.u.p1.pred + sl * NN; i16 *rp = W.u.p1.res + sl * NN;
-                for (int yi = 0; yi < 4; yi++) for (int xi = 0; xi < 4; xi++) {
-                    const int y = by * 4 + yi, x = bx * 4 + xi;
-                    const int p = P.per_mode_border ? pred_px(T, W.bc[c], N, lg, mode, y, x) : pred_px(T, W.bsh, N, lg, mode, y, x);
+                BorderRef br;
+                if (P.per_mode_border) { const BorderS &b = SM.X.bc[c]; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
+                else { const Border &b = W.bsh; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
+                NOUNROLL
+                for (int pi = 0; pi < 16; pi++) {
+                    const int y = by * 4 + (pi >> 2), x = bx * 4 + (pi & 3);
+                    const int p = pred_px(T, br, N, LG, mode, y, x);
                     pp[y * N + x] = (u8)p;
-                    rp[y * N + x] = (i16)((int)S.org[P.y0 + y][P.x0 + x] - p);
+                    rp[y * N + x] = (i16)((int)SM.org[P.y0 + y][P.x0 + x] - p);
                 }
             }
         }
         wave_sync();
         // ---- step 2: tmp = (C * res + ra) >> a                                              (:514 forward)
         LANES(l) {
-            const int sl = l / lpc, blk = l - sl * lpc, by = blk / nb, bx = blk - by * nb, c = c0 + sl;
+            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
             if (c < ncand) {
-                const i16 *rp = W.u.p1.res + sl * NN; i32 *tp = W.u.p1.tmp + sl * NN;
                 int acc[4][4];
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = ra;
-                for (int k0 = 0; k0 < N; k0 += 4) {
-                    int xv[4][4];
-                    for (int kk = 0; kk < 4; kk++) for (int cc = 0; cc < 4; cc++) xv[kk][cc] = rp[(k0 + kk) * N + bx * 4 + cc];
-                    for (int r = 0; r < 4; r++) {
-                        const i8 *cr = C + (by * 4 + r) * N + k0;
-                        for (int kk = 0; kk < 4; kk++) { const int cv = cr[kk]; for (int cc = 0; cc < 4; cc++) acc[r][cc] += cv * xv[kk][cc]; }
-                    }
+                mac_MX<N>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
+                i32 *tp = W.u.p1.tmp + sl * NN;
+                for (int r = 0; r < 4; r++) {
+                    int4 o; o.x = acc[r][0] >> a1; o.y = acc[r][1] >> a1; o.z = acc[r][2] >> a1; o.w = acc[r][3] >> a1;
+                    *(int4 *)(tp + (by * 4 + r) * N + bx * 4) = o;
                 }
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) tp[(by * 4 + r) * N + bx * 4 + cc] = acc[r][cc] >> a1;
             }
         }
         wave_sync();
         // ---- step 3: coef = (tmp * C^T + rb) >> b ; RDOQ ; levels out ; dequantise           (:515, :540-614)
         LANES(l) {
-            const int sl = l / lpc, blk = l - sl * lpc, by = blk / nb, bx = blk - by * nb, c = c0 + sl;
+            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
             if (c < ncand) {
                 const int mode = (P.only_mode >= 0) ? P.only_mode : c;
-                const i32 *tp = W.u.p1.tmp + sl * NN; i16 *dp = W.u.p1.res + sl * NN;
                 int acc[4][4];
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = rb;
-                for (int k0 = 0; k0 < N; k0 += 4) {
-                    int tv[4][4];
-                    for (int r = 0; r < 4; r++) for (int kk = 0; kk < 4; kk++) tv[r][kk] = tp[(by * 4 + r) * N + k0 + kk];
-                    for (int cc = 0; cc < 4; cc++) {
-                        const i8 *cr = C + (bx * 4 + cc) * N + k0;
-                        for (int kk = 0; kk < 4; kk++) { const int cv = cr[kk]; for (int r = 0; r < 4; r++) acc[r][cc] += tv[r][kk] * cv; }
-                    }
-                }
-                int lvl[4][4], sum = 0;
+                mac_YM32<N>(acc, W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
+                int sum = 0, any = 0;
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
                     const int cf = acc[r][cc] >> b1, av = iabs(cf);
                     const int d = (av > 0x1ffff) ? dmax : imin((av & 0x1ffff) << 14, dmax);
                     int lq = clip16((int)(((u32)d + (u32)add) >> sh));
-                    const int lo = imax(0, lq - 2);
-                    int best = I32MAX, pick = 0;
-                    for (; lq >= lo; lq--) {
-                        const int e = iabs(d - (lq << sh)) >> dsh;
-                        const int dist = ((e < 46340) ? e * e : I32MAX) >> 7;
-                        const int cost = rd_cost(rw, dist, level_rate(lq));
-                        if (cost < best) { best = cost; pick = lq; }
+                    int pick = 0;
+                    if (lq > 0) {                                   // level 0 alone needs no pricing
+                        const int lo = imax(0, lq - 2);
+                        int best = I32MAX;
+                        NOUNROLL
+                        for (; lq >= lo; lq--) {
+                            const int e = iabs(d - (lq << sh)) >> dsh;
+                            const int dist = ((e < 46340) ? e * e : I32MAX) >> 7;
+                            const int cost = rd_cost(rw, dist, level_rate(lq));
+                            if (cost < best) { best = cost; pick = lq; }
+                        }
                     }
-                    lvl[r][cc] = (cf < 0) ? -pick : pick;
+                    acc[r][cc] = (cf < 0) ? -pick : pick;
+                    any |= pick;
                     sum += imin(d, thr);
+                    SCHED_FENCE();
                 }
-                const int zero_out = sum < thr;
+                if (sum < thr) any = 0;                              // weak group: cleared (:588-591)
                 // scan bookkeeping: this lane's block is coefficient group (by,bx)
                 const int st = (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0;   // :1133-1141
                 const int g = T.cgrank[st][s][by * 8 + bx];
-                int hi = -1, any = 0;
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) { if (zero_out) lvl[r][cc] = 0; any |= lvl[r][cc]; }
-                i16 *lvg = (P.lv && any) ? P.lv + (size_t)c * NN + g * 16 : (i16 *)0;   // only coded groups are ever read back
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
-                    const int v = lvl[r][cc];
-                    const int n = T.incg_rank[st][r * 4 + cc];
-                    if (v) hi = imax(hi, n);
-                    if (lvg) lvg[n] = (i16)v;
-                    dp[(by * 4 + r) * N + bx * 4 + cc] = (i16)clip16(v * dq);
-                }
-                if (hi >= 0 && P.only_mode < 0) {
-                    lds_max(&W.last[P.k][c], g * 16 + hi);
-                    const int bit = by * 8 + bx;
-                    lds_or(&W.cgm[P.k][c][bit >> 5], 1u << (bit & 31));
+                i16 *dp = W.u.p1.res + sl * NN;
+                if (any) {
+                    int hi = 0;
+                    i16 *lvg = P.lv ? P.lv + (size_t)c * NN + g * 16 : (i16 *)0;     // only coded groups are ever read back
+                    for (int r = 0; r < 4; r++) {
+                        for (int cc = 0; cc < 4; cc++) {
+                            const int v = acc[r][cc];
+                            const int n = T.incg_rank[st][r * 4 + cc];
+                            if (v) hi = imax(hi, n);
+                            if (lvg) g_st16(lvg + n, v);
+                            acc[r][cc] = clip16(v * dq);
+                        }
+                        uint2 o; o.x = (u32)(acc[r][0] & 0xFFFF) | (u32)acc[r][1] << 16; o.y = (u32)(acc[r][2] & 0xFFFF) | (u32)acc[r][3] << 16;
+                        *(uint2 *)(dp + (by * 4 + r) * N + bx * 4) = o;
+                    }
+                    if (P.only_mode < 0) {
+                        lds_max(&W.last[P.k][c], g * 16 + hi);
+                        const int bit = by * 8 + bx;
+                        lds_or(&W.cgm[P.k][c][bit >> 5], 1u << (bit & 31));
+                    }
+                } else {
+                    uint2 z; z.x = 0; z.y = 0;
+                    for (int r = 0; r < 4; r++) *(uint2 *)(dp + (by * 4 + r) * N + bx * 4) = z;
                 }
             }
         }
         wave_sync();
         // ---- step 4: itmp = clip16((C^T * deq + 64) >> 7)                                    (:514 inverse)
         LANES(l) {
-            const int sl = l / lpc, blk = l - sl * lpc, by = blk / nb, bx = blk - by * nb, c = c0 + sl;
+            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
             if (c < ncand) {
-                const i16 *dp = W.u.p1.res + sl * NN; i16 *ip = (i16 *)W.u.p1.tmp + sl * NN;
                 int acc[4][4];
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = 64;
-                for (int k0 = 0; k0 < N; k0 += 4) {
-                    int xv[4][4];
-                    for (int kk = 0; kk < 4; kk++) for (int cc = 0; cc < 4; cc++) xv[kk][cc] = dp[(k0 + kk) * N + bx * 4 + cc];
-                    for (int r = 0; r < 4; r++) {
-                        const i8 *cr = CT + (by * 4 + r) * N + k0;
-                        for (int kk = 0; kk < 4; kk++) { const int cv = cr[kk]; for (int cc = 0; cc < 4; cc++) acc[r][cc] += cv * xv[kk][cc]; }
-                    }
+                mac_MX<N>(acc, CT, W.u.p1.res + sl * NN, by * 4, bx * 4);
+                i16 *ip = (i16 *)W.u.p1.tmp + sl * NN;       // tmp (i32) was last read in step 3; reuse it as i16
+                for (int r = 0; r < 4; r++) {
+                    uint2 o;
+                    o.x = (u32)(clip16(acc[r][0] >> 7) & 0xFFFF) | (u32)clip16(acc[r][1] >> 7) << 16;
+                    o.y = (u32)(clip16(acc[r][2] >> 7) & 0xFFFF) | (u32)clip16(acc[r][3] >> 7) << 16;
+                    *(uint2 *)(ip + (by * 4 + r) * N + bx * 4) = o;
                 }
-                // all lanes of this candidate must have finished reading tmp before it is overwritten as i16:
-                // they have — step 3 ended with a wave_sync and this step only reads `res`.
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) ip[(by * 4 + r) * N + bx * 4 + cc] = (i16)clip16(acc[r][cc] >> 7);
             }
         }
         wave_sync();
         // ---- step 5: rec = clip8(clip16((itmp * C + 2048) >> 12) + pred) ; SSE                (:515 inverse, :146,:165)
         LANES(l) {
-            const int sl = l / lpc, blk = l - sl * lpc, by = blk / nb, bx = blk - by * nb, c = c0 + sl;
+            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
             if (c < ncand) {
-                const i16 *ip = (const i16 *)W.u.p1.tmp + sl * NN; const u8 *pp = W.u.p1.pred + sl * NN;
+                const u8 *pp = W.u.p1.pred + sl * NN;
                 int acc[4][4];
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = 2048;
-                for (int k0 = 0; k0 < N; k0 += 4) {
-                    int tv[4][4];
-                    for (int r = 0; r < 4; r++) for (int kk = 0; kk < 4; kk++) tv[r][kk] = ip[(by * 4 + r) * N + k0 + kk];
-                    for (int cc = 0; cc < 4; cc++) {
-                        const i8 *cr = CT + (bx * 4 + cc) * N + k0;
-                        for (int kk = 0; kk < 4; kk++) { const int cv = cr[kk]; for (int r = 0; r < 4; r++) acc[r][cc] += tv[r][kk] * cv; }
-                    }
-                }
+                mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, CT, by * 4, bx * 4);
                 int part = 0;
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
-                    const int y = by * 4 + r, x = bx * 4 + cc;
-                    const int rc = clip3(clip16(acc[r][cc] >> 12) + pp[y * N + x], 0, 255);
-                    const int d = (int)S.org[P.y0 + y][P.x0 + x] - rc;
-                    part += d * d;
-                    if (P.out_kind == OUT_REC4) W.rec4[c][y * 4 + x] = (u8)rc;
-                    else if (P.out_kind == OUT_TILE) S.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
-                    else if (P.out_kind == OUT_T3SIDE) {
-                        if (y == N - 1) W.t3row[c][P.k][x] = (u8)rc;
-                        if (x == N - 1) W.t3col[c][P.k][y] = (u8)rc;
+                for (int r = 0; r < 4; r++) {
+                    const int y = by * 4 + r;
+                    const u32 pw = *(const u32 *)(pp + y * N + bx * 4);
+                    const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                    for (int cc = 0; cc < 4; cc++) {
+                        const int x = bx * 4 + cc;
+                        const int rc = clip3(clip16(acc[r][cc] >> 12) + (int)((pw >> (8 * cc)) & 255), 0, 255);
+                        const int d = (int)((ow >> (8 * cc)) & 255) - rc;
+                        part += d * d;
+                        if (P.out_kind == OUT_REC4) W.rec4[c][y * 4 + x] = (u8)rc;
+                        else if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
+                        else if (P.out_kind == OUT_T3SIDE) {
+                            if (y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
+                            if (x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
+                        }
                     }
                 }
                 if (P.only_mode < 0) lds_add(&W.sse[c], part);
@@ -543,24 +671,44 @@ HD void p1_run(Shm &S, WaveMem &W, const P1Args &P) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Trial coding.  Each lane binarises its candidate one unit at a time into a private token FIFO and
-// drains it through the arithmetic coder; the SIMT loop keeps the drain convergent across lanes.
-//   token: bit15=0 -> context bin  (ci<<1 | bin);  bit15=1 -> bypass chunk (n<<8 | value), n<=8
-// ---------------------------------------------------------------------------------------------------
-struct Fifo { u16 *buf; int n; };
-HD void tk_bin(Fifo &f, int ci, int bin) { f.buf[f.n++] = (u16)((ci << 1) | (bin & 1)); }
-HD void tk_bypass(Fifo &f, int v, int len) {                  // chunking of :898-910
-    v &= (1 << len) - 1;
-    while (len > 0) { const int n = imin(len, 8); len -= n; f.buf[f.n++] = (u16)(0x8000 | (n << 8) | ((v >> len) & ((1 << n) - 1))); }
+HD void p1_run(int wave, const P1Args &P) {
+    if (P.N == 32) p1_run_t<5>(wave, P);
+    else if (P.N == 16) p1_run_t<4>(wave, P);
+    else if (P.N == 8) p1_run_t<3>(wave, P);
+    else p1_run_t<2>(wave, P);
 }
-HD void fifo_drain(Fifo &f, Arith &a, u8 *cx, const Tables &T, u8 *sink) {
-    for (int i = 0; i < f.n; i++) {
-        const int t = f.buf[i];
-        if (t & 0x8000) code_bypass_chunk(a, sink, t & 0xFF, (t >> 8) & 0xF);
-        else code_bin(a, cx, T, sink, t >> 1, t & 1);
-    }
-    f.n = 0;
+
+// ---------------------------------------------------------------------------------------------------
+// Trial coding.  One lane codes one candidate with its own arithmetic coder + context copy.  Inside a
+// coefficient group the lanes walk the scan positions 15..0 TOGETHER (sig flags, then greater-1 flags,
+// then remaining levels), so every wave step is one predicated bin for all lanes: convergent code, no
+// token buffers.  Bit-exactness: same bins, same order, same <=8-bin bypass chunking as :898-1268.
+// ---------------------------------------------------------------------------------------------------
+#ifdef IMCVT_HOSTEMU
+#define WAVE_ANY(c) (c)
+#else
+#define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#endif
+
+struct Coder { Arith a; u8 *cx; u8 *sink; };
+
+HD void put_bin(Coder &c, int ci, int bin) {                                               // :913-932
+    Arith &a = c.a;
+    const int p = c.cx[ci];
+    const uint2 e = SM.T.pst[p];
+    const int lps = (int)((e.x >> (((a.range >> 6) & 3) * 8)) & 0xFF);
+    const int rm = a.range - lps;
+    const int is_lps = (bin ^ p) & 1;
+    const int sh = is_lps ? imin(6, clz32((u32)lps) - 23) : (rm < 256);
+    c.cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
+    a.low = (a.low + (is_lps ? rm : 0)) << sh;
+    a.range = (is_lps ? lps : rm) << sh;
+    a.nbits -= sh;
+    carry_out(a, c.sink);
+}
+HD void put_bypass(Coder &c, int v, int len) {                                             // :898-910
+    v &= (1 << len) - 1;
+    while (len > 0) { const int n = imin(len, 8); len -= n; code_bypass_chunk(c.a, c.sink, (v >> len) & ((1 << n) - 1), n); }
 }
 
 HD void mpm_list(int l, int a, int *m) {                       // :957-976
@@ -568,43 +716,49 @@ HD void mpm_list(int l, int a, int *m) {                       // :957-976
     else if (l > 1) { m[0] = l; m[1] = ((l + 29) & 31) + 2; m[2] = ((l - 1) & 31) + 2; }
     else { m[0] = 0; m[1] = 1; m[2] = 26; }
 }
-HD int mpm_hit(const int *m, int mode) { int h = -1; for (int j = 0; j < 3; j++) if (m[j] == mode) h = j; return h; }
-HD void tk_mode_rest(Fifo &f, int *m, int hit, int mode) {    // second half of :984-1017
-    if (hit >= 0) { tk_bypass(f, hit > 0, 1); if (hit > 0) tk_bypass(f, hit - 1, 1); }
+HD int scan_type_of(int N, int mode) { return (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0; }
+
+// prev_intra_luma_pred_flag of one PU; returns the hit index (or -1) and the sorted-descending candidates in m[]
+HD int luma_mode_flag(Coder &c, int ml, int ma, int mode, int *m) {
+    mpm_list(ml, ma, m);
+    const int hit = (m[2] == mode) ? 2 : (m[1] == mode) ? 1 : (m[0] == mode) ? 0 : -1;   // later entries win, as :992-994
+    put_bin(c, CX_PREV_INTRA, hit >= 0);
+    return hit;
+}
+HD void luma_mode_rest(Coder &c, int *m, int hit, int mode) {  // mpm_idx / rem_intra_luma_pred_mode (:998-1016)
+    if (hit >= 0) { put_bypass(c, hit > 0, 1); if (hit > 0) put_bypass(c, hit - 1, 1); }
     else {
         int t, r = mode;
         if (m[0] < m[1]) { t = m[0]; m[0] = m[1]; m[1] = t; }
         if (m[1] < m[2]) { t = m[1]; m[1] = m[2]; m[2] = t; }
         if (m[0] < m[1]) { t = m[0]; m[0] = m[1]; m[1] = t; }
-        for (int j = 0; j < 3; j++) if (r > m[j]) r--;
-        tk_bypass(f, r, 5);
+        r -= (r > m[0]); r -= (r > m[1]); r -= (r > m[2]);
+        put_bypass(c, r, 5);
     }
 }
 
-HD int scan_type_of(int N, int mode) { return (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0; }
-
-HD void tk_last_pos(Fifo &f, int N, int s, int st, int y, int x) {          // :1045-1086
+HD void put_last_pos(Coder &c, int s, int st, int y, int x) {                               // :1045-1086
     const int base = (s == 0) ? 0 : (s == 1) ? 3 : (s == 2) ? 6 : 10, shf = (s == 0) ? 0 : 1;
-    int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;
+    const int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;
     // group index of a coordinate: 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8*8,9*8
     const int gx = tx < 4 ? tx : (2 * (31 - clz32((u32)tx)) + ((tx >> (30 - clz32((u32)tx))) & 1));
     const int gy = ty < 4 ? ty : (2 * (31 - clz32((u32)ty)) + ((ty >> (30 - clz32((u32)ty))) & 1));
     const int gmax = 2 * (s + 2) - 1;                                         // group of N-1
-    for (int i = 0; i < gx; i++) tk_bin(f, CX_LAST_X + base + (i >> shf), 1);
-    if (gx < gmax) tk_bin(f, CX_LAST_X + base + (gx >> shf), 0);
-    for (int i = 0; i < gy; i++) tk_bin(f, CX_LAST_Y + base + (i >> shf), 1);
-    if (gy < gmax) tk_bin(f, CX_LAST_Y + base + (gy >> shf), 0);
-    if (gx > 3) { const int nb_ = (gx - 2) >> 1, mn = (2 + (gx & 1)) << (nb_); for (int i = nb_ - 1; i >= 0; i--) tk_bypass(f, ((tx - mn) >> i) & 1, 1); }
-    if (gy > 3) { const int nb_ = (gy - 2) >> 1, mn = (2 + (gy & 1)) << (nb_); for (int i = nb_ - 1; i >= 0; i--) tk_bypass(f, ((ty - mn) >> i) & 1, 1); }
+    for (int i = 0; i < gx; i++) put_bin(c, CX_LAST_X + base + (i >> shf), 1);
+    if (gx < gmax) put_bin(c, CX_LAST_X + base + (gx >> shf), 0);
+    for (int i = 0; i < gy; i++) put_bin(c, CX_LAST_Y + base + (i >> shf), 1);
+    if (gy < gmax) put_bin(c, CX_LAST_Y + base + (gy >> shf), 0);
+    if (gx > 3) { const int nb_ = (gx - 2) >> 1, mn = (2 + (gx & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) put_bypass(c, ((tx - mn) >> i) & 1, 1); }
+    if (gy > 3) { const int nb_ = (gy - 2) >> 1, mn = (2 + (gy & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) put_bypass(c, ((ty - mn) >> i) & 1, 1); }
 }
 
-HD void tk_remaining(Fifo &f, int v, int k) {                                // :1153-1168
-    if (v < (3 << k)) { const int p = v >> k; tk_bypass(f, (1 << (p + 1)) - 2, p + 1); tk_bypass(f, v & ((1 << k) - 1), k); }
+HD void put_remaining(Coder &c, int v, int k) {                                            // :1153-1168
+    if (v < (3 << k)) { const int p = v >> k; put_bypass(c, (1 << (p + 1)) - 2, p + 1); put_bypass(c, v & ((1 << k) - 1), k); }
     else {
         int n = k; v -= 3 << k;
         for (; v >= (1 << n); n++) v -= 1 << n;
         const int t = 4 + n - k;
-        tk_bypass(f, (1 << t) - 2, t); tk_bypass(f, v, n);
+        put_bypass(c, (1 << t) - 2, t); put_bypass(c, v, n);
     }
 }
 
@@ -614,45 +768,56 @@ struct TrialJob {
     int shape;          // 0: 2Nx2N one TU, 1: 2Nx2N four TUs, 2: NxN, 3: residual of one 4x4 TU only (PU pricing, :1515)
     int ctx_split;      // context of split_cu_flag=0, or -1 when the flag is absent
     int mode[4], ml[4], ma[4];
-    const i16 *lv[4];   // scan-ordered levels per TU
+    const i16 *lv[4];   // scan-ordered levels per TU (global memory)
     int last[4];        // last significant scan position per TU (-1: all zero)
     u32 cg0[4], cg1[4]; // significant-group bitmaps
 };
 
-// Code the whole job on (a, cx).  mag: 16 x i16 lane-private scratch.
-HD void trial_run(const Tables &T, const TrialJob &J, Arith &a, u8 *cx, u8 *sink, Fifo &f, i16 *mag) {
+// Code the whole job.  lvl: 16 x i16 lane-private LDS scratch (levels of the current group, scan order).
+HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
+    const Tables &T = SM.T;
     const int ntu = (J.shape == 0 || J.shape == 3) ? 1 : 4;
     const int Ntu = (J.shape == 0) ? J.N : (J.shape == 3) ? 4 : J.N / 2;
     const int s = (Ntu == 4) ? 0 : (Ntu == 8) ? 1 : (Ntu == 16) ? 2 : 3, ncg = Ntu >> 2;
     // ---- coding_unit header (:1271-1339)
+    const long long pth = prof_now();
     if (J.shape != 3) {
-        const int np = (J.shape == 2) ? 4 : 1;
-        int mp[4][3], hit[4];
-        if (J.ctx_split >= 0) tk_bin(f, J.ctx_split, 0);
-        if (J.N == 8) tk_bin(f, CX_PART, J.shape != 2);
-        for (int i = 0; i < np; i++) { mpm_list(J.ml[i], J.ma[i], mp[i]); hit[i] = mpm_hit(mp[i], J.mode[i]); tk_bin(f, CX_PREV_INTRA, hit[i] >= 0); }
-        for (int i = 0; i < np; i++) tk_mode_rest(f, mp[i], hit[i], J.mode[i]);
-        tk_bin(f, CX_CHROMA_PRED, 0);
-        if (J.shape != 2) tk_bin(f, CX_SPLIT_TU + (J.N == 32 ? 0 : J.N == 16 ? 1 : 2), J.shape == 1);
-        tk_bin(f, CX_CBF_CHROMA, 0); tk_bin(f, CX_CBF_CHROMA, 0);
-        fifo_drain(f, a, cx, T, sink);
+        if (J.ctx_split >= 0) put_bin(c, J.ctx_split, 0);
+        if (J.N == 8) put_bin(c, CX_PART, J.shape != 2);
+        if (J.shape == 2) {
+            int m0[3], m1[3], m2[3], m3[3];
+            const int h0 = luma_mode_flag(c, J.ml[0], J.ma[0], J.mode[0], m0), h1 = luma_mode_flag(c, J.ml[1], J.ma[1], J.mode[1], m1);
+            const int h2 = luma_mode_flag(c, J.ml[2], J.ma[2], J.mode[2], m2), h3 = luma_mode_flag(c, J.ml[3], J.ma[3], J.mode[3], m3);
+            luma_mode_rest(c, m0, h0, J.mode[0]); luma_mode_rest(c, m1, h1, J.mode[1]);
+            luma_mode_rest(c, m2, h2, J.mode[2]); luma_mode_rest(c, m3, h3, J.mode[3]);
+        } else {
+            int m0[3];
+            const int h0 = luma_mode_flag(c, J.ml[0], J.ma[0], J.mode[0], m0);
+            luma_mode_rest(c, m0, h0, J.mode[0]);
+        }
+        put_bin(c, CX_CHROMA_PRED, 0);
+        if (J.shape != 2) put_bin(c, CX_SPLIT_TU + (J.N == 32 ? 0 : J.N == 16 ? 1 : 2), J.shape == 1);
+        put_bin(c, CX_CBF_CHROMA, 0); put_bin(c, CX_CBF_CHROMA, 0);
     }
+    prof_add(PF_T_HDR, pth);
+    NOUNROLL
     for (int k = 0; k < ntu; k++) {
         const int mode = J.mode[(J.shape == 2) ? k : 0];
         const int st = scan_type_of(Ntu, mode);
         const int cbf = J.last[k] >= 0;
-        if (J.shape != 3) tk_bin(f, CX_CBF_LUMA + (J.shape == 0 ? 1 : 0), cbf);
+        if (J.shape != 3) put_bin(c, CX_CBF_LUMA + (J.shape == 0 ? 1 : 0), cbf);
         if (!cbf && J.shape != 3) continue;
         // ---- residual_coding (:1172-1268)
         const int last = imax(J.last[k], 0);
         const u32 m0 = J.cg0[k], m1 = J.cg1[k];
+        const i16 *lvk = J.lv[k];
         const int glast = last >> 4;
         {
             const int gp = T.cgpos[st][s][glast], in = T.incg[st][last & 15];
-            tk_last_pos(f, Ntu, s, st, (gp >> 3) * 4 + (in >> 2), (gp & 7) * 4 + (in & 3));
+            put_last_pos(c, s, st, (gp >> 3) * 4 + (in >> 2), (gp & 7) * 4 + (in & 3));
         }
-        fifo_drain(f, a, cx, T, sink);
         int c1 = 1;
+        NOUNROLL
         for (int g = glast; g >= 0; g--) {
             const int gp = T.cgpos[st][s][g], gy = gp >> 3, gx = gp & 7, bit = gy * 8 + gx;
             const int coded = (int)(((bit < 32 ? m0 >> bit : m1 >> (bit - 32))) & 1);
@@ -660,54 +825,67 @@ HD void trial_run(const Tables &T, const TrialJob &J, Arith &a, u8 *cx, u8 *sink
             const int right = (gx < ncg - 1) ? (int)(((rbit < 32 ? m0 >> rbit : m1 >> (rbit - 32))) & 1) : 0;
             const int below = (gy < ncg - 1) ? (int)(((bbit < 32 ? m0 >> bbit : m1 >> (bbit - 32))) & 1) : 0;
             const int pat = (below << 1) | right, dcg = (bit == 0), has_last = (g == glast);
-            if (!dcg && !has_last) tk_bin(f, CX_CSBF + (pat != 0), coded);
-            if (coded || dcg) {
-                // 16 levels of this group, scan order
-                int v[16];
-                if (coded) { const i16 *p = J.lv[k] + g * 16; for (int n = 0; n < 16; n++) v[n] = p[n]; }
-                else for (int n = 0; n < 16; n++) v[n] = 0;
-                int sbase = 0; u32 padd = 0; u64 c4 = 0;
-                if (Ntu == 4) c4 = T.c4tab[st];
-                else { sbase = 9 + (Ntu >= 16 ? 12 : 0) + ((Ntu == 8 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); padd = T.posadd[pat][st]; }
-                int nnz = 0, signs = 0;
-                const int nstart = has_last ? (last & 15) : 15;
-                for (int n = 15; n >= 0; n--) {
-                    if (n > nstart) continue;
-                    const int is_last = has_last && n == nstart;
-                    if (!is_last && (dcg || n != 0 || nnz > 0)) {
-                        int ci;
-                        if (dcg && n == 0) ci = 0;
-                        else if (Ntu == 4) ci = (int)((c4 >> (4 * n)) & 15);
-                        else ci = sbase + (int)((padd >> (2 * n)) & 3);
-                        tk_bin(f, CX_SIG + ci, v[n] != 0);
-                    }
-                    if (v[n]) { mag[nnz++] = (i16)iabs(v[n]); signs = (signs << 1) | (v[n] < 0); }
-                }
-                if (nnz > 0) {
-                    const int set = (dcg ? 0 : 2) + (c1 == 0);
-                    int esc = nnz > 8, g2 = -1;
-                    c1 = 1;
-                    for (int j = 0; j < 8 && j < nnz; j++) {
-                        const int big = mag[j] > 1;
-                        tk_bin(f, CX_GT1 + 4 * set + c1, big);
-                        if (big) { c1 = 0; if (g2 < 0) g2 = mag[j] > 2; else esc = 1; }
-                        else if (c1 > 0 && c1 < 3) c1++;
-                    }
-                    if (c1 == 0 && g2 >= 0) { tk_bin(f, CX_GT2 + set, g2); esc |= g2; }
-                    tk_bypass(f, signs, nnz);
-                    if (esc) {
-                        int base2 = 3, rice = 0;
-                        for (int j = 0; j < nnz; j++) {
-                            const int m = mag[j], r = m - (j < 8 ? base2 : 1);
-                            if (f.n > FIFO_CAP - 6) fifo_drain(f, a, cx, T, sink);
-                            if (r >= 0) { tk_remaining(f, r, rice); if (m > (3 << rice)) rice = imin(rice + 1, 4); }
-                            if (m >= 2) base2 = 2;
+            if (!dcg && !has_last) put_bin(c, CX_CSBF + (pat != 0), coded);
+            if (!(coded || dcg)) continue;
+            // stage this group's 16 levels (scan order) in the lane's LDS slot
+            {
+                U4 q0, q1;
+                if (coded) { q0 = g_ld128(lvk + g * 16); q1 = g_ld128(lvk + g * 16 + 8); }
+                else { q0.x = q0.y = q0.z = q0.w = 0; q1 = q0; }
+                u32 *d = (u32 *)lvl;
+                d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
+            }
+            int sbase = 0; u32 padd = 0; u64 c4 = 0;
+            if (Ntu == 4) c4 = T.c4tab[st];
+            else { sbase = 9 + (Ntu >= 16 ? 12 : 0) + ((Ntu == 8 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); padd = T.posadd[pat][st]; }
+            const int nstart = has_last ? (last & 15) : 15;
+            // -- pass A: significance flags, positions 15..0 in lock-step
+            int nnz = 0, signs = 0;
+            NOUNROLL
+            for (int n = 15; n >= 0; n--) {
+                const int v = lvl[n];
+                if (n <= nstart) {
+                    if (n != nstart || !has_last) {
+                        if (dcg || n != 0 || nnz > 0) {
+                            const int ci = (dcg && n == 0) ? 0 : (Ntu == 4) ? (int)((c4 >> (4 * n)) & 15) : sbase + (int)((padd >> (2 * n)) & 3);
+                            put_bin(c, CX_SIG + ci, v != 0);
                         }
+                    }
+                    if (v) { nnz++; signs = (signs << 1) | (v < 0); }
+                }
+            }
+            if (nnz == 0) continue;
+            // -- pass B: greater-1 flags of the first 8 non-zero levels, then one greater-2 flag
+            const int set = (dcg ? 0 : 2) + (c1 == 0);
+            int esc = nnz > 8, g2 = -1, cnt = 0;
+            c1 = 1;
+            NOUNROLL
+            for (int n = 15; n >= 0; n--) {
+                const int v = lvl[n], m = iabs(v);
+                if (n <= nstart && v != 0 && cnt < 8) {
+                    const int big = m > 1;
+                    put_bin(c, CX_GT1 + 4 * set + c1, big);
+                    if (big) { c1 = 0; if (g2 < 0) g2 = m > 2; else esc = 1; }
+                    else if (c1 > 0 && c1 < 3) c1++;
+                    cnt++;
+                }
+            }
+            if (c1 == 0 && g2 >= 0) { put_bin(c, CX_GT2 + set, g2); esc |= g2; }
+            put_bypass(c, signs, nnz);
+            // -- pass C: remaining absolute levels
+            if (esc) {
+                int base2 = 3, rice = 0, j = 0;
+                NOUNROLL
+                for (int n = 15; n >= 0; n--) {
+                    const int v = lvl[n], m = iabs(v);
+                    if (n <= nstart && v != 0) {
+                        const int r = m - (j < 8 ? base2 : 1);
+                        if (r >= 0) { put_remaining(c, r, rice); if (m > (3 << rice)) rice = imin(rice + 1, 4); }
+                        if (m >= 2) base2 = 2;
+                        j++;
                     }
                 }
             }
-            if (f.n > FIFO_CAP - 36 || coded || g == 0) fifo_drain(f, a, cx, T, sink);
         }
     }
-    fifo_drain(f, a, cx, T, sink);
 }

@@ -17,9 +17,8 @@
 
 #define HDR_MAX 96
 
-__global__ __launch_bounds__(WG_THREADS) void hevc_encode_frames(const Tables *gT, const FrameJob *jobs, const u8 *hdrs, int njobs,
-                                                                 const Scratch *scr, int *counter, i32 *trace, int trace_cap) {
-    __shared__ Shm S;
+__global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const FrameJob *jobs, const u8 *hdrs, int njobs,
+                                                                 const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof) {
     __shared__ int next_frame;
     for (;;) {
         if (threadIdx.x == 0) next_frame = atomicAdd(counter, 1);
@@ -30,7 +29,8 @@ __global__ __launch_bounds__(WG_THREADS) void hevc_encode_frames(const Tables *g
         Scratch sc = scr[blockIdx.x];
         sc.trace = (f == 0) ? trace : (i32 *)0;
         sc.trace_cap = trace_cap;
-        encode_frame(S, gT, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
+        sc.prof = prof;
+        encode_frame(gT, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
     }
 }
 
@@ -45,6 +45,7 @@ struct imcvt_hevc_ctx {
     FrameJob *h_jobs = nullptr; u8 *h_hdrs = nullptr;      // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
     int *d_trace = nullptr; int trace_cap = 0;
+    unsigned long long *d_prof = nullptr;   // [NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
@@ -72,7 +73,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     imcvt_hevc_ctx *c = new imcvt_hevc_ctx();
     hipDeviceProp_t prop;
     if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return nullptr; }
-    c->max_wg = max_workgroups > 0 ? max_workgroups : 2 * prop.multiProcessorCount;
+    c->max_wg = max_workgroups > 0 ? max_workgroups : 3 * prop.multiProcessorCount;   // LDS (52 KB) and registers (168) admit 3 per CU
     Tables *T = new Tables();
     imcvt::build_tables(*T);
     const size_t per_wg = align256(kLvBytes) + align256(kTrialBytes) + align256(kAboveBytes);
@@ -81,6 +82,8 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
            && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_counter, sizeof(int)) == hipSuccess
+           && hipMalloc(&c->d_prof, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
+           && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
            && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     delete T;
     if (ok) {
@@ -90,7 +93,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
             hs[i].lv = (i16 *)base;
             hs[i].bytes = base + align256(kLvBytes);
             hs[i].above_sz = hs[i].bytes + align256(kTrialBytes);
-            hs[i].trace = nullptr; hs[i].trace_cap = 0;
+            hs[i].trace = nullptr; hs[i].trace_cap = 0; hs[i].prof = nullptr;
         }
         ok = hipMemcpy(c->d_scratch, hs.data(), sizeof(Scratch) * c->max_wg, hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -100,7 +103,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
 
 extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
     if (!c) return;
-    hipFree(c->d_tables); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter);
+    hipFree(c->d_tables); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof);
     hipFree(c->d_jobs); hipFree(c->d_hdrs);
     if (c->h_jobs) hipHostFree(c->h_jobs);
     if (c->h_hdrs) hipHostFree(c->h_hdrs);
@@ -142,11 +145,20 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     const int grid = n < c->max_wg ? n : c->max_wg;
     HIPCHK(hipEventRecord(c->ev0, stream));
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream,
-                       c->d_tables, c->d_jobs, c->d_hdrs, n, c->d_scratch, c->d_counter, c->d_trace, c->trace_cap);
+                       c->d_tables, c->d_jobs, c->d_hdrs, n, c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return 0;
+}
+
+extern "C" int imcvt_hevc_debug_prof(imcvt_hevc_ctx *c, unsigned long long *out, int n, int reset) {
+    if (!c || !out) return IMCVT_ERR_ARG;
+    const int have = NWAVES * PF_N;
+    if (hipDeviceSynchronize() != hipSuccess) return IMCVT_ERR_HIP;
+    if (hipMemcpy(out, c->d_prof, sizeof(unsigned long long) * (n < have ? n : have), hipMemcpyDeviceToHost) != hipSuccess) return IMCVT_ERR_HIP;
+    if (reset && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * have) != hipSuccess) return IMCVT_ERR_HIP;
+    return have;
 }
 
 extern "C" float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *c) {

@@ -70,6 +70,7 @@ inline void build_tables(Tables &T) {
         T.lps4[st] = (u32)kRangeLps[st * 4] | (u32)kRangeLps[st * 4 + 1] << 8 | (u32)kRangeLps[st * 4 + 2] << 16 | (u32)kRangeLps[st * 4 + 3] << 24;
         for (int mps = 0; mps < 2; mps++) T.nextlps[st * 2 + mps] = (u8)(st == 0 ? (1 - mps) : ((kTransLps[st] << 1) | mps));
     }
+    for (int p = 0; p < 128; p++) { T.pst[p].x = T.lps4[p >> 1]; T.pst[p].y = (u32)T.nextlps[p] | (u32)((p < 124) ? p + 2 : p) << 8; }
     // sig_coeff_flag context increments per in-group scan position (reference :1115-1120)
     for (int pat = 0; pat < 4; pat++) for (int t = 0; t < 3; t++) {
         u32 w = 0;

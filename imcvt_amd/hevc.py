@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libimcvt_hevc.so")
+LIB_PATH = os.environ.get("IMCVT_HEVC_LIB") or os.path.join(_HERE, "csrc", "libimcvt_hevc.so")   # override: dev/profiling builds only
 
 _u8p = C.POINTER(C.c_ubyte)
 _ip = C.POINTER(C.c_int)
@@ -25,7 +25,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 # every symbol include/imcvt_hevc.h declares
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
-           "imcvt_hevc_set_trace", "imcvt_hevc_version")
+           "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_version")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -65,6 +65,8 @@ def load_library():
     lib.imcvt_hevc_last_kernel_ms.argtypes = [C.c_void_p]
     lib.imcvt_hevc_set_trace.restype = None
     lib.imcvt_hevc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.imcvt_hevc_debug_prof.restype = C.c_int
+    lib.imcvt_hevc_debug_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_int]
     lib.imcvt_hevc_version.restype = C.c_char_p
     lib.imcvt_hevc_version.argtypes = []
     _lib = lib
@@ -175,6 +177,15 @@ class DeviceEncoder:
         s = stream if stream is not None else torch.cuda.current_stream()
         _check(self.lib.imcvt_hevc_encode_device(self.ctx, batch["n"], batch["frames"], C.c_void_p(s.cuda_stream)),
                "imcvt_hevc_encode_device")
+
+    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "decide", "recon", "ctuio", "t_setup", "t_hdr", "t_gen", "t_drain", "n_drain", "n_tok")
+
+    def debug_prof(self, reset=True):
+        """Per-wave cycle totals by phase (only non-zero for -DIMCVT_PROF builds)."""
+        buf = (C.c_ulonglong * 256)()
+        n = _check(self.lib.imcvt_hevc_debug_prof(self.ctx, buf, 256, int(reset)), "imcvt_hevc_debug_prof")
+        k = len(self.PROF_CATS)
+        return [[int(buf[w * k + i]) for i in range(k)] for w in range(n // k)]
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.imcvt_hevc_last_kernel_ms(self.ctx))

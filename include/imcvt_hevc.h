@@ -68,7 +68,7 @@ typedef struct imcvt_hevc_frame {
 typedef struct imcvt_hevc_ctx imcvt_hevc_ctx;
 
 /* Creates an encoder context on the current HIP device: uploads the constant tables and allocates the
- * per-workgroup scratch for up to max_workgroups concurrent frames (0 = 2 per compute unit).
+ * per-workgroup scratch for up to max_workgroups concurrent frames (0 = 3 per compute unit).
  * Returns NULL when no device is present. */
 imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups);
 void            imcvt_hevc_destroy(imcvt_hevc_ctx *ctx);
@@ -90,6 +90,10 @@ float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *ctx);
 /* Debug aid: decision trace of frame 0 of the next launch (8 ints per CU: y, x, size, kind, mode(s), cost, 0, 0)
  * into a device buffer of cap ints; pass NULL to disable. */
 void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
+
+/* Debug aid: per-wave cycle totals by phase ([waves][categories], zeros unless the library was built with
+ * -DIMCVT_PROF); copies up to n counters to `out`, optionally resets them; returns the number available. */
+int imcvt_hevc_debug_prof(imcvt_hevc_ctx *ctx, unsigned long long *out, int n, int reset);
 
 /* Library / build information, e.g. "imcvt_hevc gfx950 r1". */
 const char *imcvt_hevc_version(void);

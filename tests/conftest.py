@@ -1,0 +1,61 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build everything once: oracle port (+ reference where /root/reference exists) and the HIP library."""
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def hostemu(built):
+    """TEST-ONLY host emulation of the device source (tests/hostemu)."""
+    import ctypes as C
+    d = os.path.join(ROOT, "tests", "hostemu")
+    so = os.path.join(d, "libhostemu.so")
+    srcs = [os.path.join(d, "hostemu.cpp")] + [os.path.join(ROOT, "imcvt_amd", "csrc", f) for f in ("hevc_core.h", "hevc_frame.h", "hevc_tables.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", so, srcs[0]], check=True)
+    lib = C.CDLL(so)
+    u8p = C.POINTER(C.c_ubyte)
+    lib.hostemu_HEVCImageEncoder.restype = C.c_int
+    lib.hostemu_HEVCImageEncoder.argtypes = [u8p, u8p, u8p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int]
+    return lib
+
+
+def kat_entries():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json")))
+
+
+def kat_input(spec):
+    """Materialise a golden input (committed pixel file or seeded generator)."""
+    import numpy as np
+    from oracle import synth
+    if spec["kind"] == "file":
+        data = open(os.path.join(ROOT, "tests", "golden", spec["file"]), "rb").read()
+        hdr = data.split(b"\n", 3)
+        w, h = map(int, hdr[1].split())
+        return np.frombuffer(hdr[3], dtype=np.uint8, count=w * h).reshape(h, w)
+    return getattr(synth, spec["kind"])(spec["w"], spec["h"], spec["arg"])
+
+
+def kat_id(e):
+    s = e["input"]
+    name = s.get("file") or f"{s['kind']}{s['w']}x{s['h']}a{s['arg']}"
+    return f"{name}-q{e['qpd6']}"

@@ -26,7 +26,8 @@ extern "C" int hostemu_HEVCImageEncoder(unsigned char *pbuffer, const unsigned c
     job.img = img; job.out = pbuffer; job.rcon = img_rcon; job.h = h; job.w = w; job.hp = hp; job.wp = wp; job.q = qpd6;
     job.hdr_len = imcvt::build_headers(hdr, qpd6, hp, wp);
     job.out_len = &out_len;
-    encode_frame(*S, &T, job, sc, hdr);
+    g_shm_host = S; sc.prof = nullptr;
+    encode_frame(&T, job, sc, hdr);
     free(sc.lv); free(sc.bytes); free(sc.above_sz); free(S);
     *ysz = hp; *xsz = wp;
     return out_len;

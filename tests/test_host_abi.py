@@ -1,0 +1,61 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/imcvt_hevc.h declares, and
+fails LOUDLY without a device (no CPU fallback).  No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "imcvt_hevc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b([A-Za-z_]\w*)\s*\(", src))
+    return sorted(n for n in names if n.startswith(("imcvt_hevc_", "HEVCImage", "writeHEVC")) and n != "imcvt_hevc_frame")
+
+
+def test_library_exports_every_declared_symbol(built):
+    import imcvt_amd
+    lib = imcvt_amd.load_library()
+    syms = declared_symbols()
+    assert set(syms) == set(imcvt_amd.hevc.EXPORTS), (syms, imcvt_amd.hevc.EXPORTS)
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.imcvt_hevc_version()
+
+
+def test_geometry_helpers(built):
+    import imcvt_amd
+    lib = imcvt_amd.load_library()
+    for v, want in [(1, 32), (32, 32), (33, 64), (1080, 1088), (8192, 8192), (9000, 8192)]:     # reference :1580-1581
+        assert lib.imcvt_hevc_padded(v) == want == imcvt_amd.padded(v)
+    assert lib.imcvt_hevc_stream_bound(1080, 1920) == 2 * (1920 + 32) * (1080 + 32) + 65536   # src/imageio_hevc.c:14
+
+
+def test_frame_descriptor_layout(built):
+    import imcvt_amd
+    f = imcvt_amd.hevc.imcvt_hevc_frame
+    assert C.sizeof(f) == 48 and f.h.offset == 32 and f.qpd6.offset == 40
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_device_fails_loudly(built, capfd):
+    import imcvt_amd
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        imcvt_amd.HEVCImageEncoder(np.zeros((32, 32), np.uint8), 0)
+    with pytest.raises(RuntimeError):
+        imcvt_amd.DeviceEncoder()
+    assert imcvt_amd.writeHEVCImageFile("/tmp/_never.h265", np.zeros((8, 8), np.uint8), False, 8, 8, 0) == 1   # reference: 1 = failed
+    assert "no CPU fallback" in capfd.readouterr().err
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference the checker."""
+    for root, _, files in os.walk(os.path.join(ROOT, "imcvt_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt and "libref_" not in txt, f

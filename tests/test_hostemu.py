@@ -1,0 +1,42 @@
+"""Logic tests of the DEVICE SOURCE on CPU: imcvt_amd/csrc/hevc_{core,frame}.h compiled for the host by
+tests/hostemu (a wavefront = a serial loop over 64 lanes).  This is a test harness only — it is not shipped and is
+not a fallback; what it buys is that every decision branch of the kernel is checked against the golden vectors
+without a GPU, so the -m gpu tests only have to expose synchronisation bugs."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import kat_entries, kat_id, kat_input
+
+u8p = C.POINTER(C.c_ubyte)
+# P5 at q0 and q4 together exercise every branch of the CU search; keep the CPU suite short
+PICK = [e for e in kat_entries() if e["input"].get("w", 0) < 1920
+        and not (e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] in (1, 2, 3))
+        and not (e["input"].get("file") == "p6_green.pgm")
+        and not (e["input"].get("w") == 256 and e["qpd6"] in (1, 2, 3))]
+
+
+def emu_encode(lib, img, q):
+    h, w = img.shape
+    hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    out = np.zeros(2 * (w + 32) * (h + 32) + 65536, np.uint8)
+    rc = np.zeros(hp * wp, np.uint8)
+    ys, xs = C.c_int(h), C.c_int(w)
+    n = lib.hostemu_HEVCImageEncoder(out.ctypes.data_as(u8p), np.ascontiguousarray(img).ctypes.data_as(u8p), rc.ctypes.data_as(u8p),
+                                     C.byref(ys), C.byref(xs), q, None, 0)
+    return out[:n].tobytes(), rc.reshape(hp, wp)
+
+
+@pytest.mark.parametrize("e", PICK, ids=kat_id)
+def test_device_source_matches_golden(hostemu, e):
+    stream, rcon = emu_encode(hostemu, kat_input(e["input"]), e["qpd6"])
+    assert len(stream) == e["bytes"]
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
+def test_lds_budget(hostemu):
+    # two workgroups per CU need <= 80 KiB each (160 KiB LDS per CU)
+    assert hostemu.hostemu_shm_bytes() <= 80 * 1024
