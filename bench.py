@@ -46,9 +46,10 @@ def cpu_baseline(qpd6):
     from oracle import oracle
     cores = max(1, min(os.cpu_count() or 1, 32))
     t0 = time.perf_counter()
-    with Pool(cores) as pool:
-        pool.map(_cpu_strip, range(cores), chunksize=1)
+    pool = Pool(cores)
+    pool.map(_cpu_strip, range(cores), chunksize=1)
     wall = time.perf_counter() - t0
+    pool.close(); pool.join()       # let workers exit normally (a terminate() under rocprofv3 hangs in its signal handler)
     px = cores * W * 256
     return {"value": round(px / wall / 1e6, 4), "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if oracle.have_ref() else "port",
@@ -87,8 +88,9 @@ def main():
 
     F = args.frames
     seeds = [rank * F + i for i in range(F)]
-    with Pool(max(1, min(os.cpu_count() or 1, 16))) as pool:
-        frames_np = pool.map(_gen, seeds, chunksize=4)
+    pool = Pool(max(1, min(os.cpu_count() or 1, 16)))
+    frames_np = pool.map(_gen, seeds, chunksize=4)
+    pool.close(); pool.join()
     big = torch.from_numpy(np.stack(frames_np)).to(dev)            # [F, H, W] resident in HBM before any timing
     enc = imcvt_amd.DeviceEncoder()
     batch = enc.make_batch([big[i] for i in range(F)], args.qpd6)

@@ -41,6 +41,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:                     # one HIP runtime per process: if torch is around, let it load its runtime first
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP extension is mandatory; there is no CPU fallback)")
