@@ -87,7 +87,8 @@ def main():
     from multiprocessing import Pool
 
     F = args.frames
-    seeds = [rank * F + i for i in range(F)]
+    from imcvt_amd import shard
+    seeds = list(shard.frame_range(rank, world, F))
     pool = Pool(max(1, min(os.cpu_count() or 1, 16)))
     frames_np = pool.map(_gen, seeds, chunksize=4)
     pool.close(); pool.join()
@@ -111,10 +112,7 @@ def main():
         kernel_ms.append(enc.last_kernel_ms())          # HIP events on the launch stream (synchronises it)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, dev)
 
     # correctness of what was just timed: digests of this rank's first frames against the reference's golden digests
     lens = batch["lens"].cpu().numpy()
