@@ -65,6 +65,8 @@ HD void g_st16(i16 *p, int v) { *p = (i16)v; }
 HD u8 g_ld8(const u8 *p) { return *p; }
 HD i16 g_ld16(const i16 *p) { return *p; }
 HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
+HD u8 *uniform_ptr(u8 *p) { return p; }
+HD int hibit(u32 v) { return 31 - __builtin_clz(v); }
 #else
 #define GAS __attribute__((address_space(1)))
 HD void g_st8(u8 *p, int v) { *(GAS u8 *)p = (u8)v; }
@@ -72,6 +74,15 @@ HD void g_st16(i16 *p, int v) { *(GAS i16 *)p = (i16)v; }
 HD u8 g_ld8(const u8 *p) { return *(const GAS u8 *)p; }
 HD i16 g_ld16(const i16 *p) { return *(const GAS i16 *)p; }
 HD U4 g_ld128(const void *p) { const GAS U4 *g = (const GAS U4 *)p; U4 r; r.x = g->x; r.y = g->y; r.z = g->z; r.w = g->w; return r; }
+#endif
+#ifndef IMCVT_HOSTEMU
+// a pointer every lane agrees on, moved to SGPRs so that stores can use the scalar-base + 32-bit-offset form
+HD u8 *uniform_ptr(u8 *p) {
+    const u64 v = (u64)p;
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return (u8 *)(((u64)hi << 32) | lo);
+}
+HD int hibit(u32 v) { return 31 - __clz((int)v); }
 #endif
 HD int iabs(int v) { return v < 0 ? -v : v; }
 HD int imin(int a, int b) { return a < b ? a : b; }
@@ -227,18 +238,26 @@ HD void prof_cnt(int, int) {}
 HD void wg_sync_p() { const long long t = prof_now(); wg_sync(); prof_add(PF_SYNC, t); }
 
 // sink[a.cnt] is where the next byte goes
-HD void emit_byte(Arith &a, u8 *sink, int v) {                                             // :820-831
+struct Sink { u8 *base; u32 off; };          // byte i of the lane's run lives at base[off + i]; base is wave-uniform
+HD void sink_put(const Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), v); }
+HD void emit_byte(Arith &a, const Sink &sink, int v) {                                             // :820-831
     v &= 0xFF;
-    if (a.zeros >= 2 && v <= 3) { g_st8(sink + a.cnt++, 3); a.zeros = 0; }
-    g_st8(sink + a.cnt++, v);
+    if (a.zeros >= 2 && v <= 3) { sink_put(sink, a.cnt++, 3); a.zeros = 0; }
+    sink_put(sink, a.cnt++, v);
     a.zeros = v ? 0 : a.zeros + 1;
 }
-HD void carry_out(Arith &a, u8 *sink) {                                                    // :858-878
+HD void carry_out(Arith &a, const Sink &sink) {                                                    // :858-878
     if (a.nbits < 12) {
-        int lead = (int)((u32)a.low >> (24 - a.nbits));
+        const int lead = (int)((u32)a.low >> (24 - a.nbits));
         a.nbits += 8;
         a.low &= (i32)(0xFFFFFFFFu >> a.nbits);
-        if (lead == 0xFF) a.nbytes++;
+        const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
+        if (a.nbytes == 1 && lead != 0xFF && !(a.zeros >= 2 && v1 <= 3)) {
+            // common case: exactly one byte is buffered, no run of 0xFF, no emulation prevention
+            sink_put(sink, a.cnt++, v1);
+            a.zeros = v1 ? 0 : a.zeros + 1;
+            a.bufbyte = lead & 0xFF;
+        } else if (lead == 0xFF) a.nbytes++;
         else if (a.nbytes > 0) {
             int carry = lead >> 8, v = a.bufbyte + carry;
             a.bufbyte = lead & 0xFF;
@@ -248,7 +267,7 @@ HD void carry_out(Arith &a, u8 *sink) {                                         
         } else { a.nbytes = 1; a.bufbyte = lead; }
     }
 }
-HD void code_bin(Arith &a, u8 *cx, u8 *sink, int ci, int bin) {
+HD void code_bin(Arith &a, u8 *cx, const Sink &sink, int ci, int bin) {
     const Tables &T = SM.T;          // :913-932
     const int p = cx[ci];
     const int lps = (int)((T.lps4[p >> 1] >> (((a.range >> 6) & 3) * 8)) & 0xFF);
@@ -265,18 +284,18 @@ HD void code_bin(Arith &a, u8 *cx, u8 *sink, int ci, int bin) {
     }
     carry_out(a, sink);
 }
-HD void code_bypass_chunk(Arith &a, u8 *sink, int v, int n) {                             // one <=8-bin step of :898-910
+HD void code_bypass_chunk(Arith &a, const Sink &sink, int v, int n) {                             // one <=8-bin step of :898-910
     a.low = (a.low << n) + a.range * v;
     a.nbits -= n;
     carry_out(a, sink);
 }
-HD void code_terminate(Arith &a, u8 *sink, int bin) {                                      // :881-895
+HD void code_terminate(Arith &a, const Sink &sink, int bin) {                                      // :881-895
     a.range -= 2;
     if (bin) { a.low = (a.low + a.range) << 7; a.range = 256; a.nbits -= 7; }
     else if (a.range < 256) { a.low <<= 1; a.range <<= 1; a.nbits--; }
     carry_out(a, sink);
 }
-HD void arith_finish(Arith &a, u8 *sink) {                                                 // :839-855
+HD void arith_finish(Arith &a, const Sink &sink) {                                                 // :839-855
     int fill = 0, t;
     if ((a.low >> (32 - a.nbits)) > 0) { emit_byte(a, sink, a.bufbyte + 1); a.low -= 1 << (32 - a.nbits); }
     else { if (a.nbytes > 0) emit_byte(a, sink, a.bufbyte); fill = 0xFF; }
@@ -343,6 +362,54 @@ HD int pred_px(const Tables &T, const BorderRef &b, int N, int lg, int mode, int
         int p1 = t1 == 0 ? corner : t1 > 0 ? M[t1 - 1] : Sd[((128 - iang * t1) >> 8) - 1];
         int p2 = t2 == 0 ? corner : t2 > 0 ? M[t2 - 1] : Sd[((128 - iang * t2) >> 8) - 1];   // M[2N] is read only with of==0
         return ((32 - of) * p1 + of * p2 + 16) >> 5;
+    }
+}
+
+// Prediction of one 4x4 block at (y0,x0) of an N x N predictor (same arithmetic as pred_px, :262-381), with the per-row
+// angle terms hoisted and neighbouring reference samples shared between pixels.
+HD int ref_line(const u8 *M, const u8 *Sd, int corner, int iang, int t) {     // t==0 corner, t>0 main[t-1], t<0 projected side (:353-364)
+    return t == 0 ? corner : t > 0 ? M[t - 1] : Sd[((128 - iang * t) >> 8) - 1];
+}
+HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode, int y0, int x0, int out[4][4]) {
+    const int f = uses_filtered(N, mode);
+    const u8 *L = f ? b.fl : b.ul, *A = f ? b.fa : b.ua;
+    const int corner = f ? b.fc : b.uc;
+    if (mode == 0) {
+        const int an = A[N], ln = L[N];
+        int lv[4], av[4];
+        for (int i = 0; i < 4; i++) { lv[i] = L[y0 + i]; av[i] = A[x0 + i]; }
+        for (int yi = 0; yi < 4; yi++) for (int xi = 0; xi < 4; xi++) {
+            const int y = y0 + yi, x = x0 + xi;
+            out[yi][xi] = ((N - 1 - x) * lv[yi] + (x + 1) * an + (N - 1 - y) * av[xi] + (y + 1) * ln + N) >> (lg + 1);
+        }
+    } else if (mode == 1) {
+        const int dc = b.dc;
+        for (int yi = 0; yi < 4; yi++) for (int xi = 0; xi < 4; xi++) out[yi][xi] = dc;
+        if (N <= 16) {
+            if (y0 == 0) for (int xi = 0; xi < 4; xi++) out[0][xi] = (2 + 3 * dc + A[x0 + xi]) >> 2;
+            if (x0 == 0) for (int yi = 0; yi < 4; yi++) out[yi][0] = (2 + 3 * dc + L[y0 + yi]) >> 2;
+            if (y0 == 0 && x0 == 0) out[0][0] = (2 + 2 * dc + L[0] + A[0]) >> 2;
+        }
+    } else if (mode == 10) {
+        for (int yi = 0; yi < 4; yi++) { const int v = L[y0 + yi]; for (int xi = 0; xi < 4; xi++) out[yi][xi] = v; }
+        if (N <= 16 && y0 == 0) for (int xi = 0; xi < 4; xi++) out[0][xi] = clip3(((A[x0 + xi] - corner) >> 1) + L[0], 0, 255);
+    } else if (mode == 26) {
+        for (int xi = 0; xi < 4; xi++) { const int v = A[x0 + xi]; for (int yi = 0; yi < 4; yi++) out[yi][xi] = v; }
+        if (N <= 16 && x0 == 0) for (int yi = 0; yi < 4; yi++) out[yi][0] = clip3(((L[y0 + yi] - corner) >> 1) + A[0], 0, 255);
+    } else {
+        const int horiz = mode < 18;
+        const int ang = (int)T.ang[mode] - 32, iang = T.iang[mode];
+        const u8 *M = horiz ? L : A, *Sd = horiz ? A : L;
+        const int i0 = horiz ? x0 : y0, j0 = horiz ? y0 : x0;           // i runs along the prediction direction
+        for (int ii = 0; ii < 4; ii++) {
+            const int off = ang * (i0 + ii + 1), oi = off >> 5, of = off & 31, t0 = oi + j0 + 1;
+            int p[5];
+            for (int k = 0; k < 5; k++) p[k] = ref_line(M, Sd, corner, iang, t0 + k);      // M[2N] is read only with of==0
+            for (int jj = 0; jj < 4; jj++) {
+                const int v = ((32 - of) * p[jj] + of * p[jj + 1] + 16) >> 5;
+                if (horiz) out[jj][ii] = v; else out[ii][jj] = v;
+            }
+        }
     }
 }
 
@@ -510,6 +577,146 @@ HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *M, int row0, int col0) {
     }
 }
 
+// quantiser constants of one (size, qpd6) pair (:546-554, :606-608)
+struct QConst { int sh, add, dmax, thr, dq; RdW rw; };
+template <int S>
+HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q.dmax = I32MAX - Q.add; Q.thr = 9 << Q.sh >> 2; Q.dq = 1 << (5 - S + q); Q.rw = rd_weights(q); return Q; }
+
+// Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594).  in: acc = forward-transform sums before the
+// final shift; out: acc = signed levels.  Returns non-zero when the group keeps any level after the weak-group test.
+template <int S>
+HD int rdoq_group(int acc[4][4], const QConst &Q) {
+    constexpr int b1 = S + 8, dsh = 8 - S;
+    int sum = 0, any = 0;
+    for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
+        const int cf = acc[r][cc] >> b1, av = iabs(cf);
+        const int d = (av > 0x1ffff) ? Q.dmax : imin((av & 0x1ffff) << 14, Q.dmax);
+        const int l0 = clip16((int)(((u32)d + (u32)Q.add) >> Q.sh));
+        int pick = 0;
+        if (l0 > 0) {                                   // level 0 alone needs no pricing
+            // candidates l0, l0-1, l0-2 (>= 0), the larger level winning ties (:570-578)
+            const int e0 = iabs(d - (l0 << Q.sh)) >> dsh;
+            const int c0 = rd_cost(Q.rw, ((e0 < 46340) ? e0 * e0 : I32MAX) >> 7, level_rate(l0));
+            const int e1 = iabs(d - ((l0 - 1) << Q.sh)) >> dsh;
+            const int c1 = rd_cost(Q.rw, ((e1 < 46340) ? e1 * e1 : I32MAX) >> 7, level_rate(l0 - 1));
+            int best = c0; pick = l0;
+            if (c1 < best) { best = c1; pick = l0 - 1; }
+            if (l0 > 1) {
+                const int e2 = iabs(d - ((l0 - 2) << Q.sh)) >> dsh;
+                const int c2 = rd_cost(Q.rw, ((e2 < 46340) ? e2 * e2 : I32MAX) >> 7, level_rate(l0 - 2));
+                if (c2 < best) { best = c2; pick = l0 - 2; }
+            }
+        }
+        acc[r][cc] = (cf < 0) ? -pick : pick;
+        any |= pick;
+        sum += imin(d, Q.thr);
+        if (cc & 1) SCHED_FENCE();                      // let two coefficients overlap, not sixteen
+    }
+    return (sum < Q.thr) ? 0 : any;                     // weak group: cleared (:588-591)
+}
+
+// Store the levels of a coded group in scan order, book `last` / group bitmap, and dequantise acc in place.
+HD void emit_group(WaveMem &W, const P1Args &P, int acc[4][4], int c, int st, int s, int by, int bx, int NN, int dq) {
+    const Tables &T = SM.T;
+    const int g = T.cgrank[st][s][by * 8 + bx];
+    i16 *lvg = P.lv ? P.lv + (size_t)c * NN + g * 16 : (i16 *)0;     // only coded groups are ever read back
+    int hi = 0;
+    for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
+        const int v = acc[r][cc];
+        const int n = T.incg_rank[st][r * 4 + cc];
+        if (v) hi = imax(hi, n);
+        if (lvg) g_st16(lvg + n, v);
+        acc[r][cc] = clip16(v * dq);
+    }
+    if (P.only_mode < 0) {
+        lds_max(&W.last[P.k][c], g * 16 + hi);
+        const int bit = by * 8 + bx;
+        lds_or(&W.cgm[P.k][c][bit >> 5], 1u << (bit & 31));
+    }
+}
+
+HD int scan_type_of(int N, int mode) { return (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0; }   // :1133-1141
+
+HD void fill_border_ref(BorderRef &br, const WaveMem &W, int per_mode, int c) {
+    if (per_mode) { const BorderS &b = SM.X.bc[c]; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
+    else { const Border &b = W.bsh; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
+}
+
+// ---- 4x4 blocks: one lane owns the whole block, so the pipeline runs entirely in registers (DST constants are
+// immediates, no LDS intermediates, no wave syncs between the stages).
+HDN void p1_run_4(int wave, const P1Args P) {
+    WaveMem &W = SM.W[wave];
+    const Tables &T = SM.T;
+    const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
+    const QConst Q = qconst<0>(P.q);
+    LANES(l) {
+        const int c = l;
+        if (c < ncand) {
+            const int mode = (P.only_mode >= 0) ? P.only_mode : c;
+            BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
+            int pr[4][4], x[4][4], t[4][4];
+            pred_block4(T, br, 4, 2, mode, 0, 0, pr);
+            for (int yi = 0; yi < 4; yi++) {
+                const u32 ow = *(const u32 *)&SM.org[P.y0 + yi][P.x0];
+                for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
+            }
+            // forward DST (:391-396): t = (D*x + 1) >> 1 ; coef sums = t*D^T + 128 (shift by 8 inside rdoq_group)
+            for (int j = 0; j < 4; j++) {
+                const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
+                t[0][j] = (29 * a + 55 * b + 74 * cc_ + 84 * d + 1) >> 1;
+                t[1][j] = (74 * (a + b - d) + 1) >> 1;
+                t[2][j] = (84 * a - 29 * b - 74 * cc_ + 55 * d + 1) >> 1;
+                t[3][j] = (55 * a - 84 * b + 74 * cc_ - 29 * d + 1) >> 1;
+            }
+            for (int i = 0; i < 4; i++) {
+                const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
+                x[i][0] = 29 * a + 55 * b + 74 * cc_ + 84 * d + 128;
+                x[i][1] = 74 * (a + b - d) + 128;
+                x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
+                x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
+            }
+            const int any = rdoq_group<0>(x, Q);
+            int part = 0;
+            if (any) {
+                emit_group(W, P, x, c, scan_type_of(4, mode), 0, 0, 0, 16, Q.dq);
+                // inverse DST with the 16-bit clips (:511-515): t = clip16((D^T*x + 64) >> 7) ; r = clip16((t*D + 2048) >> 12)
+                for (int j = 0; j < 4; j++) {
+                    const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
+                    t[0][j] = clip16((29 * a + 74 * b + 84 * cc_ + 55 * d + 64) >> 7);
+                    t[1][j] = clip16((55 * a + 74 * b - 29 * cc_ - 84 * d + 64) >> 7);
+                    t[2][j] = clip16((74 * (a - cc_ + d) + 64) >> 7);
+                    t[3][j] = clip16((84 * a - 74 * b + 55 * cc_ - 29 * d + 64) >> 7);
+                }
+                for (int i = 0; i < 4; i++) {
+                    const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
+                    x[i][0] = clip16((29 * a + 74 * b + 84 * cc_ + 55 * d + 2048) >> 12);
+                    x[i][1] = clip16((55 * a + 74 * b - 29 * cc_ - 84 * d + 2048) >> 12);
+                    x[i][2] = clip16((74 * (a - cc_ + d) + 2048) >> 12);
+                    x[i][3] = clip16((84 * a - 74 * b + 55 * cc_ - 29 * d + 2048) >> 12);
+                }
+            } else {
+                for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) x[i][j] = 0;   // all-zero levels reconstruct to the prediction
+            }
+            for (int yi = 0; yi < 4; yi++) {
+                const u32 ow = *(const u32 *)&SM.org[P.y0 + yi][P.x0];
+                for (int xi = 0; xi < 4; xi++) {
+                    const int rc = clip3(x[yi][xi] + pr[yi][xi], 0, 255);
+                    const int d = (int)((ow >> (8 * xi)) & 255) - rc;
+                    part += d * d;
+                    if (P.out_kind == OUT_REC4) W.rec4[c][yi * 4 + xi] = (u8)rc;
+                    else if (P.out_kind == OUT_TILE) SM.rec[P.y0 + yi + 1][P.x0 + xi + 1] = (u8)rc;
+                    else if (P.out_kind == OUT_T3SIDE) {
+                        if (yi == 3) SM.X.t3row[c][P.k][xi] = (u8)rc;
+                        if (xi == 3) SM.X.t3col[c][P.k][yi] = (u8)rc;
+                    }
+                }
+            }
+            if (P.only_mode < 0) W.sse[c] += part;         // this lane is the only writer of sse[c] in this pass
+        }
+    }
+    wave_sync();
+}
+
 template <int LG>
 HDN void p1_run_t(int wave, const P1Args P) {
     constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
@@ -517,12 +724,8 @@ HDN void p1_run_t(int wave, const P1Args P) {
     const Tables &T = SM.T;
     const i8 *C = T.C + mat_off(s), *CT = T.CT + mat_off(s);
     const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
-    const int q = P.q;
-    // quantiser constants (:546-554)
-    constexpr int a1 = s + 1, b1 = a1 + 7, ra = 1 << a1 >> 1, rb = 1 << b1 >> 1, dsh = 8 - s;
-    const int sh = 19 - s + q, add = 1 << sh >> 1, dmax = I32MAX - add, thr = 9 << sh >> 2;
-    const int dq = 1 << (5 - s + q);
-    const RdW rw = rd_weights(q);
+    constexpr int a1 = s + 1, ra = 1 << a1 >> 1, rb = 1 << (a1 + 7) >> 1;
+    const QConst Q = qconst<s>(P.q);
 
     NOUNROLL
     for (int c0 = 0; c0 < ncand; c0 += G) {
@@ -532,15 +735,17 @@ HDN void p1_run_t(int wave, const P1Args P) {
             if (c < ncand) {
                 const int mode = (P.only_mode >= 0) ? P.only_mode : c;
                 u8 *pp = W.u.p1.pred + sl * NN; i16 *rp = W.u.p1.res + sl * NN;
-                BorderRef br;
-                if (P.per_mode_border) { const BorderS &b = SM.X.bc[c]; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
-                else { const Border &b = W.bsh; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
-                NOUNROLL
-                for (int pi = 0; pi < 16; pi++) {
-                    const int y = by * 4 + (pi >> 2), x = bx * 4 + (pi & 3);
-                    const int p = pred_px(T, br, N, LG, mode, y, x);
-                    pp[y * N + x] = (u8)p;
-                    rp[y * N + x] = (i16)((int)SM.org[P.y0 + y][P.x0 + x] - p);
+                BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
+                int pr[4][4];
+                pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
+                for (int yi = 0; yi < 4; yi++) {
+                    const int y = by * 4 + yi;
+                    const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                    *(u32 *)(pp + y * N + bx * 4) = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
+                    uint2 rw_;
+                    rw_.x = (u32)(((int)(ow & 255) - pr[yi][0]) & 0xFFFF) | (u32)((int)((ow >> 8) & 255) - pr[yi][1]) << 16;
+                    rw_.y = (u32)(((int)((ow >> 16) & 255) - pr[yi][2]) & 0xFFFF) | (u32)((int)(ow >> 24) - pr[yi][3]) << 16;
+                    *(uint2 *)(rp + y * N + bx * 4) = rw_;
                 }
             }
         }
@@ -568,51 +773,13 @@ HDN void p1_run_t(int wave, const P1Args P) {
                 int acc[4][4];
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = rb;
                 mac_YM32<N>(acc, W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
-                int sum = 0, any = 0;
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
-                    const int cf = acc[r][cc] >> b1, av = iabs(cf);
-                    const int d = (av > 0x1ffff) ? dmax : imin((av & 0x1ffff) << 14, dmax);
-                    int lq = clip16((int)(((u32)d + (u32)add) >> sh));
-                    int pick = 0;
-                    if (lq > 0) {                                   // level 0 alone needs no pricing
-                        const int lo = imax(0, lq - 2);
-                        int best = I32MAX;
-                        NOUNROLL
-                        for (; lq >= lo; lq--) {
-                            const int e = iabs(d - (lq << sh)) >> dsh;
-                            const int dist = ((e < 46340) ? e * e : I32MAX) >> 7;
-                            const int cost = rd_cost(rw, dist, level_rate(lq));
-                            if (cost < best) { best = cost; pick = lq; }
-                        }
-                    }
-                    acc[r][cc] = (cf < 0) ? -pick : pick;
-                    any |= pick;
-                    sum += imin(d, thr);
-                    SCHED_FENCE();
-                }
-                if (sum < thr) any = 0;                              // weak group: cleared (:588-591)
-                // scan bookkeeping: this lane's block is coefficient group (by,bx)
-                const int st = (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0;   // :1133-1141
-                const int g = T.cgrank[st][s][by * 8 + bx];
+                const int any = rdoq_group<s>(acc, Q);
                 i16 *dp = W.u.p1.res + sl * NN;
                 if (any) {
-                    int hi = 0;
-                    i16 *lvg = P.lv ? P.lv + (size_t)c * NN + g * 16 : (i16 *)0;     // only coded groups are ever read back
+                    emit_group(W, P, acc, c, scan_type_of(N, mode), s, by, bx, NN, Q.dq);
                     for (int r = 0; r < 4; r++) {
-                        for (int cc = 0; cc < 4; cc++) {
-                            const int v = acc[r][cc];
-                            const int n = T.incg_rank[st][r * 4 + cc];
-                            if (v) hi = imax(hi, n);
-                            if (lvg) g_st16(lvg + n, v);
-                            acc[r][cc] = clip16(v * dq);
-                        }
                         uint2 o; o.x = (u32)(acc[r][0] & 0xFFFF) | (u32)acc[r][1] << 16; o.y = (u32)(acc[r][2] & 0xFFFF) | (u32)acc[r][3] << 16;
                         *(uint2 *)(dp + (by * 4 + r) * N + bx * 4) = o;
-                    }
-                    if (P.only_mode < 0) {
-                        lds_max(&W.last[P.k][c], g * 16 + hi);
-                        const int bit = by * 8 + bx;
-                        lds_or(&W.cgm[P.k][c][bit >> 5], 1u << (bit & 31));
                     }
                 } else {
                     uint2 z; z.x = 0; z.y = 0;
@@ -656,8 +823,7 @@ HDN void p1_run_t(int wave, const P1Args P) {
                         const int rc = clip3(clip16(acc[r][cc] >> 12) + (int)((pw >> (8 * cc)) & 255), 0, 255);
                         const int d = (int)((ow >> (8 * cc)) & 255) - rc;
                         part += d * d;
-                        if (P.out_kind == OUT_REC4) W.rec4[c][y * 4 + x] = (u8)rc;
-                        else if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
+                        if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
                         else if (P.out_kind == OUT_T3SIDE) {
                             if (y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
                             if (x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
@@ -675,7 +841,7 @@ HD void p1_run(int wave, const P1Args &P) {
     if (P.N == 32) p1_run_t<5>(wave, P);
     else if (P.N == 16) p1_run_t<4>(wave, P);
     else if (P.N == 8) p1_run_t<3>(wave, P);
-    else p1_run_t<2>(wave, P);
+    else p1_run_4(wave, P);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -690,7 +856,7 @@ HD void p1_run(int wave, const P1Args &P) {
 #define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
 #endif
 
-struct Coder { Arith a; u8 *cx; u8 *sink; };
+struct Coder { Arith a; u8 *cx; Sink sink; };
 
 HD void put_bin(Coder &c, int ci, int bin) {                                               // :913-932
     Arith &a = c.a;
@@ -716,7 +882,6 @@ HD void mpm_list(int l, int a, int *m) {                       // :957-976
     else if (l > 1) { m[0] = l; m[1] = ((l + 29) & 31) + 2; m[2] = ((l - 1) & 31) + 2; }
     else { m[0] = 0; m[1] = 1; m[2] = 26; }
 }
-HD int scan_type_of(int N, int mode) { return (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0; }
 
 // prev_intra_luma_pred_flag of one PU; returns the hit index (or -1) and the sorted-descending candidates in m[]
 HD int luma_mode_flag(Coder &c, int ml, int ma, int mode, int *m) {
@@ -835,37 +1000,41 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
                 u32 *d = (u32 *)lvl;
                 d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
             }
-            int sbase = 0; u32 padd = 0; u64 c4 = 0;
-            if (Ntu == 4) c4 = T.c4tab[st];
-            else { sbase = 9 + (Ntu >= 16 ? 12 : 0) + ((Ntu == 8 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); padd = T.posadd[pat][st]; }
+            // significance context of scan position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
+            u64 tab; int fbits, base;
+            if (Ntu == 4) { tab = T.c4tab[st]; fbits = 4; base = 0; }
+            else { tab = T.posadd[pat][st]; fbits = 2; base = 9 + (Ntu >= 16 ? 12 : 0) + ((Ntu == 8 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); }
+            const int fmask = (1 << fbits) - 1;
             const int nstart = has_last ? (last & 15) : 15;
             // -- pass A: significance flags, positions 15..0 in lock-step
-            int nnz = 0, signs = 0;
+            int nnz = 0, signs = 0; u32 nzm = 0;
             NOUNROLL
             for (int n = 15; n >= 0; n--) {
                 const int v = lvl[n];
-                if (n <= nstart) {
-                    if (n != nstart || !has_last) {
-                        if (dcg || n != 0 || nnz > 0) {
-                            const int ci = (dcg && n == 0) ? 0 : (Ntu == 4) ? (int)((c4 >> (4 * n)) & 15) : sbase + (int)((padd >> (2 * n)) & 3);
-                            put_bin(c, CX_SIG + ci, v != 0);
-                        }
+                const int in = n <= nstart;
+                const int code = in & !(has_last & (n == nstart)) & (dcg | (n != 0) | (nnz > 0));
+                if (WAVE_ANY(code)) {
+                    if (code) {
+                        const int ci = (dcg & (n == 0)) ? 0 : base + (int)((tab >> (fbits * n)) & fmask);
+                        put_bin(c, CX_SIG + ci, v != 0);
                     }
-                    if (v) { nnz++; signs = (signs << 1) | (v < 0); }
                 }
+                if (in & (v != 0)) { nnz++; signs = (signs << 1) | (v < 0); nzm |= 1u << n; }
             }
             if (nnz == 0) continue;
-            // -- pass B: greater-1 flags of the first 8 non-zero levels, then one greater-2 flag
+            // -- pass B: greater-1 flags of the first 8 non-zero levels (scan-reverse order), then one greater-2 flag
             const int set = (dcg ? 0 : 2) + (c1 == 0);
-            int esc = nnz > 8, g2 = -1, cnt = 0;
+            int esc = nnz > 8, g2 = -1;
             c1 = 1;
-            NOUNROLL
-            for (int n = 15; n >= 0; n--) {
-                const int v = lvl[n], m = iabs(v);
-                if (n <= nstart && v != 0 && cnt < 8) {
-                    const int big = m > 1;
+            {
+                u32 m = nzm; int cnt = 0;
+                NOUNROLL
+                while (m != 0 && cnt < 8) {
+                    const int n = hibit(m); m &= ~(1u << n);
+                    const int mg = iabs((int)lvl[n]);
+                    const int big = mg > 1;
                     put_bin(c, CX_GT1 + 4 * set + c1, big);
-                    if (big) { c1 = 0; if (g2 < 0) g2 = m > 2; else esc = 1; }
+                    if (big) { c1 = 0; if (g2 < 0) g2 = mg > 2; else esc = 1; }
                     else if (c1 > 0 && c1 < 3) c1++;
                     cnt++;
                 }
@@ -874,16 +1043,15 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
             put_bypass(c, signs, nnz);
             // -- pass C: remaining absolute levels
             if (esc) {
-                int base2 = 3, rice = 0, j = 0;
+                int base2 = 3, rice = 0, j = 0; u32 m = nzm;
                 NOUNROLL
-                for (int n = 15; n >= 0; n--) {
-                    const int v = lvl[n], m = iabs(v);
-                    if (n <= nstart && v != 0) {
-                        const int r = m - (j < 8 ? base2 : 1);
-                        if (r >= 0) { put_remaining(c, r, rice); if (m > (3 << rice)) rice = imin(rice + 1, 4); }
-                        if (m >= 2) base2 = 2;
-                        j++;
-                    }
+                while (m != 0) {
+                    const int n = hibit(m); m &= ~(1u << n);
+                    const int mg = iabs((int)lvl[n]);
+                    const int r = mg - (j < 8 ? base2 : 1);
+                    if (r >= 0) { put_remaining(c, r, rice); if (mg > (3 << rice)) rice = imin(rice + 1, 4); }
+                    if (mg >= 2) base2 = 2;
+                    j++;
                 }
             }
         }

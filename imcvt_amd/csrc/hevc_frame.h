@@ -36,6 +36,7 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
     WaveMem &W = SM.W[wave];
     const int q = F.job.q, h = N / 2;
     i16 *lv = wave_lv(F.sc, wave);
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
     LANES(l) {
         if (l < NMODE) {
             W.sse[l] = 0;
@@ -84,7 +85,7 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
             Arith a = SM.entry_a[depth];
             const int len0 = arith_len(a);
             prof_add(PF_T_SETUP, pts);
-            Coder c; c.a = a; c.cx = cx; c.sink = lane_bytes(F.sc, wave, l) - a.cnt;
+            Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)((wave * NMODE + l) * TRIAL_BYTES - a.cnt);
             trial_run(J, c, W.u.p2.lvl[l]);
             W.fin[l] = c.a;
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(c.a) - len0);
@@ -100,6 +101,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
     WaveMem &W = SM.W[wave];
     const int q = F.job.q;
     i16 *lv = wave_lv(F.sc, wave);
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
     const RdW rw = rd_weights(q);
     for (int k = 0; k < 4; k++) {
         const Avail ca = child_avail(av, k);
@@ -120,7 +122,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
                 u8 *cx = W.u.p2.cx[l];
                 for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.T.ctx_init[q][i];
                 Arith a; arith_reset(a);
-                Coder c; c.a = a; c.cx = cx; c.sink = lane_bytes(F.sc, wave, l);
+                Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)((wave * NMODE + l) * TRIAL_BYTES);
                 trial_run(J, c, W.u.p2.lvl[l]);
                 W.cost[l] = rd_cost(rw, W.sse[l], arith_len(c.a));
             }
@@ -160,7 +162,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
             for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.entry_cx[2][i];
             Arith a = SM.entry_a[2];
             const int len0 = arith_len(a);
-            Coder c; c.a = a; c.cx = cx; c.sink = lane_bytes(F.sc, wave, 0) - a.cnt;
+            Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)(wave * NMODE * TRIAL_BYTES - a.cnt);
             trial_run(J, c, W.u.p2.lvl[0]);
             W.fin[0] = c.a;
             W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(c.a) - len0);
@@ -260,7 +262,8 @@ HDN void enter_cu(int depth, int N, int y0, int x0, int code_split) {
                 const int uy = y0 >> 2, ux = x0 >> 2;
                 const int big_l = N > nb_size(uy, ux - 1), big_a = N > nb_size(uy - 1, ux);
                 Arith a = SM.live;
-                code_bin(a, SM.cx, live_sink, CX_SPLIT_CU + big_l + big_a, 1);
+                Sink ls; ls.base = live_sink; ls.off = 0;
+                code_bin(a, SM.cx, ls, CX_SPLIT_CU + big_l + big_a, 1);
                 SM.live = a;
             }
         }
@@ -350,7 +353,8 @@ HDN void encode_ctu() {
         }
         if (tid == 64) {
             Arith a = SM.live;
-            code_terminate(a, live_sink, (cy + 32 >= J.hp) && (cx + 32 >= J.wp));
+            Sink ls; ls.base = live_sink; ls.off = 0;
+            code_terminate(a, ls, (cy + 32 >= J.hp) && (cx + 32 >= J.wp));
             SM.live = a;
         }
     }
@@ -390,7 +394,8 @@ HD void encode_frame(const Tables *gT, const FrameJob &job, const Scratch &sc, c
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) {
             Arith a = SM.live;
-            arith_finish(a, job.out + F.out_pos);                                      // :1639-1640
+            Sink ls; ls.base = job.out + F.out_pos; ls.off = 0;
+            arith_finish(a, ls);                                      // :1639-1640
             *job.out_len = F.out_pos + a.cnt;
         }
     }
