@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (BASELINE config 4: 512 x 1080p)")
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 4 frames; just under the 4 x 256 resident-frame capacity of one MI355X)")
     ap.add_argument("--qpd6", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -138,8 +138,8 @@ def main():
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tp):
             t = json.load(open(tp))
-            if t.get("frames") == F and t.get("qpd6") == args.qpd6:
-                traffic = t.get("hbm_bytes_per_launch")
+            if t.get("qpd6") == args.qpd6 and t.get("frames"):       # measured per launch of t["frames"] frames; frames are independent
+                traffic = int(t["hbm_bytes_per_launch"] * F / t["frames"])
         macs = 12320 * hp * wp * F                                          # transform MACs per launch
         line = {
             "metric": "Mpixels/s HEVC intra encode (gray8), bit-exact vs CPU", "value": round(value, 3), "unit": "Mpixels/s",

@@ -84,6 +84,12 @@ HD u8 *uniform_ptr(u8 *p) {
 }
 HD int hibit(u32 v) { return 31 - __clz((int)v); }
 #endif
+// 24-bit multiplies are full rate on the VALU; v_mul_lo_u32 is not.  Only used where both operands provably fit.
+#ifdef IMCVT_HOSTEMU
+HD int mul24(int a, int b) { return a * b; }
+#else
+HD int mul24(int a, int b) { return __mul24(a, b); }
+#endif
 HD int iabs(int v) { return v < 0 ? -v : v; }
 HD int imin(int a, int b) { return a < b ? a : b; }
 HD int imax(int a, int b) { return a > b ? a : b; }
@@ -102,19 +108,20 @@ enum { CX_SPLIT_CU = 0, CX_PART = 3, CX_PREV_INTRA = 4, CX_CHROMA_PRED = 5, CX_S
 struct Tables {
     i8  C[1360];           // forward matrices, row-major [i][k]; offsets {0,16,80,336} for N=4,8,16,32   (:391-464)
     i8  CT[1360];          // their transposes [k][i]
-    u8  cgpos[3][4][64];   // [scan type][log2N-2][g] -> (gy<<3)|gx, coefficient-group scan order        (:1126-1150)
-    u8  cgrank[3][4][64];  // inverse: [type][s][gy*8+gx] -> g
+    u8  cgpos_d[4][64];    // diagonal: [log2N-2][g] -> (gy<<3)|gx, coefficient-group scan order           (:1126-1150)
+    u8  cgrank_d[4][64];   // inverse: [s][gy*8+gx] -> g
+    u8  cgpos_hv[2][4];    // horizontal / vertical group order of an 8x8 TU (4 groups); 4x4 TUs have one group
+    u8  cgrank_hv[2][16];  // inverse, indexed gy*8+gx (only 0,1,8,9 used)
     u8  incg[3][16];       // [type][n] -> (yi<<2)|xi inside a 4x4 group
     u8  incg_rank[3][16];  // inverse: [type][yi*4+xi] -> n
-    u32 lps4[64];          // rangeTabLps rows packed little-endian                                       (:703-712)
-    u8  nextlps[128];      // packed-state transition on LPS                                              (:701)
     uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8        (:700-712)
     u32 posadd[4][3];      // sig_coeff ctx increment per in-group scan position, 2 bits each [pattern][type]  (:1115-1120)
     u64 c4tab[3];          // 4x4-TU sig_coeff ctx per scan position, 4 bits each [type]                  (:1092)
-    u8  ctx_init[5][CTX_STRIDE];   // initial context states per qpd6                                    (:726-784)
     u8  ang[36];           // intraPredAngle + 32                                                         (:282)
     u16 iang[36];          // |invAngle|                                                                  (:283)
 };
+// tables that stay in global memory (read once per frame)
+struct ColdTables { u8 ctx_init[5][CTX_STRIDE]; };   // initial context states per qpd6 (:726-784)
 HD int mat_off(int s) { return s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -136,27 +143,38 @@ struct Border {          // prediction references of one block (:196-257): unfil
     u8 uc, fc; i16 dc;
     u8 ul[68], ua[68], fl[68], fa[68];
 };
-struct BorderS {         // same for blocks <= 16 (the four-TU shape keeps one per mode)
-    u8 uc, fc; i16 dc;
-    u8 ul[36], ua[36], fl[36], fa[36];
+struct BorderS {         // per-mode border of a block <= 16 (four-TU shape): only the variant (filtered or not) that mode uses
+    u8 c, pad_; i16 dc;
+    u8 l[36], a[36];
 };
 
+struct FinState { u32 w0, w1, w2; };   // packed Arith: low | range,nbits,zeros(sat 2),bufbyte | nbytes,cnt
+HD FinState pack_arith(const Arith &a) {
+    FinState f; f.w0 = (u32)a.low;
+    f.w1 = (u32)a.range | (u32)a.nbits << 10 | (u32)imin(a.zeros, 2) << 16 | (u32)a.bufbyte << 18;
+    f.w2 = (u32)a.nbytes | (u32)a.cnt << 16; return f;
+}
+HD Arith unpack_arith(const FinState &f) {
+    Arith a; a.low = (i32)f.w0; a.range = (i32)(f.w1 & 1023); a.nbits = (i32)((f.w1 >> 10) & 63); a.zeros = (i32)((f.w1 >> 16) & 3);
+    a.bufbyte = (i32)(f.w1 >> 18); a.nbytes = (i32)(f.w2 & 0xFFFF); a.cnt = (i32)(f.w2 >> 16); return a;
+}
+
 struct alignas(16) WaveMem {
-    union alignas(16) {
-        struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                 // one pipeline pass
-        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) i16 lvl[NMODE][16]; } p2;                      // trial coders
-    } u;
     Border  bsh;                 // border shared by all modes of a block
-    u8  rec4[NMODE][16];         // 4x4 PU candidates' reconstructions
     i32 last[4][NMODE];          // per TU: last significant scan position (-1: none)
-    u32 cgm[4][NMODE][2];        // per TU: significant-group bitmap, bit gy*8+gx
+    u32 cgm[NMODE][4];           // significant-group bitmap: one TU -> words [c][0..1] (bit gy*8+gx); four TUs (<=16 groups) -> word [c][k]
     i32 sse[NMODE];
     i32 cost[NMODE];
-    Arith fin[NMODE];            // coder state each trial ended in
-    // NxN bookkeeping (PU wave)
-    i32 pu_mode[4], pu_sse[4], pu_last[4];
+    FinState fin[NMODE];         // coder state each trial ended in
+    i32 pu_mode[4], pu_sse[4], pu_last[4];   // NxN bookkeeping (PU wave)
     i32 nxn_cost;
+    union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
+        struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                   // one pipeline pass
+        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) i16 lvl[NMODE][16]; } p2;                      // trial coders
+        struct { u8 pad_[4352]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
+    } u;
 };
+#define WAVE2_BYTES (sizeof(WaveMem) - 7168 + 4352 + NMODE * 16)
 
 // Per-frame job and per-workgroup scratch (global memory)
 struct FrameJob {
@@ -188,8 +206,8 @@ struct FrameCtx {
 
 struct FourTU {                  // state of the four-TU shape (one wave evaluates it at a time)
     BorderS bc[NMODE];           // per-mode borders of TUs 1..3
-    u8  t3row[NMODE][4][16];     // per mode: bottom row / right column of each reconstructed TU
-    u8  t3col[NMODE][4][16];
+    u8  t3row[NMODE][3][16];     // per mode: bottom row / right column of reconstructed TUs 0..2 (TU 3 has no successor)
+    u8  t3col[NMODE][3][16];
 };
 
 struct alignas(16) Shm {
@@ -209,7 +227,8 @@ struct alignas(16) Shm {
     unsigned long long prof[NWAVES][PF_N];
 #endif
     FourTU X;
-    WaveMem W[NWAVES];
+    u8  cx0[CTX_STRIDE];         // fresh context states of this frame's qpd6 (:1505)
+    alignas(16) u8 wraw[2 * sizeof(WaveMem) + WAVE2_BYTES];   // wave slices; the last (4x4-only) one is truncated
 };
 
 // The workgroup's LDS image is one file-scope object, so non-inlined callees still address it with ds_* ops.
@@ -220,6 +239,9 @@ static Shm *g_shm_host;
 __shared__ Shm g_shm;
 #define SM g_shm
 #endif
+#define WM(w) (*(WaveMem *)(SM.wraw + (w) * sizeof(WaveMem)))
+HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
+HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }
 
 // Optional cycle accounting per wave (build with -DIMCVT_PROF): category -> accumulated shader clocks
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
@@ -267,25 +289,21 @@ HD void carry_out(Arith &a, const Sink &sink) {                                 
         } else { a.nbytes = 1; a.bufbyte = lead; }
     }
 }
-HD void code_bin(Arith &a, u8 *cx, const Sink &sink, int ci, int bin) {
-    const Tables &T = SM.T;          // :913-932
+HD void code_bin(Arith &a, u8 *cx, const Sink &sink, int ci, int bin) {                     // :913-932
     const int p = cx[ci];
-    const int lps = (int)((T.lps4[p >> 1] >> (((a.range >> 6) & 3) * 8)) & 0xFF);
-    a.range -= lps;
-    if (bin != (p & 1)) {
-        const int sh = imin(6, clz32((u32)lps) - 23);     // renorm table :714 == 8 - floor(log2 lps), capped at 6
-        cx[ci] = T.nextlps[p];
-        a.low = (a.low + a.range) << sh;
-        a.range = lps << sh;
-        a.nbits -= sh;
-    } else {
-        cx[ci] = (u8)((p < 124) ? p + 2 : p);
-        if (a.range < 256) { a.low <<= 1; a.range <<= 1; a.nbits--; }
-    }
+    const uint2 e = SM.T.pst[p];
+    const int lps = (int)((e.x >> (((a.range >> 6) & 3) * 8)) & 0xFF);
+    const int rm = a.range - lps;
+    const int is_lps = (bin ^ p) & 1;
+    const int sh = is_lps ? imin(6, clz32((u32)lps) - 23) : (rm < 256);     // renorm table :714 == 8 - floor(log2 lps), capped at 6
+    cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
+    a.low = (a.low + (is_lps ? rm : 0)) << sh;
+    a.range = (is_lps ? lps : rm) << sh;
+    a.nbits -= sh;
     carry_out(a, sink);
 }
 HD void code_bypass_chunk(Arith &a, const Sink &sink, int v, int n) {                             // one <=8-bin step of :898-910
-    a.low = (a.low << n) + a.range * v;
+    a.low = (a.low << n) + mul24(a.range, v);      // range <= 510, v <= 255
     a.nbits -= n;
     carry_out(a, sink);
 }
@@ -418,7 +436,7 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
 // ---------------------------------------------------------------------------------------------------
 // Shared border of the block at (y0,x0) from the reconstruction tile.  Wave-uniform call.
 HDN void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int ha, int har) {
-    WaveMem &W = SM.W[wave];
+    WaveMem &W = WM(wave);
     Border &b = W.bsh;
     const int n2 = 2 * N;
     LANES(l) {
@@ -455,54 +473,48 @@ HDN void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int 
 }
 
 // Per-mode borders of TU k (1..3) of the four-TU shape of the CU at (y0,x0,N): samples inside the CU come
-// from that mode's own reconstruction of TUs < k (:1459,1466), the rest from the tile.
+// from that mode's own reconstruction of TUs < k (:1459,1466), the rest from the tile.  Only the variant the mode
+// predicts from is stored (mode c of size h uses either the unfiltered or the [1 2 1]-filtered border, :274-289).
+struct TuSrc { const u8 *col0, *col2, *row0, *row1, *ab, *lf; int k, h, hl, hbl, ha, har, uc; };
+HD int tu_left(const TuSrc &s, int i) {          // unfiltered left / below-left sample i (0..2h-1)
+    const int h = s.h;
+    if (s.k == 1) return (i < h) ? s.col0[i] : s.col0[h - 1];
+    if (s.k == 2) return (i < h) ? (s.hl ? s.lf[i * RS] : s.uc) : (s.hbl ? s.lf[i * RS] : (s.hl ? s.lf[(h - 1) * RS] : s.uc));
+    return (i < h) ? s.col2[i] : s.col2[h - 1];
+}
+HD int tu_above(const TuSrc &s, int i) {         // unfiltered above / above-right sample i
+    const int h = s.h;
+    if (s.k == 1) return (i < h) ? (s.ha ? s.ab[i] : s.uc) : (s.har ? s.ab[i] : (s.ha ? s.ab[h - 1] : s.uc));
+    if (s.k == 2) return (i < h) ? s.row0[i] : s.row1[i - h];
+    return (i < h) ? s.row1[i] : s.row1[h - 1];
+}
 HDN void border_tu_split(int wave, int N, int y0, int x0, int k, int hl, int hbl, int ha, int har) {
-    WaveMem &W = SM.W[wave];
     const int h = N / 2, n2 = N;   // 2*h entries per side
     LANES(l) {
         for (int e = l; e < NMODE * n2; e += 64) {
             const int c = e / n2, i = e - c * n2;
             BorderS &b = SM.X.bc[c];
-            int uc, lv_, av_;
-            if (k == 1) {
-                const u8 *col0 = SM.X.t3col[c][0];
-                const u8 *ab = &SM.rec[y0][x0 + h + 1];                     // row y0-1, starting at column x0+h
-                uc = ha ? ab[-1] : col0[0];
-                lv_ = (i < h) ? col0[i] : col0[h - 1];
-                av_ = (i < h) ? (ha ? ab[i] : uc) : (har ? ab[i] : (ha ? ab[h - 1] : uc));
-            } else if (k == 2) {
-                const u8 *lf = &SM.rec[y0 + h + 1][x0];                     // column x0-1, starting at row y0+h
-                const u8 *row0 = SM.X.t3row[c][0], *row1 = SM.X.t3row[c][1];
-                uc = hl ? lf[-RS] : row0[0];
-                lv_ = (i < h) ? (hl ? lf[i * RS] : uc) : (hbl ? lf[i * RS] : (hl ? lf[(h - 1) * RS] : uc));
-                av_ = (i < h) ? row0[i] : row1[i - h];
-            } else {
-                const u8 *col2 = SM.X.t3col[c][2], *row1 = SM.X.t3row[c][1];
-                uc = SM.X.t3row[c][0][h - 1];
-                lv_ = (i < h) ? col2[i] : col2[h - 1];
-                av_ = (i < h) ? row1[i] : row1[h - 1];
+            TuSrc s;
+            s.k = k; s.h = h; s.hl = hl; s.hbl = hbl; s.ha = ha; s.har = har;
+            s.col0 = SM.X.t3col[c][0]; s.col2 = SM.X.t3col[c][2]; s.row0 = SM.X.t3row[c][0]; s.row1 = SM.X.t3row[c][1];
+            s.ab = &SM.rec[y0][x0 + h + 1];                       // row y0-1, starting at column x0+h
+            s.lf = &SM.rec[y0 + h + 1][x0];                       // column x0-1, starting at row y0+h
+            s.uc = (k == 1) ? (ha ? s.ab[-1] : s.col0[0]) : (k == 2) ? (hl ? s.lf[-RS] : s.row0[0]) : s.row0[h - 1];
+            const int filt = uses_filtered(h, c);
+            int lv_ = tu_left(s, i), av_ = tu_above(s, i);
+            if (filt && i != n2 - 1) {                             // [1 2 1]/4, ends unfiltered (:246-256)
+                const int lp = (i == 0) ? s.uc : tu_left(s, i - 1), ap = (i == 0) ? s.uc : tu_above(s, i - 1);
+                lv_ = (2 + 2 * lv_ + lp + tu_left(s, i + 1)) >> 2;
+                av_ = (2 + 2 * av_ + ap + tu_above(s, i + 1)) >> 2;
             }
-            b.ul[i] = (u8)lv_; b.ua[i] = (u8)av_;
-            if (i == 0) { b.uc = (u8)uc; b.ul[n2] = 0; b.ua[n2] = 0; b.fl[n2] = 0; b.fa[n2] = 0; }
-        }
-    }
-    wave_sync();
-    LANES(l) {
-        for (int e = l; e < NMODE * n2; e += 64) {
-            const int c = e / n2, i = e - c * n2;
-            BorderS &b = SM.X.bc[c];
-            int fl_, fa_;
-            if (i == 0) { fl_ = (2 + 2 * b.ul[0] + b.ul[1] + b.uc) >> 2; fa_ = (2 + 2 * b.ua[0] + b.ua[1] + b.uc) >> 2; }
-            else if (i == n2 - 1) { fl_ = b.ul[i]; fa_ = b.ua[i]; }
-            else { fl_ = (2 + 2 * b.ul[i] + b.ul[i - 1] + b.ul[i + 1]) >> 2; fa_ = (2 + 2 * b.ua[i] + b.ua[i - 1] + b.ua[i + 1]) >> 2; }
-            b.fl[i] = (u8)fl_; b.fa[i] = (u8)fa_;
-        }
-        if (l < NMODE) {
-            BorderS &b = SM.X.bc[l];
-            int dc = h;
-            for (int i = 0; i < h; i++) dc += b.ul[i] + b.ua[i];
-            b.dc = (i16)(dc / (2 * h));
-            b.fc = (u8)((2 + b.ul[0] + b.ua[0] + 2 * b.uc) >> 2);
+            b.l[i] = (u8)lv_; b.a[i] = (u8)av_;
+            if (i == 0) {
+                b.c = (u8)(filt ? (2 + tu_left(s, 0) + tu_above(s, 0) + 2 * s.uc) >> 2 : s.uc);
+                b.l[n2] = 0; b.a[n2] = 0;
+                int dc = h;                                         // DC always predicts from the unfiltered border
+                for (int j = 0; j < h; j++) dc += tu_left(s, j) + tu_above(s, j);
+                b.dc = (i16)(dc / (2 * h));
+            }
         }
     }
     wave_sync();
@@ -521,6 +533,7 @@ struct P1Args {
     int per_mode_border; // 0: W.bsh, 1: SM.X.bc[c]
     int out_kind;        // what to keep of the reconstruction
     int only_mode;       // -1: all 35 modes, else just this one (winner reconstruction)
+    int cg_words2;       // 1: the TU has up to 64 groups (bitmap in cgm[c][0..1]); 0: <=16 groups (cgm[c][k])
     i16 *lv;             // global levels base for this TU: [c][N*N], scan order (may be null for only_mode)
     int q;
 };
@@ -596,7 +609,7 @@ HD int rdoq_group(int acc[4][4], const QConst &Q) {
         if (l0 > 0) {                                   // level 0 alone needs no pricing
             // candidates l0, l0-1, l0-2 (>= 0), the larger level winning ties (:570-578)
             const int e0 = iabs(d - (l0 << Q.sh)) >> dsh;
-            const int c0 = rd_cost(Q.rw, ((e0 < 46340) ? e0 * e0 : I32MAX) >> 7, level_rate(l0));
+            const int c0 = rd_cost(Q.rw, ((e0 < 46340) ? e0 * e0 : I32MAX) >> 7, level_rate(l0));   // e*e needs 32 bits
             const int e1 = iabs(d - ((l0 - 1) << Q.sh)) >> dsh;
             const int c1 = rd_cost(Q.rw, ((e1 < 46340) ? e1 * e1 : I32MAX) >> 7, level_rate(l0 - 1));
             int best = c0; pick = l0;
@@ -618,7 +631,7 @@ HD int rdoq_group(int acc[4][4], const QConst &Q) {
 // Store the levels of a coded group in scan order, book `last` / group bitmap, and dequantise acc in place.
 HD void emit_group(WaveMem &W, const P1Args &P, int acc[4][4], int c, int st, int s, int by, int bx, int NN, int dq) {
     const Tables &T = SM.T;
-    const int g = T.cgrank[st][s][by * 8 + bx];
+    const int g = cg_rank(st, s, by * 8 + bx);
     i16 *lvg = P.lv ? P.lv + (size_t)c * NN + g * 16 : (i16 *)0;     // only coded groups are ever read back
     int hi = 0;
     for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
@@ -631,21 +644,21 @@ HD void emit_group(WaveMem &W, const P1Args &P, int acc[4][4], int c, int st, in
     if (P.only_mode < 0) {
         lds_max(&W.last[P.k][c], g * 16 + hi);
         const int bit = by * 8 + bx;
-        lds_or(&W.cgm[P.k][c][bit >> 5], 1u << (bit & 31));
+        if (P.cg_words2) lds_or(&W.cgm[c][bit >> 5], 1u << (bit & 31)); else lds_or(&W.cgm[c][P.k], 1u << bit);
     }
 }
 
 HD int scan_type_of(int N, int mode) { return (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0; }   // :1133-1141
 
 HD void fill_border_ref(BorderRef &br, const WaveMem &W, int per_mode, int c) {
-    if (per_mode) { const BorderS &b = SM.X.bc[c]; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
+    if (per_mode) { const BorderS &b = SM.X.bc[c]; br.ul = b.l; br.ua = b.a; br.fl = b.l; br.fa = b.a; br.uc = b.c; br.fc = b.c; br.dc = b.dc; }
     else { const Border &b = W.bsh; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
 }
 
 // ---- 4x4 blocks: one lane owns the whole block, so the pipeline runs entirely in registers (DST constants are
 // immediates, no LDS intermediates, no wave syncs between the stages).
 HDN void p1_run_4(int wave, const P1Args P) {
-    WaveMem &W = SM.W[wave];
+    WaveMem &W = WM(wave);
     const Tables &T = SM.T;
     const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
     const QConst Q = qconst<0>(P.q);
@@ -703,11 +716,11 @@ HDN void p1_run_4(int wave, const P1Args P) {
                     const int rc = clip3(x[yi][xi] + pr[yi][xi], 0, 255);
                     const int d = (int)((ow >> (8 * xi)) & 255) - rc;
                     part += d * d;
-                    if (P.out_kind == OUT_REC4) W.rec4[c][yi * 4 + xi] = (u8)rc;
+                    if (P.out_kind == OUT_REC4) W.u.w2.rec4[c][yi * 4 + xi] = (u8)rc;
                     else if (P.out_kind == OUT_TILE) SM.rec[P.y0 + yi + 1][P.x0 + xi + 1] = (u8)rc;
                     else if (P.out_kind == OUT_T3SIDE) {
-                        if (yi == 3) SM.X.t3row[c][P.k][xi] = (u8)rc;
-                        if (xi == 3) SM.X.t3col[c][P.k][yi] = (u8)rc;
+                        if (P.k < 3 && yi == 3) SM.X.t3row[c][P.k][xi] = (u8)rc;
+                        if (P.k < 3 && xi == 3) SM.X.t3col[c][P.k][yi] = (u8)rc;
                     }
                 }
             }
@@ -720,7 +733,7 @@ HDN void p1_run_4(int wave, const P1Args P) {
 template <int LG>
 HDN void p1_run_t(int wave, const P1Args P) {
     constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
-    WaveMem &W = SM.W[wave];
+    WaveMem &W = WM(wave);
     const Tables &T = SM.T;
     const i8 *C = T.C + mat_off(s), *CT = T.CT + mat_off(s);
     const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
@@ -825,8 +838,8 @@ HDN void p1_run_t(int wave, const P1Args P) {
                         part += d * d;
                         if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
                         else if (P.out_kind == OUT_T3SIDE) {
-                            if (y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
-                            if (x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
+                            if (P.k < 3 && y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
+                            if (P.k < 3 && x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
                         }
                     }
                 }
@@ -858,20 +871,7 @@ HD void p1_run(int wave, const P1Args &P) {
 
 struct Coder { Arith a; u8 *cx; Sink sink; };
 
-HD void put_bin(Coder &c, int ci, int bin) {                                               // :913-932
-    Arith &a = c.a;
-    const int p = c.cx[ci];
-    const uint2 e = SM.T.pst[p];
-    const int lps = (int)((e.x >> (((a.range >> 6) & 3) * 8)) & 0xFF);
-    const int rm = a.range - lps;
-    const int is_lps = (bin ^ p) & 1;
-    const int sh = is_lps ? imin(6, clz32((u32)lps) - 23) : (rm < 256);
-    c.cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
-    a.low = (a.low + (is_lps ? rm : 0)) << sh;
-    a.range = (is_lps ? lps : rm) << sh;
-    a.nbits -= sh;
-    carry_out(a, c.sink);
-}
+HD void put_bin(Coder &c, int ci, int bin) { code_bin(c.a, c.cx, c.sink, ci, bin); }
 HD void put_bypass(Coder &c, int v, int len) {                                             // :898-910
     v &= (1 << len) - 1;
     while (len > 0) { const int n = imin(len, 8); len -= n; code_bypass_chunk(c.a, c.sink, (v >> len) & ((1 << n) - 1), n); }
@@ -918,8 +918,11 @@ HD void put_last_pos(Coder &c, int s, int st, int y, int x) {                   
 }
 
 HD void put_remaining(Coder &c, int v, int k) {                                            // :1153-1168
-    if (v < (3 << k)) { const int p = v >> k; put_bypass(c, (1 << (p + 1)) - 2, p + 1); put_bypass(c, v & ((1 << k) - 1), k); }
-    else {
+    if (v < (3 << k)) {                                  // prefix of <=3 bins, suffix of k<=4 bins: one chunk each
+        const int p = v >> k;
+        code_bypass_chunk(c.a, c.sink, (1 << (p + 1)) - 2, p + 1);
+        if (k) code_bypass_chunk(c.a, c.sink, v & ((1 << k) - 1), k);
+    } else {
         int n = k; v -= 3 << k;
         for (; v >= (1 << n); n++) v -= 1 << n;
         const int t = 4 + n - k;
@@ -978,13 +981,13 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
         const i16 *lvk = J.lv[k];
         const int glast = last >> 4;
         {
-            const int gp = T.cgpos[st][s][glast], in = T.incg[st][last & 15];
+            const int gp = cg_pos(st, s, glast), in = T.incg[st][last & 15];
             put_last_pos(c, s, st, (gp >> 3) * 4 + (in >> 2), (gp & 7) * 4 + (in & 3));
         }
         int c1 = 1;
         NOUNROLL
         for (int g = glast; g >= 0; g--) {
-            const int gp = T.cgpos[st][s][g], gy = gp >> 3, gx = gp & 7, bit = gy * 8 + gx;
+            const int gp = cg_pos(st, s, g), gy = gp >> 3, gx = gp & 7, bit = gy * 8 + gx;
             const int coded = (int)(((bit < 32 ? m0 >> bit : m1 >> (bit - 32))) & 1);
             const int rbit = bit + 1, bbit = bit + 8;
             const int right = (gx < ncg - 1) ? (int)(((rbit < 32 ? m0 >> rbit : m1 >> (rbit - 32))) & 1) : 0;
@@ -1000,6 +1003,7 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
                 u32 *d = (u32 *)lvl;
                 d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
             }
+            const long long ptA = prof_now();
             // significance context of scan position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
             u64 tab; int fbits, base;
             if (Ntu == 4) { tab = T.c4tab[st]; fbits = 4; base = 0; }
@@ -1021,7 +1025,9 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
                 }
                 if (in & (v != 0)) { nnz++; signs = (signs << 1) | (v < 0); nzm |= 1u << n; }
             }
+            prof_add(PF_T_GEN, ptA);
             if (nnz == 0) continue;
+            const long long ptB = prof_now();
             // -- pass B: greater-1 flags of the first 8 non-zero levels (scan-reverse order), then one greater-2 flag
             const int set = (dcg ? 0 : 2) + (c1 == 0);
             int esc = nnz > 8, g2 = -1;
@@ -1040,7 +1046,10 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
                 }
             }
             if (c1 == 0 && g2 >= 0) { put_bin(c, CX_GT2 + set, g2); esc |= g2; }
-            put_bypass(c, signs, nnz);
+            if (nnz > 8) { code_bypass_chunk(c.a, c.sink, (signs >> (nnz - 8)) & 0xFF, 8); code_bypass_chunk(c.a, c.sink, signs & ((1 << (nnz - 8)) - 1), nnz - 8); }
+            else code_bypass_chunk(c.a, c.sink, signs, nnz);
+            prof_add(PF_T_DRAIN, ptB); prof_cnt(PF_T_NTOK, 1);
+            const long long ptC = prof_now();
             // -- pass C: remaining absolute levels
             if (esc) {
                 int base2 = 3, rice = 0, j = 0; u32 m = nzm;
@@ -1054,6 +1063,7 @@ HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
                     j++;
                 }
             }
+            prof_add(PF_T_NDRAIN, ptC);
         }
     }
 }

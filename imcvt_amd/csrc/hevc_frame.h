@@ -33,19 +33,19 @@ HD int nb_mode(const int uy, int ux) { return SM.mapmode[uy + 1][ux + 1]; }
 // ---- one candidate set: 2Nx2N with one TU (shape 0) or four TUs (shape 1); wave-uniform call --------------------
 HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
-    WaveMem &W = SM.W[wave];
+    WaveMem &W = WM(wave);
     const int q = F.job.q, h = N / 2;
     i16 *lv = wave_lv(F.sc, wave);
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
     LANES(l) {
         if (l < NMODE) {
             W.sse[l] = 0;
-            for (int k = 0; k < 4; k++) { W.last[k][l] = -1; W.cgm[k][l][0] = 0; W.cgm[k][l][1] = 0; }
+            for (int k = 0; k < 4; k++) { W.last[k][l] = -1; W.cgm[l][k] = 0; }
         }
     }
     wave_sync();
     P1Args P;
-    P.q = q; P.only_mode = -1;
+    P.q = q; P.only_mode = -1; P.cg_words2 = (shape == 0);
     long long pt = prof_now();
     if (shape == 0) {
         border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
@@ -77,7 +77,7 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
             const int nt = shape ? 4 : 1, tn = shape ? h * h : N * N;
             for (int k = 0; k < nt; k++) {
                 J.lv[k] = lv + (size_t)k * NMODE * tn + (size_t)l * tn;
-                J.last[k] = W.last[k][l]; J.cg0[k] = W.cgm[k][l][0]; J.cg1[k] = W.cgm[k][l][1];
+                J.last[k] = W.last[k][l]; J.cg0[k] = shape ? W.cgm[l][k] : W.cgm[l][0]; J.cg1[k] = shape ? 0u : W.cgm[l][1];
             }
             const long long pts = prof_now();
             u8 *cx = W.u.p2.cx[l];
@@ -87,7 +87,7 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
             prof_add(PF_T_SETUP, pts);
             Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)((wave * NMODE + l) * TRIAL_BYTES - a.cnt);
             trial_run(J, c, W.u.p2.lvl[l]);
-            W.fin[l] = c.a;
+            W.fin[l] = pack_arith(c.a);
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(c.a) - len0);
         }
     }
@@ -98,7 +98,7 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
 // ---- the NxN chain of an 8x8 CU (:1490-1543); wave-uniform call ---------------------------------------------------
 HDN void eval_NxN(int wave, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
-    WaveMem &W = SM.W[wave];
+    WaveMem &W = WM(wave);
     const int q = F.job.q;
     i16 *lv = wave_lv(F.sc, wave);
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
@@ -106,21 +106,21 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
     for (int k = 0; k < 4; k++) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
-        LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.last[0][l] = -1; W.cgm[0][l][0] = 0; W.cgm[0][l][1] = 0; } }
+        LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.last[0][l] = -1; W.cgm[l][0] = 0; } }
         wave_sync();
         long long pt = prof_now();
         border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
         P1Args P;
-        P.q = q; P.only_mode = -1; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4; P.lv = lv;
+        P.q = q; P.only_mode = -1; P.cg_words2 = 0; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4; P.lv = lv;
         p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             if (l < NMODE) {
                 TrialJob J;
                 J.N = 8; J.shape = 3; J.ctx_split = -1; J.mode[0] = l; J.ml[0] = 0; J.ma[0] = 0;
-                J.lv[0] = lv + l * 16; J.last[0] = W.last[0][l]; J.cg0[0] = W.cgm[0][l][0]; J.cg1[0] = 0;
+                J.lv[0] = lv + l * 16; J.last[0] = W.last[0][l]; J.cg0[0] = W.cgm[l][0]; J.cg1[0] = 0;
                 u8 *cx = W.u.p2.cx[l];
-                for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.T.ctx_init[q][i];
+                for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.cx0[i];
                 Arith a; arith_reset(a);
                 Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)((wave * NMODE + l) * TRIAL_BYTES);
                 trial_run(J, c, W.u.p2.lvl[l]);
@@ -141,7 +141,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
             if (l < 16) {
                 const int bm = W.pu_mode[k];
                 g_st16(lv + NMODE * 16 + k * 16 + l, (W.pu_last[k] >= 0) ? (int)g_ld16(lv + bm * 16 + l) : 0);   // kept beside the candidates' levels
-                SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.rec4[bm][l];
+                SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
             }
         }
         wave_sync();
@@ -164,7 +164,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
             const int len0 = arith_len(a);
             Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)(wave * NMODE * TRIAL_BYTES - a.cnt);
             trial_run(J, c, W.u.p2.lvl[0]);
-            W.fin[0] = c.a;
+            W.fin[0] = pack_arith(c.a);
             W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(c.a) - len0);
         }
     }
@@ -186,13 +186,13 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) {
             int best = (N > 8) ? SM.split_cost[depth] : I32MAX, kind = 0, mode = 0;
-            for (int m = 0; m < NMODE; m++) if (best >= SM.W[0].cost[m]) { best = SM.W[0].cost[m]; kind = 1; mode = m; }
-            for (int m = 0; m < NMODE; m++) if (best >= SM.W[1].cost[m]) { best = SM.W[1].cost[m]; kind = 2; mode = m; }
-            if (N == 8 && best >= SM.W[2].nxn_cost) { best = SM.W[2].nxn_cost; kind = 3; }
+            for (int m = 0; m < NMODE; m++) if (best >= WM(0).cost[m]) { best = WM(0).cost[m]; kind = 1; mode = m; }
+            for (int m = 0; m < NMODE; m++) if (best >= WM(1).cost[m]) { best = WM(1).cost[m]; kind = 2; mode = m; }
+            if (N == 8 && best >= WM(2).nxn_cost) { best = WM(2).nxn_cost; kind = 3; }
             SM.win_kind = kind; SM.win_mode = mode;
             if (F.sc.trace && F.trace_n + 8 <= F.sc.trace_cap) {
                 i32 *t = F.sc.trace + F.trace_n;
-                t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = N; t[3] = kind; t[4] = (kind == 3) ? (SM.W[2].pu_mode[0] | SM.W[2].pu_mode[1] << 8 | SM.W[2].pu_mode[2] << 16 | SM.W[2].pu_mode[3] << 24) : mode;
+                t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = N; t[3] = kind; t[4] = (kind == 3) ? (WM(2).pu_mode[0] | WM(2).pu_mode[1] << 8 | WM(2).pu_mode[2] << 16 | WM(2).pu_mode[3] << 24) : mode;
                 t[5] = best; t[6] = 0; t[7] = 0;
                 F.trace_n += 8;
             }
@@ -202,19 +202,19 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
     const int kind = SM.win_kind, mode = SM.win_mode;
     if (kind != 0) {
         const int ww = (kind == 3) ? 2 : kind - 1, wl = (kind == 3) ? 0 : mode;
-        const int cnt0 = SM.entry_a[depth].cnt, cnt1 = SM.W[ww].fin[wl].cnt;
+        const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WM(ww).fin[wl].w2 >> 16);
         const u8 *src = lane_bytes(F.sc, ww, wl);
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
             for (int i = tid; i < cnt1 - cnt0; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(src + i));
-            if (tid < CTX_STRIDE) SM.cx[tid] = SM.W[ww].u.p2.cx[wl][tid];
-            if (tid == 64) SM.live = SM.W[ww].fin[wl];
+            if (tid < CTX_STRIDE) SM.cx[tid] = WM(ww).u.p2.cx[wl][tid];
+            if (tid == 64) SM.live = unpack_arith(WM(ww).fin[wl]);
             if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445, :1549-1553)
                 const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
                 if (i < n && j < n) {
                     const int uy = (y0 >> 2) + i, ux = (x0 >> 2) + j;
                     SM.mapsz[uy + 1][ux + 1] = (u8)N;
-                    SM.mapmode[uy + 1][ux + 1] = (u8)((kind == 3) ? SM.W[2].pu_mode[i * 2 + j] : mode);
+                    SM.mapmode[uy + 1][ux + 1] = (u8)((kind == 3) ? WM(2).pu_mode[i * 2 + j] : mode);
                 }
             }
         }
@@ -225,7 +225,7 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
                 if (w == 0) {
                     const int wave = 0;
                     P1Args P;
-                    P.q = F.job.q; P.only_mode = mode; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.lv = (i16 *)0;
+                    P.q = F.job.q; P.only_mode = mode; P.cg_words2 = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.lv = (i16 *)0;
                     if (kind == 1) {
                         border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
                         P.N = N; P.y0 = y0; P.x0 = x0;
@@ -278,6 +278,7 @@ HDN void price_split(int depth, int N, int y0, int x0) {
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
         int part = 0;
+        NOUNROLL
         for (int i = tid; i < N * N; i += WG_THREADS) {
             const int y = y0 + i / N, x = x0 + i % N;
             const int d = (int)SM.org[y][x] - SM.rec[y + 1][x + 1];
@@ -295,13 +296,14 @@ HDN void price_split(int depth, int N, int y0, int x0) {
     wg_sync();
 }
 
-HDN void encode_ctu() {
+HD void encode_ctu() {
     const FrameJob J = F.job;
     const int cy = F.ctu_y, cx = F.ctu_x;
     Avail a32; a32.l = cx > 0; a32.bl = 0; a32.a = cy > 0; a32.ar = (cy > 0) && (cx + 32 < J.wp);
     // ---- load the CTU: source pixels replicate the original edges, neighbours come from the padded reconstruction (:1613-1621)
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
+        NOUNROLL
         for (int i = tid; i < 1024; i += WG_THREADS) {
             const int y = i >> 5, x = i & 31;
             SM.org[y][x] = g_ld8(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1));
@@ -342,6 +344,7 @@ HDN void encode_ctu() {
     u8 *live_sink = J.out + F.out_pos;
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
+        NOUNROLL
         for (int i = tid; i < 1024; i += WG_THREADS) {
             const int y = i >> 5, x = i & 31;
             g_st8(J.rcon + (size_t)(cy + y) * J.wp + cx + x, SM.rec[y + 1][x + 1]);
@@ -364,10 +367,11 @@ HDN void encode_ctu() {
 }
 
 // Encode one frame with one workgroup.  `hdr` = the stream headers, prepared on the host (:664-690).
-HD void encode_frame(const Tables *gT, const FrameJob &job, const Scratch &sc, const u8 *hdr) {
+HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job, const Scratch sc, const u8 *hdr) {
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
         const u32 *src = (const u32 *)gT; u32 *dst = (u32 *)&SM.T;
+        NOUNROLL
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
         for (int i = tid; i < job.hdr_len; i += WG_THREADS) g_st8(job.out + i, g_ld8(hdr + i));
         if (tid == 0) { F.job = job; F.sc = sc; F.out_pos = job.hdr_len; F.trace_n = 0; F.ctu_y = 0; F.ctu_x = 0; }
@@ -378,7 +382,7 @@ HD void encode_frame(const Tables *gT, const FrameJob &job, const Scratch &sc, c
     wg_sync();
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
-        if (tid < CTX_STRIDE) SM.cx[tid] = SM.T.ctx_init[job.q][tid];
+        if (tid < CTX_STRIDE) { const u8 v = g_ld8(&gK->ctx_init[job.q][tid]); SM.cx[tid] = v; SM.cx0[tid] = v; }
         if (tid == 64) arith_reset(SM.live);
     }
     wg_sync();

@@ -17,7 +17,7 @@
 
 #define HDR_MAX 96
 
-__global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const FrameJob *jobs, const u8 *hdrs, int njobs,
+__global__ __launch_bounds__(WG_THREADS, 4) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof) {
     __shared__ int next_frame;
     for (;;) {
@@ -30,14 +30,14 @@ __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables
         sc.trace = (f == 0) ? trace : (i32 *)0;
         sc.trace_cap = trace_cap;
         sc.prof = prof;
-        encode_frame(gT, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
+        encode_frame(gT, gK, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 struct imcvt_hevc_ctx {
     int device = 0, max_wg = 0;
-    Tables *d_tables = nullptr;
+    Tables *d_tables = nullptr; ColdTables *d_cold = nullptr;
     Scratch *d_scratch = nullptr;
     void *d_pool = nullptr;            // backing store of all per-workgroup scratch
     int *d_counter = nullptr;
@@ -73,19 +73,31 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     imcvt_hevc_ctx *c = new imcvt_hevc_ctx();
     hipDeviceProp_t prop;
     if (hipGetDevice(&c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return nullptr; }
-    c->max_wg = max_workgroups > 0 ? max_workgroups : 3 * prop.multiProcessorCount;   // LDS (52 KB) and registers (168) admit 3 per CU
-    Tables *T = new Tables();
-    imcvt::build_tables(*T);
+    {   // Full residency (4 workgroups x 3 waves per CU) needs private-segment memory for every resident wave; ROCr
+        // throttles wave launch when that exceeds its scratch limit, so raise the limit to what this kernel needs.
+        hipFuncAttributes fa; size_t cur = 0, mx = 0;
+        if (hipFuncGetAttributes(&fa, (const void *)hevc_encode_frames) == hipSuccess
+            && hipDeviceGetLimit(&cur, hipExtLimitScratchCurrent) == hipSuccess && hipDeviceGetLimit(&mx, hipExtLimitScratchMax) == hipSuccess) {
+            const size_t need = (size_t)fa.localSizeBytes * 64 * 32 * prop.multiProcessorCount + (64u << 20);   // sized for 32 waves/CU like ROCr does
+            if (getenv("IMCVT_HEVC_VERBOSE")) fprintf(stderr, "imcvt_hevc: scratch limit cur=%zu max=%zu need=%zu (%zu B/lane)\n", cur, mx, need, (size_t)fa.localSizeBytes);
+            if (cur < need) (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, need < mx ? need : mx);
+        } else (void)hipGetLastError();
+    }
+    c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
+    Tables *T = new Tables(); ColdTables *K = new ColdTables();
+    imcvt::build_tables(*T, *K);
     const size_t per_wg = align256(kLvBytes) + align256(kTrialBytes) + align256(kAboveBytes);
     bool ok = hipMalloc(&c->d_tables, sizeof(Tables)) == hipSuccess
            && hipMemcpy(c->d_tables, T, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess
+           && hipMalloc(&c->d_cold, sizeof(ColdTables)) == hipSuccess
+           && hipMemcpy(c->d_cold, K, sizeof(ColdTables), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_counter, sizeof(int)) == hipSuccess
            && hipMalloc(&c->d_prof, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
            && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
            && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    delete T;
+    delete T; delete K;
     if (ok) {
         std::vector<Scratch> hs(c->max_wg);
         for (int i = 0; i < c->max_wg; i++) {
@@ -103,7 +115,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
 
 extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
     if (!c) return;
-    hipFree(c->d_tables); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof);
+    hipFree(c->d_tables); hipFree(c->d_cold); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof);
     hipFree(c->d_jobs); hipFree(c->d_hdrs);
     if (c->h_jobs) hipHostFree(c->h_jobs);
     if (c->h_hdrs) hipHostFree(c->h_hdrs);
@@ -145,10 +157,23 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     const int grid = n < c->max_wg ? n : c->max_wg;
     HIPCHK(hipEventRecord(c->ev0, stream));
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream,
-                       c->d_tables, c->d_jobs, c->d_hdrs, n, c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof);
+                       c->d_tables, c->d_cold, c->d_jobs, c->d_hdrs, n, c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;
+    return 0;
+}
+
+extern "C" int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds_per_block, int *lds_per_cu) {
+    if (!have_device()) return IMCVT_ERR_NO_DEVICE;
+    int nb = 0, dev = 0; hipDeviceProp_t prop; hipFuncAttributes fa;
+    HIPCHK(hipGetDevice(&dev)); HIPCHK(hipGetDeviceProperties(&prop, dev));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hevc_encode_frames, WG_THREADS, 0));
+    HIPCHK(hipFuncGetAttributes(&fa, (const void *)hevc_encode_frames));
+    if (blocks_per_cu) *blocks_per_cu = nb;
+    if (cus) *cus = prop.multiProcessorCount;
+    if (lds_per_block) *lds_per_block = (int)fa.sharedSizeBytes;
+    if (lds_per_cu) *lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     return 0;
 }
 

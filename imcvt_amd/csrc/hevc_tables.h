@@ -43,8 +43,8 @@ inline int dct_entry(int n, int i, int j) {
     return (m > 32) ? -kCos32[64 - m] : kCos32[m];
 }
 
-inline void build_tables(Tables &T) {
-    memset(&T, 0, sizeof(T));
+inline void build_tables(Tables &T, ColdTables &K) {
+    memset(&T, 0, sizeof(T)); memset(&K, 0, sizeof(K));
     for (int s = 0; s < 4; s++) {
         const int n = 4 << s, off = s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336;
         for (int i = 0; i < n; i++) for (int k = 0; k < n; k++) {
@@ -57,20 +57,22 @@ inline void build_tables(Tables &T) {
     for (int d = 0; d < 7; d++) for (int y = (d < 3 ? d : 3); y >= 0; y--) { const int x = d - y; if (x > 3) continue; T.incg[0][n++] = (u8)((y << 2) | x); }
     for (int k = 0; k < 16; k++) { T.incg[1][k] = (u8)(((k >> 2) << 2) | (k & 3)); T.incg[2][k] = (u8)(((k & 3) << 2) | (k >> 2)); }
     for (int t = 0; t < 3; t++) for (int k = 0; k < 16; k++) T.incg_rank[t][T.incg[t][k]] = (u8)k;
-    // group orders
-    for (int t = 0; t < 3; t++) for (int s = 0; s < 4; s++) {
+    // group orders: diagonal for every size; horizontal / vertical only exist for 8x8 TUs (2x2 groups)
+    for (int s = 0; s < 4; s++) {
         const int ncg = 1 << s; int m = 0;
-        if (t == 0) { for (int d = 0; d < 2 * ncg - 1; d++) for (int y = (d < ncg - 1 ? d : ncg - 1); y >= 0; y--) { const int x = d - y; if (x >= ncg) continue; T.cgpos[t][s][m++] = (u8)((y << 3) | x); } }
-        else if (t == 1) { for (int y = 0; y < ncg; y++) for (int x = 0; x < ncg; x++) T.cgpos[t][s][m++] = (u8)((y << 3) | x); }
-        else { for (int x = 0; x < ncg; x++) for (int y = 0; y < ncg; y++) T.cgpos[t][s][m++] = (u8)((y << 3) | x); }
-        for (int g = 0; g < m; g++) T.cgrank[t][s][T.cgpos[t][s][g]] = (u8)g;     // index (gy<<3)|gx == gy*8+gx
+        for (int d = 0; d < 2 * ncg - 1; d++) for (int y = (d < ncg - 1 ? d : ncg - 1); y >= 0; y--) { const int x = d - y; if (x >= ncg) continue; T.cgpos_d[s][m++] = (u8)((y << 3) | x); }
+        for (int g = 0; g < m; g++) T.cgrank_d[s][T.cgpos_d[s][g]] = (u8)g;     // index (gy<<3)|gx == gy*8+gx
     }
+    { int m = 0; for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) T.cgpos_hv[0][m++] = (u8)((y << 3) | x); }
+    { int m = 0; for (int x = 0; x < 2; x++) for (int y = 0; y < 2; y++) T.cgpos_hv[1][m++] = (u8)((y << 3) | x); }
+    for (int t = 0; t < 2; t++) for (int g = 0; g < 4; g++) T.cgrank_hv[t][T.cgpos_hv[t][g]] = (u8)g;
     // CABAC
-    for (int st = 0; st < 64; st++) {
-        T.lps4[st] = (u32)kRangeLps[st * 4] | (u32)kRangeLps[st * 4 + 1] << 8 | (u32)kRangeLps[st * 4 + 2] << 16 | (u32)kRangeLps[st * 4 + 3] << 24;
-        for (int mps = 0; mps < 2; mps++) T.nextlps[st * 2 + mps] = (u8)(st == 0 ? (1 - mps) : ((kTransLps[st] << 1) | mps));
+    for (int p = 0; p < 128; p++) {
+        const int st = p >> 1, mps = p & 1;
+        const u32 next_lps = (st == 0) ? (u32)(1 - mps) : (u32)((kTransLps[st] << 1) | mps);
+        T.pst[p].x = (u32)kRangeLps[st * 4] | (u32)kRangeLps[st * 4 + 1] << 8 | (u32)kRangeLps[st * 4 + 2] << 16 | (u32)kRangeLps[st * 4 + 3] << 24;
+        T.pst[p].y = next_lps | (u32)((p < 124) ? p + 2 : p) << 8;
     }
-    for (int p = 0; p < 128; p++) { T.pst[p].x = T.lps4[p >> 1]; T.pst[p].y = (u32)T.nextlps[p] | (u32)((p < 124) ? p + 2 : p) << 8; }
     // sig_coeff_flag context increments per in-group scan position (reference :1115-1120)
     for (int pat = 0; pat < 4; pat++) for (int t = 0; t < 3; t++) {
         u32 w = 0;
@@ -92,7 +94,7 @@ inline void build_tables(Tables &T) {
             const int v = kCtxInit[i];
             int st = ((((v >> 4) * 5 - 45) * qp) >> 4) + ((v & 15) << 3) - 16;
             st = st < 1 ? 1 : st > 126 ? 126 : st;
-            T.ctx_init[q][i] = (st >= 64) ? (u8)(((st - 64) << 1) | 1) : (u8)((63 - st) << 1);
+            K.ctx_init[q][i] = (st >= 64) ? (u8)(((st - 64) << 1) | 1) : (u8)((63 - st) << 1);
         }
     }
     for (int m = 0; m < 35; m++) { T.ang[m] = (u8)(kAng[m] + 32); T.iang[m] = kInvAng[m]; }

@@ -25,7 +25,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 # every symbol include/imcvt_hevc.h declares
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
-           "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_version")
+           "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -71,6 +71,8 @@ def load_library():
     lib.imcvt_hevc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.imcvt_hevc_debug_prof.restype = C.c_int
     lib.imcvt_hevc_debug_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_int]
+    lib.imcvt_hevc_debug_occupancy.restype = C.c_int
+    lib.imcvt_hevc_debug_occupancy.argtypes = [_ip, _ip, _ip, _ip]
     lib.imcvt_hevc_version.restype = C.c_char_p
     lib.imcvt_hevc_version.argtypes = []
     _lib = lib
@@ -182,7 +184,7 @@ class DeviceEncoder:
         _check(self.lib.imcvt_hevc_encode_device(self.ctx, batch["n"], batch["frames"], C.c_void_p(s.cuda_stream)),
                "imcvt_hevc_encode_device")
 
-    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "decide", "recon", "ctuio", "t_setup", "t_hdr", "t_gen", "t_drain", "n_drain", "n_tok")
+    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "decide", "recon", "ctuio", "t_setup", "t_hdr", "passA", "passB", "passC", "n_cg")
 
     def debug_prof(self, reset=True):
         """Per-wave cycle totals by phase (only non-zero for -DIMCVT_PROF builds)."""

@@ -68,7 +68,7 @@ typedef struct imcvt_hevc_frame {
 typedef struct imcvt_hevc_ctx imcvt_hevc_ctx;
 
 /* Creates an encoder context on the current HIP device: uploads the constant tables and allocates the
- * per-workgroup scratch for up to max_workgroups concurrent frames (0 = 3 per compute unit).
+ * per-workgroup scratch for up to max_workgroups concurrent frames (0 = 4 per compute unit).
  * Returns NULL when no device is present. */
 imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups);
 void            imcvt_hevc_destroy(imcvt_hevc_ctx *ctx);
@@ -94,6 +94,9 @@ void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
 /* Debug aid: per-wave cycle totals by phase ([waves][categories], zeros unless the library was built with
  * -DIMCVT_PROF); copies up to n counters to `out`, optionally resets them; returns the number available. */
 int imcvt_hevc_debug_prof(imcvt_hevc_ctx *ctx, unsigned long long *out, int n, int reset);
+
+/* Debug aid: what the HIP occupancy API reports for the encoder kernel on the current device. */
+int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds_per_block, int *lds_per_cu);
 
 /* Library / build information, e.g. "imcvt_hevc gfx950 r1". */
 const char *imcvt_hevc_version(void);

@@ -10,8 +10,8 @@
 
 extern "C" int hostemu_HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
                                         int *ysz, int *xsz, int qpd6, int *trace, int trace_cap) {
-    static Tables T; static int ready = 0;
-    if (!ready) { imcvt::build_tables(T); ready = 1; }
+    static Tables T; static ColdTables K; static int ready = 0;
+    if (!ready) { imcvt::build_tables(T, K); ready = 1; }
     const int h = *ysz, w = *xsz;
     const int hp = ((h < 8192 ? h : 8192) + 31) / 32 * 32, wp = ((w < 8192 ? w : 8192) + 31) / 32 * 32;
     Shm *S = (Shm *)calloc(1, sizeof(Shm));
@@ -27,7 +27,7 @@ extern "C" int hostemu_HEVCImageEncoder(unsigned char *pbuffer, const unsigned c
     job.hdr_len = imcvt::build_headers(hdr, qpd6, hp, wp);
     job.out_len = &out_len;
     g_shm_host = S; sc.prof = nullptr;
-    encode_frame(&T, job, sc, hdr);
+    encode_frame(&T, &K, job, sc, hdr);
     free(sc.lv); free(sc.bytes); free(sc.above_sz); free(S);
     *ysz = hp; *xsz = wp;
     return out_len;
