@@ -511,9 +511,11 @@ HDN void border_tu_split(int wave, int N, int y0, int x0, int k, int hl, int hbl
             if (i == 0) {
                 b.c = (u8)(filt ? (2 + tu_left(s, 0) + tu_above(s, 0) + 2 * s.uc) >> 2 : s.uc);
                 b.l[n2] = 0; b.a[n2] = 0;
-                int dc = h;                                         // DC always predicts from the unfiltered border
-                for (int j = 0; j < h; j++) dc += tu_left(s, j) + tu_above(s, j);
-                b.dc = (i16)(dc / (2 * h));
+                if (c == 1) {                                       // only the DC mode reads dc (unfiltered border)
+                    int dc = h;
+                    for (int j = 0; j < h; j++) dc += tu_left(s, j) + tu_above(s, j);
+                    b.dc = (i16)(dc / (2 * h));
+                }
             }
         }
     }
