@@ -12,6 +12,7 @@
 // Conventions: code outside LANES(){} is wave-uniform; every value that crosses a LANES block lives in LDS.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 typedef uint8_t u8;  typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
 typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
@@ -25,14 +26,20 @@ typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
   struct uint2 { uint32_t x, y; }; struct int4 { int32_t x, y, z, w; };
   #define HD static inline
   #define HDN static
-  #define LANES(l) for (int l = 0; l < 64; ++l)
-  #define WAVES(w) for (int w = 0; w < NWAVES; ++w)
-  HD void wave_sync() {}
-  HD void wg_sync() {}
+  // every lane is a cooperative fiber (tests/hostemu/hostemu.cpp): real SIMT semantics, real barriers
+  static int emu_lane(); static int emu_wave(); static void emu_wave_sync(); static void emu_wg_sync();
+  static uint64_t emu_ballot(int p); static int emu_shfl(int v, int src_lane);
+  #define LANES(l) for (int l = emu_lane(), l##_once = 1; l##_once; l##_once = 0)
+  #define WAVES(w) for (int w = emu_wave(), w##_once = 1; w##_once; w##_once = 0)
+  HD void wave_sync() { emu_wave_sync(); }
+  HD void wave_sync_lds() { emu_wave_sync(); }
+  HD void wg_sync() { emu_wg_sync(); }
   HD i32 lds_add(i32 *p, i32 v) { i32 o = *p; *p += v; return o; }
   HD i32 lds_max(i32 *p, i32 v) { i32 o = *p; if (v > o) *p = v; return o; }
   HD u32 lds_or(u32 *p, u32 v) { u32 o = *p; *p |= v; return o; }
   HD int clz32(u32 v) { return v ? __builtin_clz(v) : 32; }
+  HD u64 wave_ballot(int p) { return emu_ballot(p); }
+  HD int wave_shfl(int v, int src_lane) { return emu_shfl(v, src_lane); }
 #else
   #define HD __device__ __forceinline__
   #define HDN __device__ __noinline__
@@ -41,7 +48,11 @@ typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
   // LDS traffic of one wavefront is in program order; the fence only stops the compiler (and drains
   // global stores, which the trial coders read back from other lanes of the same wave).
   HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+  // same, but only LDS traffic is ordered (global stores stay in flight)
+  HD void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); }
   HD void wg_sync() { __syncthreads(); }
+  HD u64 wave_ballot(int p) { return __builtin_amdgcn_ballot_w64(p != 0); }
+  HD int wave_shfl(int v, int src_lane) { return __shfl(v, src_lane, 64); }
   HD i32 lds_add(i32 *p, i32 v) { return atomicAdd(p, v); }
   HD i32 lds_max(i32 *p, i32 v) { return atomicMax(p, v); }
   HD u32 lds_or(u32 *p, u32 v) { return atomicOr(p, v); }
@@ -65,15 +76,20 @@ HD void g_st16(i16 *p, int v) { *p = (i16)v; }
 HD u8 g_ld8(const u8 *p) { return *p; }
 HD i16 g_ld16(const i16 *p) { return *p; }
 HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
+HD void g_st128(void *p, const U4 &v) { *(U4 *)p = v; }
 HD u8 *uniform_ptr(u8 *p) { return p; }
 HD int hibit(u32 v) { return 31 - __builtin_clz(v); }
+HD int popc32(u32 v) { return __builtin_popcount(v); }
+HD int ctz64(u64 v) { return __builtin_ctzll(v); }
 #else
 #define GAS __attribute__((address_space(1)))
 HD void g_st8(u8 *p, int v) { *(GAS u8 *)p = (u8)v; }
 HD void g_st16(i16 *p, int v) { *(GAS i16 *)p = (i16)v; }
 HD u8 g_ld8(const u8 *p) { return *(const GAS u8 *)p; }
 HD i16 g_ld16(const i16 *p) { return *(const GAS i16 *)p; }
-HD U4 g_ld128(const void *p) { const GAS U4 *g = (const GAS U4 *)p; U4 r; r.x = g->x; r.y = g->y; r.z = g->z; r.w = g->w; return r; }
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+HD U4 g_ld128(const void *p) { const u32x4 v = *(const GAS u32x4 *)p; U4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+HD void g_st128(void *p, const U4 &v) { u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(GAS u32x4 *)p = t; }
 #endif
 #ifndef IMCVT_HOSTEMU
 // a pointer every lane agrees on, moved to SGPRs so that stores can use the scalar-base + 32-bit-offset form
@@ -83,6 +99,8 @@ HD u8 *uniform_ptr(u8 *p) {
     return (u8 *)(((u64)hi << 32) | lo);
 }
 HD int hibit(u32 v) { return 31 - __clz((int)v); }
+HD int popc32(u32 v) { return __popc(v); }
+HD int ctz64(u64 v) { return __builtin_ctzll(v); }
 #endif
 // 24-bit multiplies are full rate on the VALU; v_mul_lo_u32 is not.  Only used where both operands provably fit.
 #ifdef IMCVT_HOSTEMU
@@ -136,8 +154,6 @@ HD int arith_len(const Arith &a) { return 8 * (a.cnt + a.nbytes) + 23 - a.nbits;
 // Workgroup memory
 // ---------------------------------------------------------------------------------------------------
 #define RS 68            // reconstruction tile stride: 1 border column + 64, padded
-#define FIFO_CAP 36
-#define FIFO_STRIDE 38   // u16 units per lane (odd dword stride: conflict-free when lanes read the same slot)
 
 struct Border {          // prediction references of one block (:196-257): unfiltered / [1 2 1]-filtered
     u8 uc, fc; i16 dc;
@@ -159,22 +175,26 @@ HD Arith unpack_arith(const FinState &f) {
     a.bufbyte = (i32)(f.w1 >> 18); a.nbytes = (i32)(f.w2 & 0xFFFF); a.cnt = (i32)(f.w2 >> 16); return a;
 }
 
+#ifndef RING_BYTES
+#define RING_BYTES 64      // per-lane byte ring of the trial coders (RingSink)
+#endif
+#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + NMODE * RING_BYTES)      // p2's extent
 struct alignas(16) WaveMem {
     Border  bsh;                 // border shared by all modes of a block
-    i32 last[4][NMODE];          // per TU: last significant scan position (-1: none)
-    u32 cgm[NMODE][4];           // significant-group bitmap: one TU -> words [c][0..1] (bit gy*8+gx); four TUs (<=16 groups) -> word [c][k]
+    i32 tokn[NMODE + 1];         // tokens written so far to each candidate's stream (slot NMODE: the NxN stream)
+    i32 tnz[NMODE];              // the TU tokenised last has a non-zero level
     i32 sse[NMODE];
     i32 cost[NMODE];
     FinState fin[NMODE];         // coder state each trial ended in
-    i32 pu_mode[4], pu_sse[4], pu_last[4];   // NxN bookkeeping (PU wave)
+    i32 pu_mode[4], pu_sse[4], pu_cnt[4];   // NxN bookkeeping (PU wave)
     i32 nxn_cost;
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
         struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                   // one pipeline pass
-        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) i16 lvl[NMODE][16]; } p2;                      // trial coders
-        struct { u8 pad_[4352]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
+        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) u8 ring[NMODE][RING_BYTES]; } p2;                // trial coders: context copies, byte rings
+        struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
     } u;
 };
-#define WAVE2_BYTES (sizeof(WaveMem) - 7168 + 4352 + NMODE * 16)
+#define WAVE2_BYTES (sizeof(WaveMem) - 7168 + W2_PAD + NMODE * 16)
 
 // Per-frame job and per-workgroup scratch (global memory)
 struct FrameJob {
@@ -185,16 +205,27 @@ struct FrameJob {
     i32 hdr_len;     // header bytes already placed at out[0..hdr_len)
     i32 *out_len;    // result
 };
+#define TRIAL_BYTES 3584
+#define TOK_CAP 7040             // u16 per candidate stream: 18 (CU header) + 4 x 25 (cbf + last position per TU) + 64 groups x 108, rounded to 16 bytes
+#define TOK_SLOTS (NMODE + 1)
 struct Scratch {
-    i16 *lv;         // [NWAVES][NMODE*1024] quantised levels in scan order
+    u16 *tok;        // [NWAVES][TOK_SLOTS][TOK_CAP] bin tokens of the candidates being priced
     u8  *bytes;      // [NWAVES][NMODE][TRIAL_BYTES] bytes emitted by trial coders
     u8  *above_sz;   // [wp/4] CU sizes of the CTU row above (:1633-1636)
     i32 *trace;      // optional decision trace (8 ints per CU), or null
     unsigned long long *prof;   // optional [NWAVES][PF_N] cycle totals (IMCVT_PROF builds), or null
     i32 trace_cap;
 };
-#define TRIAL_BYTES 3584
-#define LV_PER_WAVE (NMODE * 1024)
+// host side: size and carving of one workgroup's scratch slab
+static inline size_t scratch_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline size_t scratch_tok_bytes() { return scratch_align((size_t)NWAVES * TOK_SLOTS * TOK_CAP * sizeof(u16) + 64); }
+static inline size_t scratch_bytes_per_wg() { return scratch_tok_bytes() + scratch_align((size_t)NWAVES * NMODE * TRIAL_BYTES) + scratch_align(8192 / 4 + 64); }
+static inline void scratch_carve(Scratch &sc, u8 *base) {
+    sc.tok = (u16 *)base; base += scratch_tok_bytes();
+    sc.bytes = base;      base += scratch_align((size_t)NWAVES * NMODE * TRIAL_BYTES);
+    sc.above_sz = base;
+    sc.trace = nullptr; sc.trace_cap = 0; sc.prof = nullptr;
+}
 
 struct FrameCtx {
     FrameJob job;
@@ -215,10 +246,10 @@ struct alignas(16) Shm {
     FrameCtx F;                  // per-frame context (kept in LDS so that callees read it with ds_* ops)
     alignas(16) u8 org[32][32];
     alignas(16) u8 rec[33][RS];             // rec[y+1][x+1]; row 0 / column 0 are the neighbours
-    u8  cx[CTX_STRIDE];          // live contexts
+    alignas(4) u8 cx[CTX_STRIDE];   // live contexts
     Arith live;
     Arith entry_a[3];            // coder + contexts on entry to the CU of depth 0/1/2
-    u8  entry_cx[3][CTX_STRIDE];
+    alignas(4) u8 entry_cx[3][CTX_STRIDE];
     u8  mapsz[10][12], mapmode[10][12];   // 4x4-unit neighbour maps of this CTU with a 1-cell apron (:1591-1599)
     i32 split_cost[3];
     i32 win_kind, win_mode;      // decision broadcast
@@ -227,7 +258,7 @@ struct alignas(16) Shm {
     unsigned long long prof[NWAVES][PF_N];
 #endif
     FourTU X;
-    u8  cx0[CTX_STRIDE];         // fresh context states of this frame's qpd6 (:1505)
+    alignas(4) u8 cx0[CTX_STRIDE];       // fresh context states of this frame's qpd6 (:1505)
     alignas(16) u8 wraw[2 * sizeof(WaveMem) + WAVE2_BYTES];   // wave slices; the last (4x4-only) one is truncated
 };
 
@@ -259,16 +290,48 @@ HD void prof_cnt(int, int) {}
 // workgroup barrier whose wait time is booked under PF_SYNC
 HD void wg_sync_p() { const long long t = prof_now(); wg_sync(); prof_add(PF_SYNC, t); }
 
-// sink[a.cnt] is where the next byte goes
+// Byte sinks.  sink[a.cnt] is where the next byte goes.
+//   Sink     — straight to global memory (the live coder: split flags, terminate bins, finish; the safe trial path).
+//   RingSink — the trial coders: bytes collect in a 64-byte LDS ring per lane and leave as aligned 16-byte global stores
+//              between token blocks, so the hot inner loop issues no VMEM instruction at all (a token load then only
+//              has to be waited for where it is used, one block later).  A burst the ring cannot take (a run of >= 30
+//              pending 0xFF bytes resolving at once) raises `ovf`; the caller then repeats the trial on the safe path.
 struct Sink { u8 *base; u32 off; };          // byte i of the lane's run lives at base[off + i]; base is wave-uniform
-HD void sink_put(const Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), v); }
-HD void emit_byte(Arith &a, const Sink &sink, int v) {                                             // :820-831
+HD void sink_put(Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), v); }
+HD int sink_room(Sink &, int) { return 1; }
+struct RingSink { u8 *ring; u8 *gbuf; int c0, fl, ovf; };   // byte i lives at local index j = i - c0: ring[j % RING_BYTES] until flushed, then gbuf[j]; fl = bytes flushed (multiple of 16)
+HD void ring_flush16(RingSink &s) { const U4 b = *(const U4 *)(s.ring + (s.fl & (RING_BYTES - 1))); g_st128(s.gbuf + s.fl, b); s.fl += 16; }
+HD void sink_put(RingSink &s, int i, int v) { s.ring[(i - s.c0) & (RING_BYTES - 1)] = (u8)v; }
+#ifdef IMCVT_FORCE_OVF      // test builds: every rare-path byte overflows, so the safe path is exercised
+HD int sink_room(RingSink &s, int) { s.ovf = 1; return 0; }
+#else
+HD int sink_room(RingSink &s, int i) { if (i - s.c0 - s.fl >= RING_BYTES - 8) { s.ovf = 1; return 0; } return 1; }
+#endif   // rare paths leave 8 slots for the block's common-path bytes
+HD void ring_sync(RingSink &s, int cnt) { NOUNROLL while (cnt - s.c0 - s.fl >= 16) ring_flush16(s); }   // between token blocks: < 16 bytes stay pending
+HD void ring_finish(RingSink &s, int cnt) { NOUNROLL while (cnt - s.c0 > s.fl) ring_flush16(s); }        // tail: the bytes beyond cnt are never read
+template <class S>
+HD void emit_byte(Arith &a, S &sink, int v) {                                                     // :820-831
     v &= 0xFF;
-    if (a.zeros >= 2 && v <= 3) { sink_put(sink, a.cnt++, 3); a.zeros = 0; }
-    sink_put(sink, a.cnt++, v);
+    if (a.zeros >= 2 && v <= 3) { if (sink_room(sink, a.cnt)) sink_put(sink, a.cnt, 3); a.cnt++; a.zeros = 0; }
+    if (sink_room(sink, a.cnt)) sink_put(sink, a.cnt, v);
+    a.cnt++;
     a.zeros = v ? 0 : a.zeros + 1;
 }
-HD void carry_out(Arith &a, const Sink &sink) {                                                    // :858-878
+// the rare branches of :858-878: a run of 0xFF bytes grows or resolves, emulation prevention, the very first byte
+template <class S>
+HD void carry_rare(Arith &a, S &sink, int lead) {
+    if (lead == 0xFF) a.nbytes++;
+    else if (a.nbytes > 0) {
+        int carry = lead >> 8, v = a.bufbyte + carry;
+        a.bufbyte = lead & 0xFF;
+        emit_byte(a, sink, v);
+        v = (0xFF + carry) & 0xFF;
+        NOUNROLL
+        for (; a.nbytes > 1; a.nbytes--) emit_byte(a, sink, v);
+    } else { a.nbytes = 1; a.bufbyte = lead; }
+}
+template <class S>
+HD void carry_out(Arith &a, S &sink) {                                                            // :858-878
     if (a.nbits < 12) {
         const int lead = (int)((u32)a.low >> (24 - a.nbits));
         a.nbits += 8;
@@ -279,17 +342,10 @@ HD void carry_out(Arith &a, const Sink &sink) {                                 
             sink_put(sink, a.cnt++, v1);
             a.zeros = v1 ? 0 : a.zeros + 1;
             a.bufbyte = lead & 0xFF;
-        } else if (lead == 0xFF) a.nbytes++;
-        else if (a.nbytes > 0) {
-            int carry = lead >> 8, v = a.bufbyte + carry;
-            a.bufbyte = lead & 0xFF;
-            emit_byte(a, sink, v);
-            v = (0xFF + carry) & 0xFF;
-            for (; a.nbytes > 1; a.nbytes--) emit_byte(a, sink, v);
-        } else { a.nbytes = 1; a.bufbyte = lead; }
+        } else carry_rare(a, sink, lead);
     }
 }
-HD void code_bin(Arith &a, u8 *cx, const Sink &sink, int ci, int bin) {                     // :913-932
+HD void code_bin(Arith &a, u8 *cx, Sink &sink, int ci, int bin) {                     // :913-932
     const int p = cx[ci];
     const uint2 e = SM.T.pst[p];
     const int lps = (int)((e.x >> (((a.range >> 6) & 3) * 8)) & 0xFF);
@@ -302,18 +358,13 @@ HD void code_bin(Arith &a, u8 *cx, const Sink &sink, int ci, int bin) {         
     a.nbits -= sh;
     carry_out(a, sink);
 }
-HD void code_bypass_chunk(Arith &a, const Sink &sink, int v, int n) {                             // one <=8-bin step of :898-910
-    a.low = (a.low << n) + mul24(a.range, v);      // range <= 510, v <= 255
-    a.nbits -= n;
-    carry_out(a, sink);
-}
-HD void code_terminate(Arith &a, const Sink &sink, int bin) {                                      // :881-895
+HD void code_terminate(Arith &a, Sink &sink, int bin) {                                      // :881-895
     a.range -= 2;
     if (bin) { a.low = (a.low + a.range) << 7; a.range = 256; a.nbits -= 7; }
     else if (a.range < 256) { a.low <<= 1; a.range <<= 1; a.nbits--; }
     carry_out(a, sink);
 }
-HD void arith_finish(Arith &a, const Sink &sink) {                                                 // :839-855
+HD void arith_finish(Arith &a, Sink &sink) {                                                 // :839-855
     int fill = 0, t;
     if ((a.low >> (32 - a.nbits)) > 0) { emit_byte(a, sink, a.bufbyte + 1); a.low -= 1 << (32 - a.nbits); }
     else { if (a.nbytes > 0) emit_byte(a, sink, a.bufbyte); fill = 0xFF; }
@@ -531,12 +582,12 @@ enum { OUT_NONE = 0, OUT_REC4 = 1, OUT_T3SIDE = 2, OUT_TILE = 3 };
 
 struct P1Args {
     int N, y0, x0;       // block inside the CTU
-    int k;               // TU slot for last/cgm/levels
+    int k;               // TU slot (four-TU shape)
     int per_mode_border; // 0: W.bsh, 1: SM.X.bc[c]
     int out_kind;        // what to keep of the reconstruction
     int only_mode;       // -1: all 35 modes, else just this one (winner reconstruction)
-    int cg_words2;       // 1: the TU has up to 64 groups (bitmap in cgm[c][0..1]); 0: <=16 groups (cgm[c][k])
-    i16 *lv;             // global levels base for this TU: [c][N*N], scan order (may be null for only_mode)
+    int shape;           // CU shape the TU belongs to (0: one TU, 1: four TUs, 2: NxN, 3: PU pricing) — picks the cbf_luma context
+    u16 *tok;            // the wave's token streams ([TOK_SLOTS][TOK_CAP]); null: no tokens (winner reconstruction)
     int q;
 };
 
@@ -630,26 +681,6 @@ HD int rdoq_group(int acc[4][4], const QConst &Q) {
     return (sum < Q.thr) ? 0 : any;                     // weak group: cleared (:588-591)
 }
 
-// Store the levels of a coded group in scan order, book `last` / group bitmap, and dequantise acc in place.
-HD void emit_group(WaveMem &W, const P1Args &P, int acc[4][4], int c, int st, int s, int by, int bx, int NN, int dq) {
-    const Tables &T = SM.T;
-    const int g = cg_rank(st, s, by * 8 + bx);
-    i16 *lvg = P.lv ? P.lv + (size_t)c * NN + g * 16 : (i16 *)0;     // only coded groups are ever read back
-    int hi = 0;
-    for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
-        const int v = acc[r][cc];
-        const int n = T.incg_rank[st][r * 4 + cc];
-        if (v) hi = imax(hi, n);
-        if (lvg) g_st16(lvg + n, v);
-        acc[r][cc] = clip16(v * dq);
-    }
-    if (P.only_mode < 0) {
-        lds_max(&W.last[P.k][c], g * 16 + hi);
-        const int bit = by * 8 + bx;
-        if (P.cg_words2) lds_or(&W.cgm[c][bit >> 5], 1u << (bit & 31)); else lds_or(&W.cgm[c][P.k], 1u << bit);
-    }
-}
-
 HD int scan_type_of(int N, int mode) { return (N <= 8) ? ((iabs(mode - 26) <= 4) ? 1 : (iabs(mode - 10) <= 4) ? 2 : 0) : 0; }   // :1133-1141
 
 HD void fill_border_ref(BorderRef &br, const WaveMem &W, int per_mode, int c) {
@@ -657,8 +688,200 @@ HD void fill_border_ref(BorderRef &br, const WaveMem &W, int per_mode, int c) {
     else { const Border &b = W.bsh; br.ul = b.ul; br.ua = b.ua; br.fl = b.fl; br.fa = b.fa; br.uc = b.uc; br.fc = b.fc; br.dc = b.dc; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Bin tokens.  The syntax of a candidate (:1172-1339) is flattened, by the lanes that own its coefficient
+// groups, into a stream of 16-bit tokens in coding order:
+//     context-coded bin :  (context index << 1) | bin                       (< 182)
+//     bypass chunk      :  0x8000 | nbins << 8 | value   (1..8 bins, the reference's own chunking :898-910)
+// Tokens do not depend on the coder or context STATE, so they are produced in parallel (one lane per 4x4
+// group) while the arithmetic coding itself — the only truly serial part — becomes a tight loop over a
+// linear stream (stream_run below), one lane per candidate.
+// ---------------------------------------------------------------------------------------------------
+struct TokW { u16 *p; int n; int wr; };       // wr == 0: count only
+HD void tk_put(TokW &w, int t) { if (w.wr) g_st16((i16 *)(w.p + w.n), t); w.n++; }
+HD void tk_bin(TokW &w, int ci, int bin) { tk_put(w, (ci << 1) | bin); }
+HD void tk_chunk(TokW &w, int v, int n) { tk_put(w, 0x8000 | (n << 8) | v); }
+HD void tk_bypass(TokW &w, int v, int len) {                                                // :898-910
+    v &= (1 << len) - 1;
+    while (len > 0) { const int n = imin(len, 8); len -= n; tk_chunk(w, (v >> len) & ((1 << n) - 1), n); }
+}
+
+HD void mpm_list(int l, int a, int *m) {                       // :957-976
+    if (l != a) { m[0] = l; m[1] = a; m[2] = (l != 0 && a != 0) ? 0 : (l + a < 2) ? 26 : 1; }
+    else if (l > 1) { m[0] = l; m[1] = ((l + 29) & 31) + 2; m[2] = ((l - 1) & 31) + 2; }
+    else { m[0] = 0; m[1] = 1; m[2] = 26; }
+}
+// prev_intra_luma_pred_flag of one PU; returns the hit index (or -1) and the candidate list in m[]
+HD int tk_luma_flag(TokW &w, int ml, int ma, int mode, int *m) {
+    mpm_list(ml, ma, m);
+    const int hit = (m[2] == mode) ? 2 : (m[1] == mode) ? 1 : (m[0] == mode) ? 0 : -1;   // later entries win, as :992-994
+    tk_bin(w, CX_PREV_INTRA, hit >= 0);
+    return hit;
+}
+HD void tk_luma_rest(TokW &w, int *m, int hit, int mode) {     // mpm_idx / rem_intra_luma_pred_mode (:998-1016)
+    if (hit >= 0) { tk_bypass(w, hit > 0, 1); if (hit > 0) tk_bypass(w, hit - 1, 1); }
+    else {
+        int t, r = mode;
+        if (m[0] < m[1]) { t = m[0]; m[0] = m[1]; m[1] = t; }
+        if (m[1] < m[2]) { t = m[1]; m[1] = m[2]; m[2] = t; }
+        if (m[0] < m[1]) { t = m[0]; m[0] = m[1]; m[1] = t; }
+        r -= (r > m[0]); r -= (r > m[1]); r -= (r > m[2]);
+        tk_bypass(w, r, 5);
+    }
+}
+// coding_unit header up to (not including) the first cbf_luma (:1271-1339).  shape 0: 2Nx2N one TU, 1: 2Nx2N four TUs, 2: NxN
+struct CuHdr { int N, shape, ctx_split; int mode[4], ml[4], ma[4]; };
+HD void tk_cu_header(TokW &w, const CuHdr &J) {
+    if (J.ctx_split >= 0) tk_bin(w, J.ctx_split, 0);
+    if (J.N == 8) tk_bin(w, CX_PART, J.shape != 2);
+    if (J.shape == 2) {
+        int m0[3], m1[3], m2[3], m3[3];
+        const int h0 = tk_luma_flag(w, J.ml[0], J.ma[0], J.mode[0], m0), h1 = tk_luma_flag(w, J.ml[1], J.ma[1], J.mode[1], m1);
+        const int h2 = tk_luma_flag(w, J.ml[2], J.ma[2], J.mode[2], m2), h3 = tk_luma_flag(w, J.ml[3], J.ma[3], J.mode[3], m3);
+        tk_luma_rest(w, m0, h0, J.mode[0]); tk_luma_rest(w, m1, h1, J.mode[1]);
+        tk_luma_rest(w, m2, h2, J.mode[2]); tk_luma_rest(w, m3, h3, J.mode[3]);
+    } else {
+        int m0[3];
+        const int h0 = tk_luma_flag(w, J.ml[0], J.ma[0], J.mode[0], m0);
+        tk_luma_rest(w, m0, h0, J.mode[0]);
+    }
+    tk_bin(w, CX_CHROMA_PRED, 0);
+    if (J.shape != 2) tk_bin(w, CX_SPLIT_TU + (J.N == 32 ? 0 : J.N == 16 ? 1 : 2), J.shape == 1);
+    tk_bin(w, CX_CBF_CHROMA, 0); tk_bin(w, CX_CBF_CHROMA, 0);
+}
+
+HD void tk_last_pos(TokW &w, int s, int st, int y, int x) {                                 // :1045-1086
+    const int base = (s == 0) ? 0 : (s == 1) ? 3 : (s == 2) ? 6 : 10, shf = (s == 0) ? 0 : 1;
+    const int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;
+    // group index of a coordinate: 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8*8,9*8
+    const int gx = tx < 4 ? tx : (2 * (31 - clz32((u32)tx)) + ((tx >> (30 - clz32((u32)tx))) & 1));
+    const int gy = ty < 4 ? ty : (2 * (31 - clz32((u32)ty)) + ((ty >> (30 - clz32((u32)ty))) & 1));
+    const int gmax = 2 * (s + 2) - 1;                                         // group of N-1
+    for (int i = 0; i < gx; i++) tk_bin(w, CX_LAST_X + base + (i >> shf), 1);
+    if (gx < gmax) tk_bin(w, CX_LAST_X + base + (gx >> shf), 0);
+    for (int i = 0; i < gy; i++) tk_bin(w, CX_LAST_Y + base + (i >> shf), 1);
+    if (gy < gmax) tk_bin(w, CX_LAST_Y + base + (gy >> shf), 0);
+    if (gx > 3) { const int nb_ = (gx - 2) >> 1, mn = (2 + (gx & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) tk_bypass(w, ((tx - mn) >> i) & 1, 1); }
+    if (gy > 3) { const int nb_ = (gy - 2) >> 1, mn = (2 + (gy & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) tk_bypass(w, ((ty - mn) >> i) & 1, 1); }
+}
+
+HD void tk_remaining(TokW &w, int v, int k) {                                              // :1153-1168
+    if (v < (3 << k)) {                                  // prefix of <=3 bins, suffix of k<=4 bins: one chunk each
+        const int p = v >> k;
+        tk_chunk(w, (1 << (p + 1)) - 2, p + 1);
+        if (k) tk_chunk(w, v & ((1 << k) - 1), k);
+    } else {
+        int n = k; v -= 3 << k;
+        for (; v >= (1 << n); n++) v -= 1 << n;
+        const int t = 4 + n - k;
+        tk_bypass(w, (1 << t) - 2, t); tk_bypass(w, v, n);
+    }
+}
+
+// Tokens of one coefficient group (the body of the group loop of :1172-1268), as straight-line code over the group's
+// 16 levels held in registers in scan order: every potential token is a predicated store, the greater-1 context
+// and Rice parameter recurrences are select chains.  Only Exp-Golomb escapes (levels beyond 3 << rice) branch.
+//   cfg : bit1 DC group | bit2 group holds the last significant coefficient | bit3 greater-1 context set carry (previous
+//         coded group ended with c1 == 0) | bits4-5 neighbour pattern (below << 1 | right) | bits6-7 scan type
+//         | bits8-9 log2(TU size) - 2
+// WR = false only counts.  Returns the token count | (this group ends with c1 == 0) << 16.
+enum { TG_DC = 2, TG_LAST = 4, TG_C1Z = 8, TG_PAT = 4, TG_ST = 6, TG_S = 8 };
+struct Lv16 { int v[16]; };
+#ifdef IMCVT_HOSTEMU
+#define UNROLL_FULL
+#else
+#define UNROLL_FULL _Pragma("unroll")
+#endif
+HD int tk_chunk_word(int v, int n) { return 0x8000 | (n << 8) | v; }
+// coeff_abs_level_remaining beyond the prefix-3 range: EG(k+1) escape (:1160-1167), out of line
+HDN int tok_escape(u16 *p, int wr, int v, int k) {
+    TokW w; w.p = p; w.n = 0; w.wr = wr;
+    int n = k; v -= 3 << k;
+    for (; v >= (1 << n); n++) v -= 1 << n;
+    const int t = 4 + n - k;
+    tk_bypass(w, (1 << t) - 2, t); tk_bypass(w, v, n);
+    return w.n;
+}
+template <bool WR>
+HD int tokg(u16 *p, const Lv16 &L, u32 nzm, int cfg) {
+    const Tables &T = SM.T;
+    const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3, s = (cfg >> TG_S) & 3;
+    int cnt = 0;
+#define TK_EMIT(pred, tok) do { const int p_ = (pred); if (WR) { if (p_) g_st16((i16 *)(p + cnt), (tok)); } cnt += p_; } while (0)
+    TK_EMIT(!dcg && !has_last, ((CX_CSBF + (pat != 0)) << 1) | (nzm != 0));
+    if (nzm == 0 && !dcg) return cnt;
+    {   // significance flags, scan positions nstart..0.  Context of position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
+        const int nstart = has_last ? hibit(nzm) : 15;
+        u32 tlo, thi = 0; int base;
+        if (s == 0) { const u64 t = T.c4tab[st]; tlo = (u32)t; thi = (u32)(t >> 32); base = 0; }
+        else { tlo = T.posadd[pat][st]; base = 9 + (s >= 2 ? 12 : 0) + ((s == 1 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); }
+        UNROLL_FULL
+        for (int n = 15; n >= 0; n--) {
+            const int code = (n <= nstart) & !(has_last & (n == nstart)) & (dcg | (n != 0) | ((nzm >> (n + 1)) != 0));
+            const int f4 = (int)(((n < 8 ? tlo : thi) >> (4 * (n & 7))) & 15), f2 = (int)((tlo >> (2 * n)) & 3);
+            const int ci = (dcg && n == 0) ? 0 : base + (s == 0 ? f4 : f2);
+            TK_EMIT(code, ((CX_SIG + ci) << 1) | (int)((nzm >> n) & 1));
+        }
+    }
+    if (nzm == 0) return cnt;
+    const int nnz = popc32(nzm);
+    const int set = (dcg ? 0 : 2) + ((cfg & TG_C1Z) != 0);
+    int c1 = 1, g2 = -1, esc = nnz > 8, seen = 0, signs = 0;
+    UNROLL_FULL
+    for (int n = 15; n >= 0; n--) {                    // greater-1 flags of the first 8 non-zero levels, scan-reverse order
+        const int v = L.v[n], mg = iabs(v), isnz = v != 0;
+        signs = isnz ? ((signs << 1) | (v < 0)) : signs;
+        const int act = isnz & (seen < 8), big = mg > 1;
+        TK_EMIT(act, ((CX_GT1 + 4 * set + c1) << 1) | big);
+        const int ab = act & big, an = act & !big;
+        esc |= ab & (g2 >= 0);
+        g2 = (ab & (g2 < 0)) ? (mg > 2) : g2;
+        c1 = ab ? 0 : ((an & (c1 > 0) & (c1 < 3)) ? c1 + 1 : c1);
+        seen += isnz;
+    }
+    TK_EMIT(g2 >= 0, ((CX_GT2 + set) << 1) | (g2 > 0));
+    esc |= (g2 > 0);
+    {   // sign bins: one or two bypass chunks
+        const int two = nnz > 8, lo = two ? nnz - 8 : 0;
+        TK_EMIT(1, two ? tk_chunk_word((signs >> lo) & 0xFF, 8) : tk_chunk_word(signs, nnz));
+        TK_EMIT(two, tk_chunk_word(signs & ((1 << lo) - 1), lo));
+    }
+    if (esc) {                                         // remaining absolute levels
+        int base2 = 3, rice = 0, j = 0;
+        UNROLL_FULL
+        for (int n = 15; n >= 0; n--) {
+            const int mg = iabs(L.v[n]), isnz = mg != 0;
+            const int r = mg - (j < 8 ? base2 : 1);
+            const int doit = isnz & (r >= 0), small = r < (3 << rice);
+            const int pp = r >> rice;                  // prefix of <=3 bins, suffix of rice<=4 bins: one chunk each
+            TK_EMIT(doit & small, tk_chunk_word((2 << pp) - 2, pp + 1));
+            TK_EMIT(doit & small & (rice != 0), tk_chunk_word(r & ((1 << rice) - 1), rice));
+            if (doit & !small) cnt += tok_escape(p + cnt, WR, r, rice);
+            rice = (doit & (mg > (3 << rice))) ? imin(rice + 1, 4) : rice;
+            base2 = (isnz & (mg >= 2)) ? 2 : base2;
+            j += isnz;
+        }
+    }
+#undef TK_EMIT
+    return cnt | ((g2 >= 0) ? 1 << 16 : 0);
+}
+HDN int tok_count(Lv16 L, u32 nzm, int cfg) { return tokg<false>((u16 *)0, L, nzm, cfg); }
+HDN int tok_write(u16 *p, Lv16 L, u32 nzm, int cfg) { return tokg<true>(p, L, nzm, cfg); }
+
+// the 16 levels of a 4x4 group (raster x[r][c]) in scan order `st`, and their non-zero mask
+HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag) {
+    const int diag[16] = { 0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15 };      // T.incg[0]
+    u32 nzm = 0;
+    for (int n = 0; n < 16; n++) {
+        const int d = x[diag[n] >> 2][diag[n] & 3];
+        const int v = fixed_diag ? d : (st == 0 ? d : st == 1 ? x[n >> 2][n & 3] : x[n & 3][n >> 2]);
+        L.v[n] = v; nzm |= (u32)(v != 0) << n;
+    }
+    return nzm;
+}
+
 // ---- 4x4 blocks: one lane owns the whole block, so the pipeline runs entirely in registers (DST constants are
-// immediates, no LDS intermediates, no wave syncs between the stages).
+// immediates, no LDS intermediates, no wave syncs between the stages) and the lane writes the TU's tokens itself.
 HDN void p1_run_4(int wave, const P1Args P) {
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
@@ -691,9 +914,22 @@ HDN void p1_run_4(int wave, const P1Args P) {
                 x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
             }
             const int any = rdoq_group<0>(x, Q);
+            const int st = scan_type_of(4, mode);
+            if (P.tok) {                                    // the TU's tokens: cbf_luma, last position, the one group
+                Lv16 L; u32 nzm = 0;
+                if (any) nzm = scan_levels(L, x, st, 0);
+                TokW w; w.p = P.tok + (size_t)c * TOK_CAP; w.n = W.tokn[c]; w.wr = 1;
+                tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
+                if (nzm != 0) {
+                    const int in = T.incg[st][hibit(nzm)];
+                    tk_last_pos(w, 0, st, in >> 2, in & 3);
+                    w.n += tok_write(w.p + w.n, L, nzm, TG_DC | TG_LAST | st << TG_ST) & 0xFFFF;
+                } else if (P.shape == 3) tk_last_pos(w, 0, st, 0, 0);   // PU pricing codes the residual syntax of an all-zero block (:1515)
+                W.tokn[c] = w.n; W.tnz[c] = (nzm != 0);
+            }
             int part = 0;
             if (any) {
-                emit_group(W, P, x, c, scan_type_of(4, mode), 0, 0, 0, 16, Q.dq);
+                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * Q.dq);
                 // inverse DST with the 16-bit clips (:511-515): t = clip16((D^T*x + 64) >> 7) ; r = clip16((t*D + 2048) >> 12)
                 for (int j = 0; j < 4; j++) {
                     const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
@@ -729,7 +965,16 @@ HDN void p1_run_4(int wave, const P1Args P) {
             if (P.only_mode < 0) W.sse[c] += part;         // this lane is the only writer of sse[c] in this pass
         }
     }
-    wave_sync();
+    wave_sync_lds();
+}
+
+// exclusive suffix sum of v over the lanes of this lane's segment of `lpc` consecutive lanes (wave collective)
+HD int seg_suffix_sum(int v, int l, int lpc, int *total) {
+    int inc = v;
+    const int r = l % lpc;
+    for (int d = 1; d < lpc; d <<= 1) { const int t = wave_shfl(inc, l + d); if (r + d < lpc) inc += t; }
+    *total = wave_shfl(inc, l - r);
+    return inc - v;
 }
 
 template <int LG>
@@ -744,111 +989,157 @@ HDN void p1_run_t(int wave, const P1Args P) {
 
     NOUNROLL
     for (int c0 = 0; c0 < ncand; c0 += G) {
+      LANES(l) {
+        // lane <-> coefficient group: slot sl of this pass, group of scan rank r of that candidate's TU
+        const int sl = l / lpc, r = l % lpc, c = c0 + sl, live = c < ncand;
+        const int mode = (P.only_mode >= 0) ? P.only_mode : (live ? c : 0);
+        const int st = scan_type_of(N, mode);
+        const int gp = cg_pos(st, s, r), by = gp >> 3, bx = gp & 7;
+        const int tokn0 = (P.tok && live) ? W.tokn[c] : 0;
         // ---- step 1: prediction and residual
-        LANES(l) {
-            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
-            if (c < ncand) {
-                const int mode = (P.only_mode >= 0) ? P.only_mode : c;
-                u8 *pp = W.u.p1.pred + sl * NN; i16 *rp = W.u.p1.res + sl * NN;
-                BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
-                int pr[4][4];
-                pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
-                for (int yi = 0; yi < 4; yi++) {
-                    const int y = by * 4 + yi;
-                    const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
-                    *(u32 *)(pp + y * N + bx * 4) = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
-                    uint2 rw_;
-                    rw_.x = (u32)(((int)(ow & 255) - pr[yi][0]) & 0xFFFF) | (u32)((int)((ow >> 8) & 255) - pr[yi][1]) << 16;
-                    rw_.y = (u32)(((int)((ow >> 16) & 255) - pr[yi][2]) & 0xFFFF) | (u32)((int)(ow >> 24) - pr[yi][3]) << 16;
-                    *(uint2 *)(rp + y * N + bx * 4) = rw_;
-                }
+        if (live) {
+            u8 *pp = W.u.p1.pred + sl * NN; i16 *rp = W.u.p1.res + sl * NN;
+            BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
+            int pr[4][4];
+            pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
+            for (int yi = 0; yi < 4; yi++) {
+                const int y = by * 4 + yi;
+                const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                *(u32 *)(pp + y * N + bx * 4) = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
+                uint2 rw_;
+                rw_.x = (u32)(((int)(ow & 255) - pr[yi][0]) & 0xFFFF) | (u32)((int)((ow >> 8) & 255) - pr[yi][1]) << 16;
+                rw_.y = (u32)(((int)((ow >> 16) & 255) - pr[yi][2]) & 0xFFFF) | (u32)((int)(ow >> 24) - pr[yi][3]) << 16;
+                *(uint2 *)(rp + y * N + bx * 4) = rw_;
             }
         }
-        wave_sync();
+        wave_sync_lds();
         // ---- step 2: tmp = (C * res + ra) >> a                                              (:514 forward)
-        LANES(l) {
-            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
-            if (c < ncand) {
-                int acc[4][4];
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = ra;
-                mac_MX<N>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
-                i32 *tp = W.u.p1.tmp + sl * NN;
-                for (int r = 0; r < 4; r++) {
-                    int4 o; o.x = acc[r][0] >> a1; o.y = acc[r][1] >> a1; o.z = acc[r][2] >> a1; o.w = acc[r][3] >> a1;
-                    *(int4 *)(tp + (by * 4 + r) * N + bx * 4) = o;
-                }
+        if (live) {
+            int acc[4][4];
+            for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = ra;
+            mac_MX<N>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
+            i32 *tp = W.u.p1.tmp + sl * NN;
+            for (int r4 = 0; r4 < 4; r4++) {
+                int4 o; o.x = acc[r4][0] >> a1; o.y = acc[r4][1] >> a1; o.z = acc[r4][2] >> a1; o.w = acc[r4][3] >> a1;
+                *(int4 *)(tp + (by * 4 + r4) * N + bx * 4) = o;
             }
         }
-        wave_sync();
-        // ---- step 3: coef = (tmp * C^T + rb) >> b ; RDOQ ; levels out ; dequantise           (:515, :540-614)
-        LANES(l) {
-            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
-            if (c < ncand) {
-                const int mode = (P.only_mode >= 0) ? P.only_mode : c;
-                int acc[4][4];
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = rb;
+        wave_sync_lds();
+        // ---- step 3: coef = (tmp * C^T + rb) >> b ; RDOQ ; tokens ; dequantise                 (:515, :540-614, :1172-1268)
+        {
+            int acc[4][4];
+            int any = 0;
+            if (live) {
+                for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = rb;
                 mac_YM32<N>(acc, W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
-                const int any = rdoq_group<s>(acc, Q);
+                any = rdoq_group<s>(acc, Q);
+            }
+            Lv16 L; u32 nzm = 0;
+            if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
+            const u64 cm = P.tok ? wave_ballot(any) : 0;
+            if (live) {
                 i16 *dp = W.u.p1.res + sl * NN;
                 if (any) {
-                    emit_group(W, P, acc, c, scan_type_of(N, mode), s, by, bx, NN, Q.dq);
-                    for (int r = 0; r < 4; r++) {
-                        uint2 o; o.x = (u32)(acc[r][0] & 0xFFFF) | (u32)acc[r][1] << 16; o.y = (u32)(acc[r][2] & 0xFFFF) | (u32)acc[r][3] << 16;
-                        *(uint2 *)(dp + (by * 4 + r) * N + bx * 4) = o;
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        for (int cc = 0; cc < 4; cc++) acc[r4][cc] = clip16(acc[r4][cc] * Q.dq);
+                        uint2 o; o.x = (u32)(acc[r4][0] & 0xFFFF) | (u32)acc[r4][1] << 16; o.y = (u32)(acc[r4][2] & 0xFFFF) | (u32)acc[r4][3] << 16;
+                        *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = o;
                     }
                 } else {
                     uint2 z; z.x = 0; z.y = 0;
-                    for (int r = 0; r < 4; r++) *(uint2 *)(dp + (by * 4 + r) * N + bx * 4) = z;
+                    for (int r4 = 0; r4 < 4; r4++) *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = z;
                 }
             }
-        }
-        wave_sync();
-        // ---- step 4: itmp = clip16((C^T * deq + 64) >> 7)                                    (:514 inverse)
-        LANES(l) {
-            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
-            if (c < ncand) {
-                int acc[4][4];
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = 64;
-                mac_MX<N>(acc, CT, W.u.p1.res + sl * NN, by * 4, bx * 4);
-                i16 *ip = (i16 *)W.u.p1.tmp + sl * NN;       // tmp (i32) was last read in step 3; reuse it as i16
-                for (int r = 0; r < 4; r++) {
-                    uint2 o;
-                    o.x = (u32)(clip16(acc[r][0] >> 7) & 0xFFFF) | (u32)clip16(acc[r][1] >> 7) << 16;
-                    o.y = (u32)(clip16(acc[r][2] >> 7) & 0xFFFF) | (u32)clip16(acc[r][3] >> 7) << 16;
-                    *(uint2 *)(ip + (by * 4 + r) * N + bx * 4) = o;
+            if (P.tok) {
+                const int sb = sl * lpc;
+                const u64 seg = (lpc == 64) ? cm : ((cm >> sb) & ((1ull << (lpc & 63)) - 1));
+                const u64 above = (r == 63) ? 0ull : (seg >> (r + 1));
+                const int has_last = any && above == 0;
+                // tokens exist for the groups up to the last coded one; an all-zero TU is just cbf_luma = 0, written by the DC lane
+                const int talk = live && (any || above != 0 || r == 0);
+                int cfg = st << TG_ST | s << TG_S | (r == 0 ? TG_DC : 0) | (has_last ? TG_LAST : 0);
+                if (talk && seg != 0) {
+                    const int right = (bx < nb - 1) ? (int)((seg >> cg_rank(st, s, by * 8 + bx + 1)) & 1) : 0;
+                    const int below = (by < nb - 1) ? (int)((seg >> cg_rank(st, s, (by + 1) * 8 + bx)) & 1) : 0;
+                    cfg |= (below << 1 | right) << TG_PAT;
                 }
-            }
-        }
-        wave_sync();
-        // ---- step 5: rec = clip8(clip16((itmp * C + 2048) >> 12) + pred) ; SSE                (:515 inverse, :146,:165)
-        LANES(l) {
-            const int sl = l / lpc, blk = l % lpc, by = blk / nb, bx = blk % nb, c = c0 + sl;
-            if (c < ncand) {
-                const u8 *pp = W.u.p1.pred + sl * NN;
-                int acc[4][4];
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) acc[r][cc] = 2048;
-                mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, CT, by * 4, bx * 4);
-                int part = 0;
-                for (int r = 0; r < 4; r++) {
-                    const int y = by * 4 + r;
-                    const u32 pw = *(const u32 *)(pp + y * N + bx * 4);
-                    const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
-                    for (int cc = 0; cc < 4; cc++) {
-                        const int x = bx * 4 + cc;
-                        const int rc = clip3(clip16(acc[r][cc] >> 12) + (int)((pw >> (8 * cc)) & 255), 0, 255);
-                        const int d = (int)((ow >> (8 * cc)) & 255) - rc;
-                        part += d * d;
-                        if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
-                        else if (P.out_kind == OUT_T3SIDE) {
-                            if (P.k < 3 && y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
-                            if (P.k < 3 && x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
-                        }
+                u16 *base = P.tok + (size_t)c * TOK_CAP + tokn0;
+                const int cbf_ctx = CX_CBF_LUMA + (P.shape == 0 ? 1 : 0);
+                // pass 1: count (and learn whether this group ends with c1 == 0)
+                const long long ptk0 = prof_now();
+                int cnt = 0, big = 0;
+                if (talk) {
+                    if (seg == 0) cnt = 1;
+                    else {
+                        TokW w; w.p = base; w.n = 0; w.wr = 0;
+                        if (has_last) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
+                        const int rr = tok_count(L, nzm, cfg);
+                        cnt = w.n + (rr & 0xFFFF); big = rr >> 16;
                     }
                 }
-                if (P.only_mode < 0) lds_add(&W.sse[c], part);
+                prof_add(PF_T_SETUP, ptk0);
+                const long long ptk1 = prof_now();
+                const u64 bmask = wave_ballot(big);
+                int total;
+                const int off = seg_suffix_sum(cnt, l, lpc, &total);
+                prof_add(PF_T_GEN, ptk1);
+                const long long ptk2 = prof_now();
+                // pass 2: write at the group's place in the candidate's stream
+                if (talk) {
+                    TokW w; w.p = base + off; w.n = 0; w.wr = 1;
+                    if (seg == 0) tk_bin(w, cbf_ctx, 0);
+                    else {
+                        if (has_last) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
+                        if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
+                        tok_write(w.p + w.n, L, nzm, cfg);
+                    }
+                    if (r == 0) { W.tokn[c] = tokn0 + total; W.tnz[c] = (seg != 0); }
+                }
+                prof_add(PF_T_HDR, ptk2);
             }
         }
-        wave_sync();
+        wave_sync_lds();
+        // ---- step 4: itmp = clip16((C^T * deq + 64) >> 7)                                    (:514 inverse)
+        if (live) {
+            int acc[4][4];
+            for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 64;
+            mac_MX<N>(acc, CT, W.u.p1.res + sl * NN, by * 4, bx * 4);
+            i16 *ip = (i16 *)W.u.p1.tmp + sl * NN;       // tmp (i32) was last read in step 3; reuse it as i16
+            for (int r4 = 0; r4 < 4; r4++) {
+                uint2 o;
+                o.x = (u32)(clip16(acc[r4][0] >> 7) & 0xFFFF) | (u32)clip16(acc[r4][1] >> 7) << 16;
+                o.y = (u32)(clip16(acc[r4][2] >> 7) & 0xFFFF) | (u32)clip16(acc[r4][3] >> 7) << 16;
+                *(uint2 *)(ip + (by * 4 + r4) * N + bx * 4) = o;
+            }
+        }
+        wave_sync_lds();
+        // ---- step 5: rec = clip8(clip16((itmp * C + 2048) >> 12) + pred) ; SSE                (:515 inverse, :146,:165)
+        if (live) {
+            const u8 *pp = W.u.p1.pred + sl * NN;
+            int acc[4][4];
+            for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 2048;
+            mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, CT, by * 4, bx * 4);
+            int part = 0;
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int y = by * 4 + r4;
+                const u32 pw = *(const u32 *)(pp + y * N + bx * 4);
+                const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                for (int cc = 0; cc < 4; cc++) {
+                    const int x = bx * 4 + cc;
+                    const int rc = clip3(clip16(acc[r4][cc] >> 12) + (int)((pw >> (8 * cc)) & 255), 0, 255);
+                    const int d = (int)((ow >> (8 * cc)) & 255) - rc;
+                    part += d * d;
+                    if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
+                    else if (P.out_kind == OUT_T3SIDE) {
+                        if (P.k < 3 && y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
+                        if (P.k < 3 && x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
+                    }
+                }
+            }
+            if (P.only_mode < 0) lds_add(&W.sse[c], part);
+        }
+        wave_sync_lds();
+      }
     }
 }
 
@@ -860,10 +1151,9 @@ HD void p1_run(int wave, const P1Args &P) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Trial coding.  One lane codes one candidate with its own arithmetic coder + context copy.  Inside a
-// coefficient group the lanes walk the scan positions 15..0 TOGETHER (sig flags, then greater-1 flags,
-// then remaining levels), so every wave step is one predicated bin for all lanes: convergent code, no
-// token buffers.  Bit-exactness: same bins, same order, same <=8-bin bypass chunking as :898-1268.
+// Stream coding.  One lane codes one candidate's token stream with its own arithmetic coder and context copy;
+// every wave step is exactly one token per live lane.  Bit-exactness: same bins, same order, same <=8-bin
+// bypass chunking as :898-1268 (the tokens), same coder arithmetic as :858-932.
 // ---------------------------------------------------------------------------------------------------
 #ifdef IMCVT_HOSTEMU
 #define WAVE_ANY(c) (c)
@@ -871,201 +1161,120 @@ HD void p1_run(int wave, const P1Args &P) {
 #define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
 #endif
 
-struct Coder { Arith a; u8 *cx; Sink sink; };
-
-HD void put_bin(Coder &c, int ci, int bin) { code_bin(c.a, c.cx, c.sink, ci, bin); }
-HD void put_bypass(Coder &c, int v, int len) {                                             // :898-910
-    v &= (1 << len) - 1;
-    while (len > 0) { const int n = imin(len, 8); len -= n; code_bypass_chunk(c.a, c.sink, (v >> len) & ((1 << n) - 1), n); }
-}
-
-HD void mpm_list(int l, int a, int *m) {                       // :957-976
-    if (l != a) { m[0] = l; m[1] = a; m[2] = (l != 0 && a != 0) ? 0 : (l + a < 2) ? 26 : 1; }
-    else if (l > 1) { m[0] = l; m[1] = ((l + 29) & 31) + 2; m[2] = ((l - 1) & 31) + 2; }
-    else { m[0] = 0; m[1] = 1; m[2] = 26; }
-}
-
-// prev_intra_luma_pred_flag of one PU; returns the hit index (or -1) and the sorted-descending candidates in m[]
-HD int luma_mode_flag(Coder &c, int ml, int ma, int mode, int *m) {
-    mpm_list(ml, ma, m);
-    const int hit = (m[2] == mode) ? 2 : (m[1] == mode) ? 1 : (m[0] == mode) ? 0 : -1;   // later entries win, as :992-994
-    put_bin(c, CX_PREV_INTRA, hit >= 0);
-    return hit;
-}
-HD void luma_mode_rest(Coder &c, int *m, int hit, int mode) {  // mpm_idx / rem_intra_luma_pred_mode (:998-1016)
-    if (hit >= 0) { put_bypass(c, hit > 0, 1); if (hit > 0) put_bypass(c, hit - 1, 1); }
-    else {
-        int t, r = mode;
-        if (m[0] < m[1]) { t = m[0]; m[0] = m[1]; m[1] = t; }
-        if (m[1] < m[2]) { t = m[1]; m[1] = m[2]; m[2] = t; }
-        if (m[0] < m[1]) { t = m[0]; m[0] = m[1]; m[1] = t; }
-        r -= (r > m[0]); r -= (r > m[1]); r -= (r > m[2]);
-        put_bypass(c, r, 5);
+// one token on the lane's coder
+template <class S>
+HD void code_token(Arith &a, u8 *cx, S &sink, u32 tok) {
+    if (tok & 0x8000u) {                                                            // bypass chunk, :898-910
+        const int nb_ = (int)((tok >> 8) & 15u);
+        a.low = (a.low << nb_) + mul24(a.range, (int)(tok & 255u));                 // range <= 510, value <= 255
+        a.nbits -= nb_;
+    } else {                                                                        // context-coded bin, :913-932
+        const int ci = (int)(tok >> 1), bin = (int)(tok & 1u);
+        const int pz = cx[ci];
+        const uint2 e = SM.T.pst[pz];
+        const int lps = (int)((e.x >> (((a.range >> 6) & 3) * 8)) & 0xFF);
+        const int rm = a.range - lps;
+        const int is_lps = (bin ^ pz) & 1;
+        const int sh = is_lps ? imin(6, clz32((u32)lps) - 23) : (rm < 256);     // renorm table :714 == 8 - floor(log2 lps), capped at 6
+        cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
+        a.low = (a.low + (is_lps ? rm : 0)) << sh;
+        a.range = (is_lps ? lps : rm) << sh;
+        a.nbits -= sh;
     }
+    carry_out(a, sink);
 }
-
-HD void put_last_pos(Coder &c, int s, int st, int y, int x) {                               // :1045-1086
-    const int base = (s == 0) ? 0 : (s == 1) ? 3 : (s == 2) ? 6 : 10, shf = (s == 0) ? 0 : 1;
-    const int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;
-    // group index of a coordinate: 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8*8,9*8
-    const int gx = tx < 4 ? tx : (2 * (31 - clz32((u32)tx)) + ((tx >> (30 - clz32((u32)tx))) & 1));
-    const int gy = ty < 4 ? ty : (2 * (31 - clz32((u32)ty)) + ((ty >> (30 - clz32((u32)ty))) & 1));
-    const int gmax = 2 * (s + 2) - 1;                                         // group of N-1
-    for (int i = 0; i < gx; i++) put_bin(c, CX_LAST_X + base + (i >> shf), 1);
-    if (gx < gmax) put_bin(c, CX_LAST_X + base + (gx >> shf), 0);
-    for (int i = 0; i < gy; i++) put_bin(c, CX_LAST_Y + base + (i >> shf), 1);
-    if (gy < gmax) put_bin(c, CX_LAST_Y + base + (gy >> shf), 0);
-    if (gx > 3) { const int nb_ = (gx - 2) >> 1, mn = (2 + (gx & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) put_bypass(c, ((tx - mn) >> i) & 1, 1); }
-    if (gy > 3) { const int nb_ = (gy - 2) >> 1, mn = (2 + (gy & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) put_bypass(c, ((ty - mn) >> i) & 1, 1); }
+// The same for the trial coders, as straight-line code (no divergent branch on the common path): a bypass chunk is a
+// "context" bin on the row's pad byte with its own shift, an idle lane's token is a 0-bin chunk, and the common-case byte
+// goes to the ring through a selected address (the pad byte when there is nothing to put).
+#define CX_PAD (CTX_STRIDE - 1)
+#define TOK_IDLE 0x8000u
+HD void code_token_ring(Arith &a, u8 *cx, RingSink &sink, u32 tok) {
+    const int byp = (int)(tok >> 15) & 1;
+    const int ci = byp ? CX_PAD : (int)(tok >> 1);
+    const int pz = cx[ci] & 127;                                                  // (the pad byte holds anything)
+    const uint2 e = SM.T.pst[pz];
+    const int lps = (int)((e.x >> ((a.range >> 3) & 24)) & 0xFF);                 // :917-918
+    const int rm = a.range - lps;
+    const int is_lps = (int)(tok ^ (u32)pz) & 1;
+    const int sh_m = rm < 256, sh_l = imin(6, clz32((u32)lps) - 23);              // renorm table :714
+    const int sh = sh_m + (-is_lps & (sh_l - sh_m));                              // (a select the compiler will not turn into a branch)
+    cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
+    const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+    const int add = (byp | !is_lps) ? 0 : rm;
+    a.low = ((a.low + add) << nb_) + mul24(a.range, byp ? (int)(tok & 255u) : 0);      // :898-910 / :921-930
+    a.range = byp ? a.range : ((is_lps ? lps : rm) << sh);
+    a.nbits -= nb_;
+    // :858-878
+    const int need = a.nbits < 12;
+    const int lead = (int)((u32)a.low >> ((24 - a.nbits) & 31));
+    const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
+    const int fast = need & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
+    if (need) { a.nbits += 8; a.low &= (i32)(0xFFFFFFFFu >> a.nbits); }
+    u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : cx + CX_PAD;
+    *dst = (u8)v1;
+    a.cnt += fast;
+    a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
+    a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
+    if (need & !fast) carry_rare(a, sink, lead);
 }
+HD void shift16(U4 &b) { b.x = (b.x >> 16) | (b.y << 16); b.y = (b.y >> 16) | (b.z << 16); b.z = (b.z >> 16) | (b.w << 16); b.w >>= 16; }
 
-HD void put_remaining(Coder &c, int v, int k) {                                            // :1153-1168
-    if (v < (3 << k)) {                                  // prefix of <=3 bins, suffix of k<=4 bins: one chunk each
-        const int p = v >> k;
-        code_bypass_chunk(c.a, c.sink, (1 << (p + 1)) - 2, p + 1);
-        if (k) code_bypass_chunk(c.a, c.sink, v & ((1 << k) - 1), k);
-    } else {
-        int n = k; v -= 3 << k;
-        for (; v >= (1 << n); n++) v -= 1 << n;
-        const int t = 4 + n - k;
-        put_bypass(c, (1 << t) - 2, t); put_bypass(c, v, n);
-    }
-}
-
-// Description of what one lane has to code
-struct TrialJob {
-    int N;              // CU size
-    int shape;          // 0: 2Nx2N one TU, 1: 2Nx2N four TUs, 2: NxN, 3: residual of one 4x4 TU only (PU pricing, :1515)
-    int ctx_split;      // context of split_cu_flag=0, or -1 when the flag is absent
-    int mode[4], ml[4], ma[4];
-    const i16 *lv[4];   // scan-ordered levels per TU (global memory)
-    int last[4];        // last significant scan position per TU (-1: all zero)
-    u32 cg0[4], cg1[4]; // significant-group bitmaps
-};
-
-// Code the whole job.  lvl: 16 x i16 lane-private LDS scratch (levels of the current group, scan order).
-HD void trial_run(const TrialJob &J, Coder &c, i16 *lvl) {
-    const Tables &T = SM.T;
-    const int ntu = (J.shape == 0 || J.shape == 3) ? 1 : 4;
-    const int Ntu = (J.shape == 0) ? J.N : (J.shape == 3) ? 4 : J.N / 2;
-    const int s = (Ntu == 4) ? 0 : (Ntu == 8) ? 1 : (Ntu == 16) ? 2 : 3, ncg = Ntu >> 2;
-    // ---- coding_unit header (:1271-1339)
-    const long long pth = prof_now();
-    if (J.shape != 3) {
-        if (J.ctx_split >= 0) put_bin(c, J.ctx_split, 0);
-        if (J.N == 8) put_bin(c, CX_PART, J.shape != 2);
-        if (J.shape == 2) {
-            int m0[3], m1[3], m2[3], m3[3];
-            const int h0 = luma_mode_flag(c, J.ml[0], J.ma[0], J.mode[0], m0), h1 = luma_mode_flag(c, J.ml[1], J.ma[1], J.mode[1], m1);
-            const int h2 = luma_mode_flag(c, J.ml[2], J.ma[2], J.mode[2], m2), h3 = luma_mode_flag(c, J.ml[3], J.ma[3], J.mode[3], m3);
-            luma_mode_rest(c, m0, h0, J.mode[0]); luma_mode_rest(c, m1, h1, J.mode[1]);
-            luma_mode_rest(c, m2, h2, J.mode[2]); luma_mode_rest(c, m3, h3, J.mode[3]);
-        } else {
-            int m0[3];
-            const int h0 = luma_mode_flag(c, J.ml[0], J.ma[0], J.mode[0], m0);
-            luma_mode_rest(c, m0, h0, J.mode[0]);
-        }
-        put_bin(c, CX_CHROMA_PRED, 0);
-        if (J.shape != 2) put_bin(c, CX_SPLIT_TU + (J.N == 32 ? 0 : J.N == 16 ? 1 : 2), J.shape == 1);
-        put_bin(c, CX_CBF_CHROMA, 0); put_bin(c, CX_CBF_CHROMA, 0);
-    }
-    prof_add(PF_T_HDR, pth);
+// Code tokens p[0..n) (global memory, 16-byte aligned) and leave the emitted bytes in gbuf[0..a.cnt - cnt_on_entry).
+// Wave collective: every lane calls it, idle lanes with n == 0.  All lanes are in the same phase of their streams, so
+// the token loads (one 16-byte block per lane per 8 steps, issued one block ahead) and the byte flushes are wave-synchronous.
+// Returns non-zero if the lane's ring overflowed (the result is then void, see RingSink).
+HD int stream_run(Arith &a, u8 *cx, u8 *ring, u8 *gbuf, const u16 *p, int n) {
+    RingSink sink; sink.ring = ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+    // token blocks are loaded unconditionally (index clamped to the stream's last block; p is always a valid address),
+    // so the loop carries no conditional load and the only wait for a block is where it is first used, one round later
+    const int last_blk = imax((n - 1) >> 3, 0);
+    U4 cur = g_ld128(p);
     NOUNROLL
-    for (int k = 0; k < ntu; k++) {
-        const int mode = J.mode[(J.shape == 2) ? k : 0];
-        const int st = scan_type_of(Ntu, mode);
-        const int cbf = J.last[k] >= 0;
-        if (J.shape != 3) put_bin(c, CX_CBF_LUMA + (J.shape == 0 ? 1 : 0), cbf);
-        if (!cbf && J.shape != 3) continue;
-        // ---- residual_coding (:1172-1268)
-        const int last = imax(J.last[k], 0);
-        const u32 m0 = J.cg0[k], m1 = J.cg1[k];
-        const i16 *lvk = J.lv[k];
-        const int glast = last >> 4;
-        {
-            const int gp = cg_pos(st, s, glast), in = T.incg[st][last & 15];
-            put_last_pos(c, s, st, (gp >> 3) * 4 + (in >> 2), (gp & 7) * 4 + (in & 3));
-        }
-        int c1 = 1;
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {           // wave-uniform: one 16-byte block of tokens per lane per round
+        const u16 *pn = p + 8 * imin((k0 >> 3) + 1, last_blk);
+#ifdef IMCVT_HOSTEMU
+        const U4 nxt = g_ld128(pn);
+#else
+        // issued and waited for by hand: the compiler's own wait placement would drain this load before the inner loop
+        u32x4 nv;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv) : "v"(pn) : "memory");
+#endif
+        ring_sync(sink, a.cnt);                             // full 16-byte runs of output leave the ring
         NOUNROLL
-        for (int g = glast; g >= 0; g--) {
-            const int gp = cg_pos(st, s, g), gy = gp >> 3, gx = gp & 7, bit = gy * 8 + gx;
-            const int coded = (int)(((bit < 32 ? m0 >> bit : m1 >> (bit - 32))) & 1);
-            const int rbit = bit + 1, bbit = bit + 8;
-            const int right = (gx < ncg - 1) ? (int)(((rbit < 32 ? m0 >> rbit : m1 >> (rbit - 32))) & 1) : 0;
-            const int below = (gy < ncg - 1) ? (int)(((bbit < 32 ? m0 >> bbit : m1 >> (bbit - 32))) & 1) : 0;
-            const int pat = (below << 1) | right, dcg = (bit == 0), has_last = (g == glast);
-            if (!dcg && !has_last) put_bin(c, CX_CSBF + (pat != 0), coded);
-            if (!(coded || dcg)) continue;
-            // stage this group's 16 levels (scan order) in the lane's LDS slot
-            {
-                U4 q0, q1;
-                if (coded) { q0 = g_ld128(lvk + g * 16); q1 = g_ld128(lvk + g * 16 + 8); }
-                else { q0.x = q0.y = q0.z = q0.w = 0; q1 = q0; }
-                u32 *d = (u32 *)lvl;
-                d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
-            }
-            const long long ptA = prof_now();
-            // significance context of scan position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
-            u64 tab; int fbits, base;
-            if (Ntu == 4) { tab = T.c4tab[st]; fbits = 4; base = 0; }
-            else { tab = T.posadd[pat][st]; fbits = 2; base = 9 + (Ntu >= 16 ? 12 : 0) + ((Ntu == 8 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); }
-            const int fmask = (1 << fbits) - 1;
-            const int nstart = has_last ? (last & 15) : 15;
-            // -- pass A: significance flags, positions 15..0 in lock-step
-            int nnz = 0, signs = 0; u32 nzm = 0;
-            NOUNROLL
-            for (int n = 15; n >= 0; n--) {
-                const int v = lvl[n];
-                const int in = n <= nstart;
-                const int code = in & !(has_last & (n == nstart)) & (dcg | (n != 0) | (nnz > 0));
-                if (WAVE_ANY(code)) {
-                    if (code) {
-                        const int ci = (dcg & (n == 0)) ? 0 : base + (int)((tab >> (fbits * n)) & fmask);
-                        put_bin(c, CX_SIG + ci, v != 0);
-                    }
-                }
-                if (in & (v != 0)) { nnz++; signs = (signs << 1) | (v < 0); nzm |= 1u << n; }
-            }
-            prof_add(PF_T_GEN, ptA);
-            if (nnz == 0) continue;
-            const long long ptB = prof_now();
-            // -- pass B: greater-1 flags of the first 8 non-zero levels (scan-reverse order), then one greater-2 flag
-            const int set = (dcg ? 0 : 2) + (c1 == 0);
-            int esc = nnz > 8, g2 = -1;
-            c1 = 1;
-            {
-                u32 m = nzm; int cnt = 0;
-                NOUNROLL
-                while (m != 0 && cnt < 8) {
-                    const int n = hibit(m); m &= ~(1u << n);
-                    const int mg = iabs((int)lvl[n]);
-                    const int big = mg > 1;
-                    put_bin(c, CX_GT1 + 4 * set + c1, big);
-                    if (big) { c1 = 0; if (g2 < 0) g2 = mg > 2; else esc = 1; }
-                    else if (c1 > 0 && c1 < 3) c1++;
-                    cnt++;
-                }
-            }
-            if (c1 == 0 && g2 >= 0) { put_bin(c, CX_GT2 + set, g2); esc |= g2; }
-            if (nnz > 8) { code_bypass_chunk(c.a, c.sink, (signs >> (nnz - 8)) & 0xFF, 8); code_bypass_chunk(c.a, c.sink, signs & ((1 << (nnz - 8)) - 1), nnz - 8); }
-            else code_bypass_chunk(c.a, c.sink, signs, nnz);
-            prof_add(PF_T_DRAIN, ptB); prof_cnt(PF_T_NTOK, 1);
-            const long long ptC = prof_now();
-            // -- pass C: remaining absolute levels
-            if (esc) {
-                int base2 = 3, rice = 0, j = 0; u32 m = nzm;
-                NOUNROLL
-                while (m != 0) {
-                    const int n = hibit(m); m &= ~(1u << n);
-                    const int mg = iabs((int)lvl[n]);
-                    const int r = mg - (j < 8 ? base2 : 1);
-                    if (r >= 0) { put_remaining(c, r, rice); if (mg > (3 << rice)) rice = imin(rice + 1, 4); }
-                    if (mg >= 2) base2 = 2;
-                    j++;
-                }
-            }
-            prof_add(PF_T_NDRAIN, ptC);
+        for (int j = 0; j < 8; j++) {                       // no VMEM instruction in here
+            code_token_ring(a, cx, sink, (k0 + j < n) ? (cur.x & 0xFFFFu) : TOK_IDLE);
+            shift16(cur);
         }
+#ifdef IMCVT_HOSTEMU
+        cur = nxt;
+#else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nv) : : "memory");
+        cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
+#endif
+    }
+    ring_finish(sink, a.cnt);
+    return sink.ovf;
+}
+// the same on the safe path: bytes go straight to memory, one token load per step
+HD void stream_run_safe(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n) {
+    Sink sink; sink.base = gbuf; sink.off = (u32)(0 - a.cnt);
+    NOUNROLL
+    for (int k = 0; WAVE_ANY(k < n); k++)
+        if (k < n) code_token(a, cx, sink, (u32)(u16)g_ld16((const i16 *)(p + k)));
+}
+// One trial: contexts copied from cx_src, coder state `a` in/out.  Wave collective (`on` = this lane has a stream).
+#ifdef IMCVT_TOKSTAT
+static long long g_tokstat[4];    // trials, tokens, lanes with a stream
+#endif
+HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, u8 *ring, u8 *gbuf, const u16 *p, int n, int on) {
+    const Arith a0 = a;
+#ifdef IMCVT_TOKSTAT
+    if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
+#endif
+    if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32 *)(cx + i) = *(const u32 *)(cx_src + i);
+    const int ovf = stream_run(a, cx, ring, gbuf, p, on ? n : 0);
+    if (WAVE_ANY(ovf)) {                                    // practically never: redo the overflowed lanes without the ring
+        if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32 *)(cx + i) = *(const u32 *)(cx_src + i); }
+        stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
     }
 }

@@ -23,7 +23,7 @@ HD Avail child_avail(const Avail &p, int k) {       // Z-order availability of q
 }
 #define F (SM.F)
 
-HD i16 *wave_lv(const Scratch &sc, int wave) { return sc.lv + (size_t)wave * LV_PER_WAVE; }
+HD u16 *wave_tok(const Scratch &sc, int wave) { return sc.tok + (size_t)wave * TOK_SLOTS * TOK_CAP; }
 HD u8 *lane_bytes(const Scratch &sc, int wave, int lane) { return sc.bytes + ((size_t)wave * NMODE + lane) * TRIAL_BYTES; }
 
 // neighbour context in 4x4 units relative to the CTU (apron row/column = neighbours outside the CTU)
@@ -35,21 +35,29 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q, h = N / 2;
-    i16 *lv = wave_lv(F.sc, wave);
+    u16 *tok = wave_tok(F.sc, wave);
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
+    const int uy = y0 >> 2, ux = x0 >> 2;
+    const int big_l = N > nb_size(uy, ux - 1), big_a = N > nb_size(uy - 1, ux);
+    const int ml = nb_mode(uy, ux - 1), ma = nb_mode(uy - 1, ux);
     LANES(l) {
-        if (l < NMODE) {
+        if (l < NMODE) {                                // every candidate's stream opens with its coding_unit header
             W.sse[l] = 0;
-            for (int k = 0; k < 4; k++) { W.last[k][l] = -1; W.cgm[l][k] = 0; }
+            CuHdr J;
+            J.N = N; J.shape = shape; J.ctx_split = (N >= 16) ? CX_SPLIT_CU + big_l + big_a : -1;
+            J.mode[0] = l; J.ml[0] = ml; J.ma[0] = ma;
+            TokW w; w.p = tok + (size_t)l * TOK_CAP; w.n = 0; w.wr = 1;
+            tk_cu_header(w, J);
+            W.tokn[l] = w.n;
         }
     }
-    wave_sync();
+    wave_sync_lds();
     P1Args P;
-    P.q = q; P.only_mode = -1; P.cg_words2 = (shape == 0);
+    P.q = q; P.only_mode = -1; P.shape = shape; P.tok = tok;
     long long pt = prof_now();
     if (shape == 0) {
         border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
-        P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE; P.lv = lv;
+        P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
         p1_run(wave, P);
     } else {
         for (int k = 0; k < 4; k++) {
@@ -58,37 +66,22 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
             if (k == 0) border_from_tile(wave, h, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
             else border_tu_split(wave, N, y0, x0, k, av.l, av.bl, av.a, av.ar);
             P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
-            P.lv = lv + (size_t)k * NMODE * h * h;
             p1_run(wave, P);
         }
     }
     prof_add(shape == 0 ? (N == 32 ? PF_P1_32 : N == 16 ? PF_P1_16 : PF_P1_8) : (N == 32 ? PF_P1_16 : N == 16 ? PF_P1_8 : PF_P1_4), pt);
+    wave_sync();                                        // the tokens are in memory
     // trial coders: lane m prices mode m from the CU's entry state
-    const int uy = y0 >> 2, ux = x0 >> 2;
-    const int big_l = N > nb_size(uy, ux - 1), big_a = N > nb_size(uy - 1, ux);
-    const int ml = nb_mode(uy, ux - 1), ma = nb_mode(uy - 1, ux);
     const RdW rw = rd_weights(q);
     pt = prof_now();
     LANES(l) {
-        if (l < NMODE) {
-            TrialJob J;
-            J.N = N; J.shape = shape; J.ctx_split = (N >= 16) ? CX_SPLIT_CU + big_l + big_a : -1;
-            J.mode[0] = l; J.ml[0] = ml; J.ma[0] = ma;
-            const int nt = shape ? 4 : 1, tn = shape ? h * h : N * N;
-            for (int k = 0; k < nt; k++) {
-                J.lv[k] = lv + (size_t)k * NMODE * tn + (size_t)l * tn;
-                J.last[k] = W.last[k][l]; J.cg0[k] = shape ? W.cgm[l][k] : W.cgm[l][0]; J.cg1[k] = shape ? 0u : W.cgm[l][1];
-            }
-            const long long pts = prof_now();
-            u8 *cx = W.u.p2.cx[l];
-            for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.entry_cx[depth][i];
-            Arith a = SM.entry_a[depth];
-            const int len0 = arith_len(a);
-            prof_add(PF_T_SETUP, pts);
-            Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)((wave * NMODE + l) * TRIAL_BYTES - a.cnt);
-            trial_run(J, c, W.u.p2.lvl[l]);
-            W.fin[l] = pack_arith(c.a);
-            W.cost[l] = rd_cost(rw, W.sse[l], arith_len(c.a) - len0);
+        const int on = l < NMODE, ll = on ? l : 0;
+        Arith a = SM.entry_a[depth];
+        const int len0 = arith_len(a);
+        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], W.u.p2.ring[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP, W.tokn[ll], on);
+        if (on) {
+            W.fin[l] = pack_arith(a);
+            W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
         }
     }
     wave_sync();
@@ -96,76 +89,90 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
 }
 
 // ---- the NxN chain of an 8x8 CU (:1490-1543); wave-uniform call ---------------------------------------------------
+// Token layout of a PU candidate (slot c): [7] cbf_luma, [8..] last position + group (the part PU pricing codes, :1515).
+// Slot NMODE holds the NxN stream ([0..) header, then the four winners' tokens) and, from NXN_KEEP on, the winners' copies.
+#define NXN_KEEP 1024
+#define NXN_KEEP_STRIDE 160
 HDN void eval_NxN(int wave, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q;
-    i16 *lv = wave_lv(F.sc, wave);
+    u16 *tok = wave_tok(F.sc, wave);
+    u16 *nxn = tok + (size_t)NMODE * TOK_CAP;
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
     const RdW rw = rd_weights(q);
     for (int k = 0; k < 4; k++) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
-        LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.last[0][l] = -1; W.cgm[l][0] = 0; } }
-        wave_sync();
+        LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.tokn[l] = 7; } }
+        wave_sync_lds();
         long long pt = prof_now();
         border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
         P1Args P;
-        P.q = q; P.only_mode = -1; P.cg_words2 = 0; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4; P.lv = lv;
+        P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
         p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
-        LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
-            if (l < NMODE) {
-                TrialJob J;
-                J.N = 8; J.shape = 3; J.ctx_split = -1; J.mode[0] = l; J.ml[0] = 0; J.ma[0] = 0;
-                J.lv[0] = lv + l * 16; J.last[0] = W.last[0][l]; J.cg0[0] = W.cgm[l][0]; J.cg1[0] = 0;
-                u8 *cx = W.u.p2.cx[l];
-                for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.cx0[i];
-                Arith a; arith_reset(a);
-                Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)((wave * NMODE + l) * TRIAL_BYTES);
-                trial_run(J, c, W.u.p2.lvl[l]);
-                W.cost[l] = rd_cost(rw, W.sse[l], arith_len(c.a));
-            }
-        }
         wave_sync();
+        LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
+            const int on = l < NMODE, ll = on ? l : 0;
+            Arith a; arith_reset(a);
+            run_trial(a, SM.cx0, W.u.p2.cx[ll], W.u.p2.ring[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP + 8, W.tokn[ll] - 8, on);
+            if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
+        }
+        wave_sync_lds();
         prof_add(PF_P2_PU, pt);
         LANES(l) {                                      // pick the PU mode: later mode wins ties (:1520)
             if (l == 0) {
                 int best = I32MAX, bm = 0;
                 for (int m = 0; m < NMODE; m++) if (best >= W.cost[m]) { best = W.cost[m]; bm = m; }
-                W.pu_mode[k] = bm; W.pu_sse[k] = W.sse[bm]; W.pu_last[k] = W.last[0][bm];
+                W.pu_mode[k] = bm; W.pu_sse[k] = W.sse[bm];
+                W.pu_cnt[k] = W.tnz[bm] ? W.tokn[bm] - 7 : 1;                            // an all-zero PU is cbf_luma = 0 inside the CU
             }
         }
-        wave_sync();
-        LANES(l) {                                      // keep its levels and put its reconstruction in place (:1523-1524)
-            if (l < 16) {
-                const int bm = W.pu_mode[k];
-                g_st16(lv + NMODE * 16 + k * 16 + l, (W.pu_last[k] >= 0) ? (int)g_ld16(lv + bm * 16 + l) : 0);   // kept beside the candidates' levels
-                SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
-            }
+        wave_sync_lds();
+        LANES(l) {                                      // keep its tokens and put its reconstruction in place (:1523-1524)
+            const int bm = W.pu_mode[k], cnt = W.pu_cnt[k];
+            const u16 *src = tok + (size_t)bm * TOK_CAP + 7;
+            u16 *dst = nxn + NXN_KEEP + k * NXN_KEEP_STRIDE;
+            for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), g_ld16((const i16 *)(src + i)));
+            if (l < 16) SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
         }
-        wave_sync();
+        wave_sync_lds();
     }
     // price the whole NxN CU from the entry state (:1530-1543)
     const int uy = y0 >> 2, ux = x0 >> 2;
     const long long ptn = prof_now();
     LANES(l) {
         if (l == 0) {
-            TrialJob J;
+            CuHdr J;
             J.N = 8; J.shape = 2; J.ctx_split = -1;
-            for (int k = 0; k < 4; k++) { J.mode[k] = W.pu_mode[k]; J.lv[k] = lv + NMODE * 16 + k * 16; J.last[k] = W.pu_last[k]; J.cg0[k] = W.pu_last[k] >= 0; J.cg1[k] = 0; }
+            for (int k = 0; k < 4; k++) J.mode[k] = W.pu_mode[k];
             J.ml[0] = nb_mode(uy, ux - 1);     J.ma[0] = nb_mode(uy - 1, ux);
             J.ml[1] = J.mode[0];                  J.ma[1] = nb_mode(uy - 1, ux + 1);
             J.ml[2] = nb_mode(uy + 1, ux - 1); J.ma[2] = J.mode[0];
             J.ml[3] = J.mode[2];                  J.ma[3] = J.mode[1];
-            u8 *cx = W.u.p2.cx[0];
-            for (int i = 0; i < CTX_STRIDE; i++) cx[i] = SM.entry_cx[2][i];
-            Arith a = SM.entry_a[2];
-            const int len0 = arith_len(a);
-            Coder c; c.a = a; c.cx = cx; c.sink.base = ubytes; c.sink.off = (u32)(wave * NMODE * TRIAL_BYTES - a.cnt);
-            trial_run(J, c, W.u.p2.lvl[0]);
-            W.fin[0] = pack_arith(c.a);
-            W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(c.a) - len0);
+            TokW w; w.p = nxn; w.n = 0; w.wr = 1;
+            tk_cu_header(w, J);
+            W.tokn[NMODE] = w.n;
+        }
+    }
+    wave_sync();                                        // header and kept tokens are in memory
+    LANES(l) {
+        int pos = W.tokn[NMODE];
+        for (int k = 0; k < 4; k++) {
+            const int cnt = W.pu_cnt[k];
+            const u16 *src = nxn + NXN_KEEP + k * NXN_KEEP_STRIDE;
+            for (int i = l; i < cnt; i += 64) g_st16((i16 *)(nxn + pos + i), g_ld16((const i16 *)(src + i)));
+            pos += cnt;
+        }
+        wave_sync();
+        const int on = l == 0;
+        Arith a = SM.entry_a[2];
+        const int len0 = arith_len(a);
+        run_trial(a, SM.entry_cx[2], W.u.p2.cx[0], W.u.p2.ring[0], ubytes + (size_t)(wave * NMODE) * TRIAL_BYTES, nxn, pos, on);
+        if (on) {
+            W.fin[0] = pack_arith(a);
+            W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);
         }
     }
     wave_sync();
@@ -225,7 +232,7 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
                 if (w == 0) {
                     const int wave = 0;
                     P1Args P;
-                    P.q = F.job.q; P.only_mode = mode; P.cg_words2 = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.lv = (i16 *)0;
+                    P.q = F.job.q; P.only_mode = mode; P.shape = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.tok = (u16 *)0;
                     if (kind == 1) {
                         border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
                         P.N = N; P.y0 = y0; P.x0 = x0;

@@ -63,9 +63,6 @@ extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r1 (
 extern "C" int imcvt_hevc_padded(int v) { return ((v < 8192 ? v : 8192) + 31) / 32 * 32; }
 extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 32) * (h + 32) + 65536; }
 
-static const size_t kLvBytes = (size_t)NWAVES * LV_PER_WAVE * sizeof(i16);
-static const size_t kTrialBytes = (size_t)NWAVES * NMODE * TRIAL_BYTES;
-static const size_t kAboveBytes = 8192 / 4 + 64;
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
@@ -86,7 +83,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
     Tables *T = new Tables(); ColdTables *K = new ColdTables();
     imcvt::build_tables(*T, *K);
-    const size_t per_wg = align256(kLvBytes) + align256(kTrialBytes) + align256(kAboveBytes);
+    const size_t per_wg = scratch_bytes_per_wg();
     bool ok = hipMalloc(&c->d_tables, sizeof(Tables)) == hipSuccess
            && hipMemcpy(c->d_tables, T, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&c->d_cold, sizeof(ColdTables)) == hipSuccess
@@ -100,13 +97,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     delete T; delete K;
     if (ok) {
         std::vector<Scratch> hs(c->max_wg);
-        for (int i = 0; i < c->max_wg; i++) {
-            u8 *base = (u8 *)c->d_pool + per_wg * i;
-            hs[i].lv = (i16 *)base;
-            hs[i].bytes = base + align256(kLvBytes);
-            hs[i].above_sz = hs[i].bytes + align256(kTrialBytes);
-            hs[i].trace = nullptr; hs[i].trace_cap = 0; hs[i].prof = nullptr;
-        }
+        for (int i = 0; i < c->max_wg; i++) scratch_carve(hs[i], (u8 *)c->d_pool + per_wg * i);
         ok = hipMemcpy(c->d_scratch, hs.data(), sizeof(Scratch) * c->max_wg, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { fprintf(stderr, "imcvt_hevc: context allocation failed\n"); imcvt_hevc_destroy(c); return nullptr; }

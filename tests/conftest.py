@@ -22,20 +22,30 @@ def built():
     return True
 
 
-@pytest.fixture(scope="session")
-def hostemu(built):
-    """TEST-ONLY host emulation of the device source (tests/hostemu)."""
+def _hostemu_lib(name, flags):
     import ctypes as C
     d = os.path.join(ROOT, "tests", "hostemu")
-    so = os.path.join(d, "libhostemu.so")
+    so = os.path.join(d, name)
     srcs = [os.path.join(d, "hostemu.cpp")] + [os.path.join(ROOT, "imcvt_amd", "csrc", f) for f in ("hevc_core.h", "hevc_frame.h", "hevc_tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", so, srcs[0]], check=True)
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", *flags, "-o", so, srcs[0]], check=True)
     lib = C.CDLL(so)
     u8p = C.POINTER(C.c_ubyte)
     lib.hostemu_HEVCImageEncoder.restype = C.c_int
     lib.hostemu_HEVCImageEncoder.argtypes = [u8p, u8p, u8p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int]
     return lib
+
+
+@pytest.fixture(scope="session")
+def hostemu(built):
+    """TEST-ONLY host emulation of the device source (tests/hostemu)."""
+    return _hostemu_lib("libhostemu.so", [])
+
+
+@pytest.fixture(scope="session")
+def hostemu_ovf(built):
+    """Same, built so that every rare-path byte of a trial coder overflows its ring: exercises the safe re-run path."""
+    return _hostemu_lib("libhostemu_ovf.so", ["-DIMCVT_FORCE_OVF"])
 
 
 def kat_entries():

@@ -37,6 +37,17 @@ def test_device_source_matches_golden(hostemu, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+OVF = [e for e in PICK if e["input"].get("w", 999) <= 100 or e["input"].get("file") == "p4_gray.pgm"]
+
+
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_ring_overflow_path_matches_golden(hostemu_ovf, e):
+    # trial coders whose byte ring overflows are repeated on the safe path (hevc_core.h run_trial): same streams
+    stream, rcon = emu_encode(hostemu_ovf, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
 def test_lds_budget(hostemu):
     # two workgroups per CU need <= 80 KiB each (160 KiB LDS per CU)
     assert hostemu.hostemu_shm_bytes() <= 80 * 1024
