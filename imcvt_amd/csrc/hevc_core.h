@@ -79,6 +79,7 @@ HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
 HD void g_st128(void *p, const U4 &v) { *(U4 *)p = v; }
 HD u8 *uniform_ptr(u8 *p) { return p; }
 HD int hibit(u32 v) { return 31 - __builtin_clz(v); }
+HD int clz_nz(u32 v) { return v ? __builtin_clz(v) : 32; }
 HD int popc32(u32 v) { return __builtin_popcount(v); }
 HD int ctz64(u64 v) { return __builtin_ctzll(v); }
 #else
@@ -99,6 +100,7 @@ HD u8 *uniform_ptr(u8 *p) {
     return (u8 *)(((u64)hi << 32) | lo);
 }
 HD int hibit(u32 v) { return 31 - __clz((int)v); }
+HD int clz_nz(u32 v) { return __builtin_clz(v); }          // v != 0 where the result is used
 HD int popc32(u32 v) { return __popc(v); }
 HD int ctz64(u64 v) { return __builtin_ctzll(v); }
 #endif
@@ -176,9 +178,11 @@ HD Arith unpack_arith(const FinState &f) {
 }
 
 #ifndef RING_BYTES
-#define RING_BYTES 64      // per-lane byte ring of the trial coders (RingSink)
+#define RING_BYTES 32      // per-lane byte ring of the trial coders (RingSink)
 #endif
-#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + NMODE * RING_BYTES)      // p2's extent
+#define LEADQ 10           // per-lane queue of byte leads: at most one per token of an 8-token block, plus the slot the idle write lands in
+struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
+#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
 struct alignas(16) WaveMem {
     Border  bsh;                 // border shared by all modes of a block
     i32 tokn[NMODE + 1];         // tokens written so far to each candidate's stream (slot NMODE: the NxN stream)
@@ -190,7 +194,7 @@ struct alignas(16) WaveMem {
     i32 nxn_cost;
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
         struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                   // one pipeline pass
-        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) u8 ring[NMODE][RING_BYTES]; } p2;                // trial coders: context copies, byte rings
+        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
     } u;
 };
@@ -300,7 +304,11 @@ struct Sink { u8 *base; u32 off; };          // byte i of the lane's run lives a
 HD void sink_put(Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), v); }
 HD int sink_room(Sink &, int) { return 1; }
 struct RingSink { u8 *ring; u8 *gbuf; int c0, fl, ovf; };   // byte i lives at local index j = i - c0: ring[j % RING_BYTES] until flushed, then gbuf[j]; fl = bytes flushed (multiple of 16)
-HD void ring_flush16(RingSink &s) { const U4 b = *(const U4 *)(s.ring + (s.fl & (RING_BYTES - 1))); g_st128(s.gbuf + s.fl, b); s.fl += 16; }
+HD void ring_flush16(RingSink &s) {      // the ring is only 4-byte aligned (odd dword stride between lanes)
+    const u32 *r = (const u32 *)(s.ring + (s.fl & (RING_BYTES - 1)));
+    U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
+    g_st128(s.gbuf + s.fl, b); s.fl += 16;
+}
 HD void sink_put(RingSink &s, int i, int v) { s.ring[(i - s.c0) & (RING_BYTES - 1)] = (u8)v; }
 #ifdef IMCVT_FORCE_OVF      // test builds: every rare-path byte overflows, so the safe path is exercised
 HD int sink_room(RingSink &s, int) { s.ovf = 1; return 0; }
@@ -1183,48 +1191,53 @@ HD void code_token(Arith &a, u8 *cx, S &sink, u32 tok) {
     }
     carry_out(a, sink);
 }
-// The same for the trial coders, as straight-line code (no divergent branch on the common path): a bypass chunk is a
-// "context" bin on the row's pad byte with its own shift, an idle lane's token is a 0-bin chunk, and the common-case byte
-// goes to the ring through a selected address (the pad byte when there is nothing to put).
+// The same for the trial coders, as straight-line code (no divergent branch): a bypass chunk is a "context" bin on the
+// row's pad byte with its own shift and an idle lane's token is a 0-bin chunk.  The arithmetic step does not touch the
+// byte-level state at all: when a byte leaves `low` (:858-862) its 9-bit lead (carry + byte) is queued in LDS, and
+// the carry / 0xFF-run / emulation-prevention logic of :863-878,:820-831 runs once per queued lead after the block
+// (lead_step below) — about one byte per eight tokens, so that logic costs an eighth of what it did per token.
 #define CX_PAD (CTX_STRIDE - 1)
 #define TOK_IDLE 0x8000u
-HD void code_token_ring(Arith &a, u8 *cx, RingSink &sink, u32 tok) {
-    const int byp = (int)(tok >> 15) & 1;
-    const int ci = byp ? CX_PAD : (int)(tok >> 1);
+HD void code_token_q(Arith &a, u8 *cx, u16 *lq, int &qn, u32 tok) {
+    const int byp = tok >= 0x8000u;
+    const u32 cim = tok >> 1;
+    const int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
     const int pz = cx[ci] & 127;                                                  // (the pad byte holds anything)
     const uint2 e = SM.T.pst[pz];
     const int lps = (int)((e.x >> ((a.range >> 3) & 24)) & 0xFF);                 // :917-918
     const int rm = a.range - lps;
     const int is_lps = (int)(tok ^ (u32)pz) & 1;
-    const int sh_m = rm < 256, sh_l = imin(6, clz32((u32)lps) - 23);              // renorm table :714
-    const int sh = sh_m + (-is_lps & (sh_l - sh_m));                              // (a select the compiler will not turn into a branch)
+    const int r2 = is_lps ? lps : rm;
+    const int sh = clz_nz((u32)r2) - 23;                                          // renorm table :714 (lps >= 6) and the MPS shift :926 (rm >= 128) in one
     cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
     const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
-    const int add = (byp | !is_lps) ? 0 : rm;
+    const int add = (is_lps & !byp) ? rm : 0;
     a.low = ((a.low + add) << nb_) + mul24(a.range, byp ? (int)(tok & 255u) : 0);      // :898-910 / :921-930
-    a.range = byp ? a.range : ((is_lps ? lps : rm) << sh);
+    a.range = byp ? a.range : (r2 << sh);
     a.nbits -= nb_;
-    // :858-878
-    const int need = a.nbits < 12;
-    const int lead = (int)((u32)a.low >> ((24 - a.nbits) & 31));
-    const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
-    const int fast = need & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
-    if (need) { a.nbits += 8; a.low &= (i32)(0xFFFFFFFFu >> a.nbits); }
-    u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : cx + CX_PAD;
-    *dst = (u8)v1;
-    a.cnt += fast;
-    a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
-    a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
-    if (need & !fast) carry_rare(a, sink, lead);
+    const int need = a.nbits < 12;                                                // :858-862
+    lq[qn] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));                          // always written; only kept when `need`
+    qn += need;
+    a.nbits += need ? 8 : 0;
+    a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
 }
-HD void shift16(U4 &b) { b.x = (b.x >> 16) | (b.y << 16); b.y = (b.y >> 16) | (b.z << 16); b.z = (b.z >> 16) | (b.w << 16); b.w >>= 16; }
+template <class S>
+HD void lead_step(Arith &a, S &sink, int lead) {                                  // :863-878
+    const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
+    if (a.nbytes == 1 && lead != 0xFF && !(a.zeros >= 2 && v1 <= 3)) {
+        sink_put(sink, a.cnt++, v1);
+        a.zeros = v1 ? 0 : a.zeros + 1;
+        a.bufbyte = lead & 0xFF;
+    } else carry_rare(a, sink, lead);
+}
+HD u32 tok_of(const U4 &b, int j) { const u32 w = (j < 2) ? b.x : (j < 4) ? b.y : (j < 6) ? b.z : b.w; return (j & 1) ? (w >> 16) : (w & 0xFFFFu); }
 
 // Code tokens p[0..n) (global memory, 16-byte aligned) and leave the emitted bytes in gbuf[0..a.cnt - cnt_on_entry).
 // Wave collective: every lane calls it, idle lanes with n == 0.  All lanes are in the same phase of their streams, so
 // the token loads (one 16-byte block per lane per 8 steps, issued one block ahead) and the byte flushes are wave-synchronous.
 // Returns non-zero if the lane's ring overflowed (the result is then void, see RingSink).
-HD int stream_run(Arith &a, u8 *cx, u8 *ring, u8 *gbuf, const u16 *p, int n) {
-    RingSink sink; sink.ring = ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) {
+    RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
     // token blocks are loaded unconditionally (index clamped to the stream's last block; p is always a valid address),
     // so the loop carries no conditional load and the only wait for a block is where it is first used, one round later
     const int last_blk = imax((n - 1) >> 3, 0);
@@ -1235,15 +1248,20 @@ HD int stream_run(Arith &a, u8 *cx, u8 *ring, u8 *gbuf, const u16 *p, int n) {
 #ifdef IMCVT_HOSTEMU
         const U4 nxt = g_ld128(pn);
 #else
-        // issued and waited for by hand: the compiler's own wait placement would drain this load before the inner loop
+        // issued and waited for by hand: the compiler's own wait placement would drain this load before the token steps
         u32x4 nv;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv) : "v"(pn) : "memory");
 #endif
-        ring_sync(sink, a.cnt);                             // full 16-byte runs of output leave the ring
-        NOUNROLL
-        for (int j = 0; j < 8; j++) {                       // no VMEM instruction in here
-            code_token_ring(a, cx, sink, (k0 + j < n) ? (cur.x & 0xFFFFu) : TOK_IDLE);
-            shift16(cur);
+        if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / lm rows belong to lane 0
+            ring_sync(sink, a.cnt);                         // full 16-byte runs of output leave the ring
+            int qn = 0;
+            const int rem = n - k0;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++)                     // no VMEM instruction in here
+                code_token_q(a, cx, lm->lq, qn, (j < rem) ? tok_of(cur, j) : TOK_IDLE);
+            NOUNROLL
+            for (int i = 0; WAVE_ANY(i < qn); i++)          // the bytes this block pushed out of `low`
+                if (i < qn) lead_step(a, sink, (int)lm->lq[i]);
         }
 #ifdef IMCVT_HOSTEMU
         cur = nxt;
@@ -1266,13 +1284,13 @@ HD void stream_run_safe(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n) {
 #ifdef IMCVT_TOKSTAT
 static long long g_tokstat[4];    // trials, tokens, lanes with a stream
 #endif
-HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, u8 *ring, u8 *gbuf, const u16 *p, int n, int on) {
+HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n, int on) {
     const Arith a0 = a;
 #ifdef IMCVT_TOKSTAT
     if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
 #endif
     if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32 *)(cx + i) = *(const u32 *)(cx_src + i);
-    const int ovf = stream_run(a, cx, ring, gbuf, p, on ? n : 0);
+    const int ovf = stream_run(a, cx, lm, gbuf, p, on ? n : 0);
     if (WAVE_ANY(ovf)) {                                    // practically never: redo the overflowed lanes without the ring
         if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32 *)(cx + i) = *(const u32 *)(cx_src + i); }
         stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);

@@ -78,7 +78,7 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a = SM.entry_a[depth];
         const int len0 = arith_len(a);
-        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], W.u.p2.ring[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP, W.tokn[ll], on);
+        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], &W.u.p2.lm[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP, W.tokn[ll], on);
         if (on) {
             W.fin[l] = pack_arith(a);
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
@@ -116,7 +116,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             const int on = l < NMODE, ll = on ? l : 0;
             Arith a; arith_reset(a);
-            run_trial(a, SM.cx0, W.u.p2.cx[ll], W.u.p2.ring[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP + 8, W.tokn[ll] - 8, on);
+            run_trial(a, SM.cx0, W.u.p2.cx[ll], &W.u.p2.lm[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP + 8, W.tokn[ll] - 8, on);
             if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
         }
         wave_sync_lds();
@@ -169,7 +169,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
         const int on = l == 0;
         Arith a = SM.entry_a[2];
         const int len0 = arith_len(a);
-        run_trial(a, SM.entry_cx[2], W.u.p2.cx[0], W.u.p2.ring[0], ubytes + (size_t)(wave * NMODE) * TRIAL_BYTES, nxn, pos, on);
+        run_trial(a, SM.entry_cx[2], W.u.p2.cx[0], &W.u.p2.lm[0], ubytes + (size_t)(wave * NMODE) * TRIAL_BYTES, nxn, pos, on);
         if (on) {
             W.fin[0] = pack_arith(a);
             W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);

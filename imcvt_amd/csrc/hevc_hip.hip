@@ -17,7 +17,7 @@
 
 #define HDR_MAX 96
 
-__global__ __launch_bounds__(WG_THREADS, 4) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
+__global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof) {
     __shared__ int next_frame;
     for (;;) {
