@@ -66,6 +66,7 @@ typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define NOUNROLL _Pragma("unroll 1")
 #endif
+typedef u32 __attribute__((may_alias)) u32a;      // a dword view of LDS data that is also accessed as bytes / 16-bit tokens
 struct alignas(16) U4 { u32 x, y, z, w; };
 // Global-memory accessors.  Pointers that come out of structs are generic ("flat") to the compiler, and FLAT
 // instructions count against lgkmcnt — every LDS wait would then also wait for a global round trip.
@@ -107,8 +108,10 @@ HD int ctz64(u64 v) { return __builtin_ctzll(v); }
 // 24-bit multiplies are full rate on the VALU; v_mul_lo_u32 is not.  Only used where both operands provably fit.
 #ifdef IMCVT_HOSTEMU
 HD int mul24(int a, int b) { return a * b; }
+HD int umul24(int a, int b) { return a * b; }
 #else
 HD int mul24(int a, int b) { return __mul24(a, b); }
+HD int umul24(int a, int b) { return (int)__umul24((u32)a, (u32)b); }      // both operands in [0, 2^24)
 #endif
 HD int iabs(int v) { return v < 0 ? -v : v; }
 HD int imin(int a, int b) { return a < b ? a : b; }
@@ -192,8 +195,10 @@ struct alignas(16) WaveMem {
     FinState fin[NMODE];         // coder state each trial ended in
     i32 pu_mode[4], pu_sse[4], pu_cnt[4];   // NxN bookkeeping (PU wave)
     i32 nxn_cost;
+    alignas(16) u16 pend[NMODE + 1][8];     // the partial last 8-token block of each candidate's stream (rest: idle tokens)
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
         struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                   // one pipeline pass
+        u32 raw[1792];                                                                                // per-lane token staging (4x4 blocks, CU headers): lane l at raw + 33 l
         struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
     } u;
@@ -305,7 +310,7 @@ HD void sink_put(Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), 
 HD int sink_room(Sink &, int) { return 1; }
 struct RingSink { u8 *ring; u8 *gbuf; int c0, fl, ovf; };   // byte i lives at local index j = i - c0: ring[j % RING_BYTES] until flushed, then gbuf[j]; fl = bytes flushed (multiple of 16)
 HD void ring_flush16(RingSink &s) {      // the ring is only 4-byte aligned (odd dword stride between lanes)
-    const u32 *r = (const u32 *)(s.ring + (s.fl & (RING_BYTES - 1)));
+    const u32a *r = (const u32a *)(s.ring + (s.fl & (RING_BYTES - 1)));
     U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
     g_st128(s.gbuf + s.fl, b); s.fl += 16;
 }
@@ -610,7 +615,7 @@ HD void mac_MX(int acc[4][4], const i8 *M, const i16 *X, int row0, int col0) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
-        for (int r = 0; r < 4; r++) mw[r] = *(const u32 *)(M + (row0 + r) * N + k0);
+        for (int r = 0; r < 4; r++) mw[r] = *(const u32a *)(M + (row0 + r) * N + k0);
         for (int kk = 0; kk < 4; kk++) {
             const uint2 xw = *(const uint2 *)(X + (k0 + kk) * N + col0);
             const int x0 = lo16(xw.x), x1 = hi16(xw.x), x2 = lo16(xw.y), x3 = hi16(xw.y);
@@ -627,7 +632,7 @@ HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
-        for (int c = 0; c < 4; c++) mw[c] = *(const u32 *)(M + (col0 + c) * N + k0);
+        for (int c = 0; c < 4; c++) mw[c] = *(const u32a *)(M + (col0 + c) * N + k0);
         for (int r = 0; r < 4; r++) {
             const int4 y = *(const int4 *)(Y + (row0 + r) * N + k0);
             for (int c = 0; c < 4; c++)
@@ -641,7 +646,7 @@ HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *M, int row0, int col0) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
-        for (int c = 0; c < 4; c++) mw[c] = *(const u32 *)(M + (col0 + c) * N + k0);
+        for (int c = 0; c < 4; c++) mw[c] = *(const u32a *)(M + (col0 + c) * N + k0);
         for (int r = 0; r < 4; r++) {
             const uint2 yw = *(const uint2 *)(Y + (row0 + r) * N + k0);
             const int y0 = lo16(yw.x), y1 = hi16(yw.x), y2 = lo16(yw.y), y3 = hi16(yw.y);
@@ -658,6 +663,9 @@ HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q
 
 // Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594).  in: acc = forward-transform sums before the
 // final shift; out: acc = signed levels.  Returns non-zero when the group keeps any level after the weak-group test.
+// RD cost inside RDOQ: dist <= (2^31-1) >> 7 and rate <= 92000 + (32 << 15) (levels are 16-bit), so with the weights of
+// :178-181 neither product nor their sum can reach the saturation branches of :182-184 — the cost is the plain sum.
+HD int rd_cost_q(const RdW &w, int dist, int rate) { return umul24(w.wd, dist) + umul24(w.wb, rate); }
 template <int S>
 HD int rdoq_group(int acc[4][4], const QConst &Q) {
     constexpr int b1 = S + 8, dsh = 8 - S;
@@ -670,14 +678,14 @@ HD int rdoq_group(int acc[4][4], const QConst &Q) {
         if (l0 > 0) {                                   // level 0 alone needs no pricing
             // candidates l0, l0-1, l0-2 (>= 0), the larger level winning ties (:570-578)
             const int e0 = iabs(d - (l0 << Q.sh)) >> dsh;
-            const int c0 = rd_cost(Q.rw, ((e0 < 46340) ? e0 * e0 : I32MAX) >> 7, level_rate(l0));   // e*e needs 32 bits
+            const int c0 = rd_cost_q(Q.rw, ((e0 < 46340) ? e0 * e0 : I32MAX) >> 7, level_rate(l0));   // e*e needs 32 bits
             const int e1 = iabs(d - ((l0 - 1) << Q.sh)) >> dsh;
-            const int c1 = rd_cost(Q.rw, ((e1 < 46340) ? e1 * e1 : I32MAX) >> 7, level_rate(l0 - 1));
+            const int c1 = rd_cost_q(Q.rw, ((e1 < 46340) ? e1 * e1 : I32MAX) >> 7, level_rate(l0 - 1));
             int best = c0; pick = l0;
             if (c1 < best) { best = c1; pick = l0 - 1; }
             if (l0 > 1) {
                 const int e2 = iabs(d - ((l0 - 2) << Q.sh)) >> dsh;
-                const int c2 = rd_cost(Q.rw, ((e2 < 46340) ? e2 * e2 : I32MAX) >> 7, level_rate(l0 - 2));
+                const int c2 = rd_cost_q(Q.rw, ((e2 < 46340) ? e2 * e2 : I32MAX) >> 7, level_rate(l0 - 2));
                 if (c2 < best) { best = c2; pick = l0 - 2; }
             }
         }
@@ -705,8 +713,20 @@ HD void fill_border_ref(BorderRef &br, const WaveMem &W, int per_mode, int c) {
 // group) while the arithmetic coding itself — the only truly serial part — becomes a tight loop over a
 // linear stream (stream_run below), one lane per candidate.
 // ---------------------------------------------------------------------------------------------------
-struct TokW { u16 *p; int n; int wr; };       // wr == 0: count only
-HD void tk_put(TokW &w, int t) { if (w.wr) g_st16((i16 *)(w.p + w.n), t); w.n++; }
+// Where a writer's tokens go: token k lands in tb[pos + k] (LDS) when 0 <= pos + k < cap, else in the dump slot tb[cap].
+// Tokens are staged in LDS and leave for global memory as whole 16-byte blocks (8 tokens), never as scattered 2-byte stores.
+#define TOK_IDLE 0x8000u
+struct TokOut { u16 *tb; int pos; int cap; int glob; };   // glob: tb is the stream in global memory, written in place (no window, no dump slot)
+HD void to_put(const TokOut &o, int k, int tok) {
+    if (o.glob) { g_st16((i16 *)(o.tb + (o.pos + k)), tok); return; }
+    const u32 i = (u32)(o.pos + k); o.tb[i < (u32)o.cap ? i : (u32)o.cap] = (u16)tok;
+}
+HD void to_put_if(const TokOut &o, int k, int tok, int pred) {
+    if (o.glob) { if (pred) g_st16((i16 *)(o.tb + (o.pos + k)), tok); return; }
+    const u32 i = pred ? (u32)(o.pos + k) : 0xFFFFFFFFu; o.tb[i < (u32)o.cap ? i : (u32)o.cap] = (u16)tok;
+}
+struct TokW { TokOut o; int n; int wr; };       // wr == 0: count only
+HD void tk_put(TokW &w, int t) { if (w.wr) to_put(w.o, w.n, t); w.n++; }
 HD void tk_bin(TokW &w, int ci, int bin) { tk_put(w, (ci << 1) | bin); }
 HD void tk_chunk(TokW &w, int v, int n) { tk_put(w, 0x8000 | (n << 8) | v); }
 HD void tk_bypass(TokW &w, int v, int len) {                                                // :898-910
@@ -757,7 +777,6 @@ HD void tk_cu_header(TokW &w, const CuHdr &J) {
     if (J.shape != 2) tk_bin(w, CX_SPLIT_TU + (J.N == 32 ? 0 : J.N == 16 ? 1 : 2), J.shape == 1);
     tk_bin(w, CX_CBF_CHROMA, 0); tk_bin(w, CX_CBF_CHROMA, 0);
 }
-
 HD void tk_last_pos(TokW &w, int s, int st, int y, int x) {                                 // :1045-1086
     const int base = (s == 0) ? 0 : (s == 1) ? 3 : (s == 2) ? 6 : 10, shf = (s == 0) ? 0 : 1;
     const int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;
@@ -773,26 +792,17 @@ HD void tk_last_pos(TokW &w, int s, int st, int y, int x) {                     
     if (gy > 3) { const int nb_ = (gy - 2) >> 1, mn = (2 + (gy & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) tk_bypass(w, ((ty - mn) >> i) & 1, 1); }
 }
 
-HD void tk_remaining(TokW &w, int v, int k) {                                              // :1153-1168
-    if (v < (3 << k)) {                                  // prefix of <=3 bins, suffix of k<=4 bins: one chunk each
-        const int p = v >> k;
-        tk_chunk(w, (1 << (p + 1)) - 2, p + 1);
-        if (k) tk_chunk(w, v & ((1 << k) - 1), k);
-    } else {
-        int n = k; v -= 3 << k;
-        for (; v >= (1 << n); n++) v -= 1 << n;
-        const int t = 4 + n - k;
-        tk_bypass(w, (1 << t) - 2, t); tk_bypass(w, v, n);
-    }
-}
-
 // Tokens of one coefficient group (the body of the group loop of :1172-1268), as straight-line code over the group's
-// 16 levels held in registers in scan order: every potential token is a predicated store, the greater-1 context
-// and Rice parameter recurrences are select chains.  Only Exp-Golomb escapes (levels beyond 3 << rice) branch.
+// 16 levels held in registers in scan order: every potential token is one LDS store to a computed slot (the dump slot
+// when the token does not exist), the greater-1 context and Rice parameter recurrences are select chains.  Only
+// Exp-Golomb escapes (levels beyond 3 << rice) branch.
 //   cfg : bit1 DC group | bit2 group holds the last significant coefficient | bit3 greater-1 context set carry (previous
 //         coded group ended with c1 == 0) | bits4-5 neighbour pattern (below << 1 | right) | bits6-7 scan type
 //         | bits8-9 log2(TU size) - 2
-// WR = false only counts.  Returns the token count | (this group ends with c1 == 0) << 16.
+//   WR   : false only counts.
+//   PRIV : the writer owns tb beyond its current position (lane-private staging) -> a token that does not exist may be
+//          written in place and overwritten by the next one; otherwise (shared pass buffer) it goes to the dump slot.
+// Part A: coded_sub_block_flag, significance flags, greater-1 / greater-2 flags, signs.  Part B: remaining levels.
 enum { TG_DC = 2, TG_LAST = 4, TG_C1Z = 8, TG_PAT = 4, TG_ST = 6, TG_S = 8 };
 struct Lv16 { int v[16]; };
 #ifdef IMCVT_HOSTEMU
@@ -802,20 +812,22 @@ struct Lv16 { int v[16]; };
 #endif
 HD int tk_chunk_word(int v, int n) { return 0x8000 | (n << 8) | v; }
 // coeff_abs_level_remaining beyond the prefix-3 range: EG(k+1) escape (:1160-1167), out of line
-HDN int tok_escape(u16 *p, int wr, int v, int k) {
-    TokW w; w.p = p; w.n = 0; w.wr = wr;
+HDN int tok_escape(TokOut o, int k0, int wr, int v, int k) {
+    TokW w; w.o = o; w.n = k0; w.wr = wr;
     int n = k; v -= 3 << k;
     for (; v >= (1 << n); n++) v -= 1 << n;
     const int t = 4 + n - k;
     tk_bypass(w, (1 << t) - 2, t); tk_bypass(w, v, n);
-    return w.n;
+    return w.n - k0;
 }
-template <bool WR>
-HD int tokg(u16 *p, const Lv16 &L, u32 nzm, int cfg) {
+struct TgB { int esc, base2, rice, j; };       // state handed from part A to part B
+#define TK_EMIT(pred, tok) do { const int p_ = (pred); if (WR) { if (PRIV) to_put(o, cnt, (tok)); else to_put_if(o, cnt, (tok), p_); } cnt += p_; } while (0)
+// returns the token count so far | (this group ends with c1 == 0) << 16
+template <bool WR, bool PRIV>
+HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B) {
     const Tables &T = SM.T;
     const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3, s = (cfg >> TG_S) & 3;
-    int cnt = 0;
-#define TK_EMIT(pred, tok) do { const int p_ = (pred); if (WR) { if (p_) g_st16((i16 *)(p + cnt), (tok)); } cnt += p_; } while (0)
+    B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0;
     TK_EMIT(!dcg && !has_last, ((CX_CSBF + (pat != 0)) << 1) | (nzm != 0));
     if (nzm == 0 && !dcg) return cnt;
     {   // significance flags, scan positions nstart..0.  Context of position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
@@ -854,27 +866,75 @@ HD int tokg(u16 *p, const Lv16 &L, u32 nzm, int cfg) {
         TK_EMIT(1, two ? tk_chunk_word((signs >> lo) & 0xFF, 8) : tk_chunk_word(signs, nnz));
         TK_EMIT(two, tk_chunk_word(signs & ((1 << lo) - 1), lo));
     }
-    if (esc) {                                         // remaining absolute levels
-        int base2 = 3, rice = 0, j = 0;
+    B.esc = esc;
+    return cnt | ((g2 >= 0) ? 1 << 16 : 0);
+}
+// remaining absolute levels of scan positions hi..lo (:1243-1262); returns the token count so far
+template <bool WR, bool PRIV, int HI, int LO>
+HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
+    if (B.esc) {
+        int base2 = B.base2, rice = B.rice, j = B.j;
         UNROLL_FULL
-        for (int n = 15; n >= 0; n--) {
+        for (int n = HI; n >= LO; n--) {
             const int mg = iabs(L.v[n]), isnz = mg != 0;
             const int r = mg - (j < 8 ? base2 : 1);
             const int doit = isnz & (r >= 0), small = r < (3 << rice);
             const int pp = r >> rice;                  // prefix of <=3 bins, suffix of rice<=4 bins: one chunk each
             TK_EMIT(doit & small, tk_chunk_word((2 << pp) - 2, pp + 1));
             TK_EMIT(doit & small & (rice != 0), tk_chunk_word(r & ((1 << rice) - 1), rice));
-            if (doit & !small) cnt += tok_escape(p + cnt, WR, r, rice);
+            if (doit & !small) cnt += tok_escape(o, cnt, WR, r, rice);
             rice = (doit & (mg > (3 << rice))) ? imin(rice + 1, 4) : rice;
             base2 = (isnz & (mg >= 2)) ? 2 : base2;
             j += isnz;
         }
+        B.base2 = base2; B.rice = rice; B.j = j;
     }
-#undef TK_EMIT
-    return cnt | ((g2 >= 0) ? 1 << 16 : 0);
+    return cnt;
 }
-HDN int tok_count(Lv16 L, u32 nzm, int cfg) { return tokg<false>((u16 *)0, L, nzm, cfg); }
-HDN int tok_write(u16 *p, Lv16 L, u32 nzm, int cfg) { return tokg<true>(p, L, nzm, cfg); }
+#undef TK_EMIT
+// one group into the shared pass buffer / count only: tokens k0.. of the writer; returns the count | c1-zero flag << 16
+HDN int tok_count(Lv16 L, u32 nzm, int cfg) {
+    TokOut o; o.tb = (u16 *)0; o.pos = 0; o.cap = 0; o.glob = 0; TgB B;
+    const int ra = tokg_a<false, false>(o, 0, L, nzm, cfg, B);
+    return tokg_b<false, false, 15, 0>(o, ra & 0xFFFF, L, B) | (ra & ~0xFFFF);
+}
+HDN int tok_write(u16 *p, int k0, Lv16 L, u32 nzm, int cfg) {      // straight into the candidate's stream in global memory
+    TokOut o; o.tb = p; o.pos = 0; o.cap = 0; o.glob = 1; TgB B;
+    const int ra = tokg_a<true, false>(o, k0, L, nzm, cfg, B);
+    return tokg_b<true, false, 15, 0>(o, ra & 0xFFFF, L, B) | (ra & ~0xFFFF);
+}
+
+// ---- lane-private token streams (CU headers, 4x4 TUs): the lane stages up to LCAP tokens in its own LDS row and hands
+// whole blocks to its candidate's stream in global memory.
+#define LCAP 64
+#define LSTRIDE 33          // dwords per lane row: 64 tokens + the dump slot; odd -> rows start in different banks
+struct LaneStream { u16 *buf; u16 *g; int blk0; };      // buf[0] is token 8 * blk0 of the stream g
+HD u16 *lane_row(WaveMem &W, int lane) { return (u16 *)(W.u.raw + lane * LSTRIDE); }
+HD void blk_copy(u32a *d, const u32a *s_) { d[0] = s_[0]; d[1] = s_[1]; d[2] = s_[2]; d[3] = s_[3]; }
+HD void blk_idle(u32a *d) { const u32 w2 = TOK_IDLE | TOK_IDLE << 16; d[0] = w2; d[1] = w2; d[2] = w2; d[3] = w2; }
+HD TokW ls_begin(LaneStream &s, WaveMem &W, int c, u16 *buf, u16 *g) {
+    const int n0 = W.tokn[c];
+    s.buf = buf; s.g = g; s.blk0 = n0 >> 3;
+    blk_copy((u32a *)buf, (const u32a *)W.pend[c]);
+    TokW w; w.o.tb = buf; w.o.pos = 0; w.o.cap = LCAP; w.o.glob = 0; w.n = n0 & 7; w.wr = 1;
+    return w;
+}
+HD void ls_out(const LaneStream &s, int nb) {
+    NOUNROLL
+    for (int b = 0; b < nb; b++) { const u32a *r = (const u32a *)(s.buf + 8 * b); U4 v; v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3]; g_st128(s.g + 8 * (s.blk0 + b), v); }
+}
+HD void ls_flush(LaneStream &s, TokW &w) {              // full blocks leave, the partial one moves to the front
+    const int nf = w.n >> 3;
+    ls_out(s, nf);
+    if (nf) blk_copy((u32a *)s.buf, (const u32a *)(s.buf + 8 * nf));
+    s.blk0 += nf; w.n &= 7;
+}
+HD void ls_end(LaneStream &s, TokW &w, WaveMem &W, int c) {
+    for (int i = 0; i < 8; i++) to_put(w.o, w.n + i, (int)TOK_IDLE);       // idle tokens up to (and beyond) the block boundary; needs w.n + 7 < LCAP
+    ls_out(s, (w.n + 7) >> 3);
+    blk_copy((u32a *)W.pend[c], (const u32a *)(s.buf + 8 * (w.n >> 3)));     // the partial block, or eight idle tokens
+    W.tokn[c] = 8 * s.blk0 + w.n;
+}
 
 // the 16 levels of a 4x4 group (raster x[r][c]) in scan order `st`, and their non-zero mask
 HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag) {
@@ -903,7 +963,7 @@ HDN void p1_run_4(int wave, const P1Args P) {
             int pr[4][4], x[4][4], t[4][4];
             pred_block4(T, br, 4, 2, mode, 0, 0, pr);
             for (int yi = 0; yi < 4; yi++) {
-                const u32 ow = *(const u32 *)&SM.org[P.y0 + yi][P.x0];
+                const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
                 for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
             }
             // forward DST (:391-396): t = (D*x + 1) >> 1 ; coef sums = t*D^T + 128 (shift by 8 inside rdoq_group)
@@ -926,14 +986,24 @@ HDN void p1_run_4(int wave, const P1Args P) {
             if (P.tok) {                                    // the TU's tokens: cbf_luma, last position, the one group
                 Lv16 L; u32 nzm = 0;
                 if (any) nzm = scan_levels(L, x, st, 0);
-                TokW w; w.p = P.tok + (size_t)c * TOK_CAP; w.n = W.tokn[c]; w.wr = 1;
+                LaneStream ls;
+                TokW w = ls_begin(ls, W, c, lane_row(W, l), P.tok + (size_t)c * TOK_CAP);
                 tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
                 if (nzm != 0) {
                     const int in = T.incg[st][hibit(nzm)];
                     tk_last_pos(w, 0, st, in >> 2, in & 3);
-                    w.n += tok_write(w.p + w.n, L, nzm, TG_DC | TG_LAST | st << TG_ST) & 0xFFFF;
+                    ls_flush(ls, w);                        // <= 7 tokens stay staged: each part below then fits the row
+                    TgB B;
+                    w.n = tokg_a<true, true>(w.o, w.n, L, nzm, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
+                    if (B.esc) {
+                        ls_flush(ls, w);
+                        w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B);
+                        ls_flush(ls, w);
+                        w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B);
+                    }
                 } else if (P.shape == 3) tk_last_pos(w, 0, st, 0, 0);   // PU pricing codes the residual syntax of an all-zero block (:1515)
-                W.tokn[c] = w.n; W.tnz[c] = (nzm != 0);
+                ls_end(ls, w, W, c);
+                W.tnz[c] = (nzm != 0);
             }
             int part = 0;
             if (any) {
@@ -957,7 +1027,7 @@ HDN void p1_run_4(int wave, const P1Args P) {
                 for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) x[i][j] = 0;   // all-zero levels reconstruct to the prediction
             }
             for (int yi = 0; yi < 4; yi++) {
-                const u32 ow = *(const u32 *)&SM.org[P.y0 + yi][P.x0];
+                const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
                 for (int xi = 0; xi < 4; xi++) {
                     const int rc = clip3(x[yi][xi] + pr[yi][xi], 0, 255);
                     const int d = (int)((ow >> (8 * xi)) & 255) - rc;
@@ -1012,8 +1082,8 @@ HDN void p1_run_t(int wave, const P1Args P) {
             pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
             for (int yi = 0; yi < 4; yi++) {
                 const int y = by * 4 + yi;
-                const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
-                *(u32 *)(pp + y * N + bx * 4) = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
+                const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                *(u32a *)(pp + y * N + bx * 4) = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
                 uint2 rw_;
                 rw_.x = (u32)(((int)(ow & 255) - pr[yi][0]) & 0xFFFF) | (u32)((int)((ow >> 8) & 255) - pr[yi][1]) << 16;
                 rw_.y = (u32)(((int)((ow >> 16) & 255) - pr[yi][2]) & 0xFFFF) | (u32)((int)(ow >> 24) - pr[yi][3]) << 16;
@@ -1045,18 +1115,10 @@ HDN void p1_run_t(int wave, const P1Args P) {
             Lv16 L; u32 nzm = 0;
             if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
             const u64 cm = P.tok ? wave_ballot(any) : 0;
-            if (live) {
-                i16 *dp = W.u.p1.res + sl * NN;
-                if (any) {
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        for (int cc = 0; cc < 4; cc++) acc[r4][cc] = clip16(acc[r4][cc] * Q.dq);
-                        uint2 o; o.x = (u32)(acc[r4][0] & 0xFFFF) | (u32)acc[r4][1] << 16; o.y = (u32)(acc[r4][2] & 0xFFFF) | (u32)acc[r4][3] << 16;
-                        *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = o;
-                    }
-                } else {
-                    uint2 z; z.x = 0; z.y = 0;
-                    for (int r4 = 0; r4 < 4; r4++) *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = z;
-                }
+            uint2 dq[4];                                    // dequantised levels, packed; stored once the token buffer (which lives in res/tmp) is done with
+            for (int r4 = 0; r4 < 4; r4++) {
+                for (int cc = 0; cc < 4; cc++) acc[r4][cc] = any ? clip16(acc[r4][cc] * Q.dq) : 0;
+                dq[r4].x = (u32)(acc[r4][0] & 0xFFFF) | (u32)acc[r4][1] << 16; dq[r4].y = (u32)(acc[r4][2] & 0xFFFF) | (u32)acc[r4][3] << 16;
             }
             if (P.tok) {
                 const int sb = sl * lpc;
@@ -1079,7 +1141,7 @@ HDN void p1_run_t(int wave, const P1Args P) {
                 if (talk) {
                     if (seg == 0) cnt = 1;
                     else {
-                        TokW w; w.p = base; w.n = 0; w.wr = 0;
+                        TokW w; w.o.tb = (u16 *)0; w.o.pos = 0; w.o.cap = 0; w.o.glob = 0; w.n = 0; w.wr = 0;
                         if (has_last) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
                         const int rr = tok_count(L, nzm, cfg);
                         cnt = w.n + (rr & 0xFFFF); big = rr >> 16;
@@ -1088,22 +1150,31 @@ HDN void p1_run_t(int wave, const P1Args P) {
                 prof_add(PF_T_SETUP, ptk0);
                 const long long ptk1 = prof_now();
                 const u64 bmask = wave_ballot(big);
+                if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
                 int total;
                 const int off = seg_suffix_sum(cnt, l, lpc, &total);
                 prof_add(PF_T_GEN, ptk1);
                 const long long ptk2 = prof_now();
-                // pass 2: write at the group's place in the candidate's stream
+                // pass 2: write at the group's place in the candidate's stream (global memory; the lines of a run are filled
+                // by the wave within this pass).  The DC lane, last in coding order, pads the final block with idle tokens.
                 if (talk) {
-                    TokW w; w.p = base + off; w.n = 0; w.wr = 1;
+                    TokW w; w.o.tb = base + off; w.o.pos = 0; w.o.cap = 0; w.o.glob = 1; w.n = 0; w.wr = 1;
                     if (seg == 0) tk_bin(w, cbf_ctx, 0);
                     else {
                         if (has_last) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
-                        if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
-                        tok_write(w.p + w.n, L, nzm, cfg);
+                        w.n = tok_write(w.o.tb, w.n, L, nzm, cfg) & 0xFFFF;
                     }
-                    if (r == 0) { W.tokn[c] = tokn0 + total; W.tnz[c] = (seg != 0); }
+                    if (r == 0) {
+                        const int e7 = (tokn0 + total) & 7;
+                        for (int i = 0; i < 7; i++) to_put_if(w.o, w.n + i, (int)TOK_IDLE, e7 != 0 && e7 + i < 8);
+                        W.tokn[c] = tokn0 + total; W.tnz[c] = (seg != 0);
+                    }
                 }
                 prof_add(PF_T_HDR, ptk2);
+            }
+            if (live) {
+                i16 *dp = W.u.p1.res + sl * NN;
+                for (int r4 = 0; r4 < 4; r4++) *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = dq[r4];
             }
         }
         wave_sync_lds();
@@ -1130,8 +1201,8 @@ HDN void p1_run_t(int wave, const P1Args P) {
             int part = 0;
             for (int r4 = 0; r4 < 4; r4++) {
                 const int y = by * 4 + r4;
-                const u32 pw = *(const u32 *)(pp + y * N + bx * 4);
-                const u32 ow = *(const u32 *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                const u32 pw = *(const u32a *)(pp + y * N + bx * 4);
+                const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
                 for (int cc = 0; cc < 4; cc++) {
                     const int x = bx * 4 + cc;
                     const int rc = clip3(clip16(acc[r4][cc] >> 12) + (int)((pw >> (8 * cc)) & 255), 0, 255);
@@ -1197,7 +1268,6 @@ HD void code_token(Arith &a, u8 *cx, S &sink, u32 tok) {
 // the carry / 0xFF-run / emulation-prevention logic of :863-878,:820-831 runs once per queued lead after the block
 // (lead_step below) — about one byte per eight tokens, so that logic costs an eighth of what it did per token.
 #define CX_PAD (CTX_STRIDE - 1)
-#define TOK_IDLE 0x8000u
 HD void code_token_q(Arith &a, u8 *cx, u16 *lq, int &qn, u32 tok) {
     const int byp = tok >= 0x8000u;
     const u32 cim = tok >> 1;
@@ -1255,10 +1325,9 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
         if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / lm rows belong to lane 0
             ring_sync(sink, a.cnt);                         // full 16-byte runs of output leave the ring
             int qn = 0;
-            const int rem = n - k0;
             UNROLL_FULL
-            for (int j = 0; j < 8; j++)                     // no VMEM instruction in here
-                code_token_q(a, cx, lm->lq, qn, (j < rem) ? tok_of(cur, j) : TOK_IDLE);
+            for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
+                code_token_q(a, cx, lm->lq, qn, tok_of(cur, j));
             NOUNROLL
             for (int i = 0; WAVE_ANY(i < qn); i++)          // the bytes this block pushed out of `low`
                 if (i < qn) lead_step(a, sink, (int)lm->lq[i]);
@@ -1289,10 +1358,10 @@ HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, LaneMem *lm, u8 *gbuf, con
 #ifdef IMCVT_TOKSTAT
     if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
 #endif
-    if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32 *)(cx + i) = *(const u32 *)(cx_src + i);
+    if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i);
     const int ovf = stream_run(a, cx, lm, gbuf, p, on ? n : 0);
     if (WAVE_ANY(ovf)) {                                    // practically never: redo the overflowed lanes without the ring
-        if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32 *)(cx + i) = *(const u32 *)(cx_src + i); }
+        if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i); }
         stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
     }
 }

@@ -42,13 +42,15 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
     const int ml = nb_mode(uy, ux - 1), ma = nb_mode(uy - 1, ux);
     LANES(l) {
         if (l < NMODE) {                                // every candidate's stream opens with its coding_unit header
-            W.sse[l] = 0;
+            W.sse[l] = 0; W.tokn[l] = 0;
+            blk_idle((u32a *)W.pend[l]);
             CuHdr J;
             J.N = N; J.shape = shape; J.ctx_split = (N >= 16) ? CX_SPLIT_CU + big_l + big_a : -1;
             J.mode[0] = l; J.ml[0] = ml; J.ma[0] = ma;
-            TokW w; w.p = tok + (size_t)l * TOK_CAP; w.n = 0; w.wr = 1;
+            LaneStream ls;
+            TokW w = ls_begin(ls, W, l, lane_row(W, l), tok + (size_t)l * TOK_CAP);
             tk_cu_header(w, J);
-            W.tokn[l] = w.n;
+            ls_end(ls, w, W, l);
         }
     }
     wave_sync_lds();
@@ -104,7 +106,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
     for (int k = 0; k < 4; k++) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
-        LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.tokn[l] = 7; } }
+        LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.tokn[l] = 7; blk_idle((u32a *)W.pend[l]); } }
         wave_sync_lds();
         long long pt = prof_now();
         border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
@@ -151,9 +153,12 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
             J.ml[1] = J.mode[0];                  J.ma[1] = nb_mode(uy - 1, ux + 1);
             J.ml[2] = nb_mode(uy + 1, ux - 1); J.ma[2] = J.mode[0];
             J.ml[3] = J.mode[2];                  J.ma[3] = J.mode[1];
-            TokW w; w.p = nxn; w.n = 0; w.wr = 1;
+            W.tokn[NMODE] = 0;
+            blk_idle((u32a *)W.pend[NMODE]);
+            LaneStream ls;
+            TokW w = ls_begin(ls, W, NMODE, lane_row(W, 0), nxn);
             tk_cu_header(w, J);
-            W.tokn[NMODE] = w.n;
+            ls_end(ls, w, W, NMODE);
         }
     }
     wave_sync();                                        // header and kept tokens are in memory
@@ -165,6 +170,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
             for (int i = l; i < cnt; i += 64) g_st16((i16 *)(nxn + pos + i), g_ld16((const i16 *)(src + i)));
             pos += cnt;
         }
+        if (l < 8 && ((pos + l) >> 3) == (pos >> 3) && (pos & 7) != 0) g_st16((i16 *)(nxn + pos + l), (int)TOK_IDLE);   // idle tokens up to the block boundary
         wave_sync();
         const int on = l == 0;
         Arith a = SM.entry_a[2];
