@@ -60,7 +60,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 4 frames; just under the 4 x 256 resident-frame capacity of one MI355X)")
     ap.add_argument("--qpd6", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,11 +135,12 @@ def main():
         algo_bytes = F * (W * H + hp * wp) + int(lens.sum())               # per launch on one GPU
         achieved = algo_bytes / k_avg / 1e9
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # written by tools/pmc_traffic.py from rocprofv3 --pmc passes (calibrated)
         if os.path.exists(tp):
             t = json.load(open(tp))
-            if t.get("qpd6") == args.qpd6 and t.get("frames"):       # measured per launch of t["frames"] frames; frames are independent
-                traffic = int(t["hbm_bytes_per_launch"] * F / t["frames"])
+            if t.get("qpd6") == args.qpd6 and t.get("hbm_bytes_per_launch") and t.get("ctus"):
+                # measured per launch of t["ctus"] CTUs of the same content class; CTUs are the unit of work (frames are independent)
+                traffic = int(t["hbm_bytes_per_launch"] * (F * (hp // 32) * (wp // 32)) / t["ctus"])
         macs = 12320 * hp * wp * F                                          # transform MACs per launch
         line = {
             "metric": "Mpixels/s HEVC intra encode (gray8), bit-exact vs CPU", "value": round(value, 3), "unit": "Mpixels/s",

@@ -893,12 +893,12 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
 }
 #undef TK_EMIT
 // one group into the shared pass buffer / count only: tokens k0.. of the writer; returns the count | c1-zero flag << 16
-HDN int tok_count(Lv16 L, u32 nzm, int cfg) {
+HD int tok_count(const Lv16 &L, u32 nzm, int cfg) {
     TokOut o; o.tb = (u16 *)0; o.pos = 0; o.cap = 0; o.glob = 0; TgB B;
     const int ra = tokg_a<false, false>(o, 0, L, nzm, cfg, B);
     return tokg_b<false, false, 15, 0>(o, ra & 0xFFFF, L, B) | (ra & ~0xFFFF);
 }
-HDN int tok_write(u16 *p, int k0, Lv16 L, u32 nzm, int cfg) {      // straight into the candidate's stream in global memory
+HD int tok_write(u16 *p, int k0, const Lv16 &L, u32 nzm, int cfg) {      // straight into the candidate's stream in global memory
     TokOut o; o.tb = p; o.pos = 0; o.cap = 0; o.glob = 1; TgB B;
     const int ra = tokg_a<true, false>(o, k0, L, nzm, cfg, B);
     return tokg_b<true, false, 15, 0>(o, ra & 0xFFFF, L, B) | (ra & ~0xFFFF);
@@ -950,7 +950,7 @@ HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag) {
 
 // ---- 4x4 blocks: one lane owns the whole block, so the pipeline runs entirely in registers (DST constants are
 // immediates, no LDS intermediates, no wave syncs between the stages) and the lane writes the TU's tokens itself.
-HDN void p1_run_4(int wave, const P1Args P) {
+HD void p1_run_4(int wave, const P1Args &P) {
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
     const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
@@ -1056,7 +1056,7 @@ HD int seg_suffix_sum(int v, int l, int lpc, int *total) {
 }
 
 template <int LG>
-HDN void p1_run_t(int wave, const P1Args P) {
+HD void p1_run_t(int wave, const P1Args &P) {
     constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
@@ -1228,6 +1228,7 @@ HD void p1_run(int wave, const P1Args &P) {
     else if (P.N == 8) p1_run_t<3>(wave, P);
     else p1_run_4(wave, P);
 }
+HDN void p1_run_cold(int wave, const P1Args P) { p1_run(wave, P); }     // the winner's reconstruction: once per CU, kept out of line
 
 // ---------------------------------------------------------------------------------------------------
 // Stream coding.  One lane codes one candidate's token stream with its own arithmetic coder and context copy;

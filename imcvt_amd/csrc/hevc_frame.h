@@ -57,19 +57,19 @@ HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int a
     P1Args P;
     P.q = q; P.only_mode = -1; P.shape = shape; P.tok = tok;
     long long pt = prof_now();
-    if (shape == 0) {
-        border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
-        P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
-        p1_run(wave, P);
-    } else {
-        for (int k = 0; k < 4; k++) {
+    const int ntu = (shape == 0) ? 1 : 4;
+    for (int k = 0; k < ntu; k++) {
+        if (shape == 0) {
+            border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
+            P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
+        } else {
             const Avail ca = child_avail(av, k);
             const int yk = y0 + (k >> 1) * h, xk = x0 + (k & 1) * h;
             if (k == 0) border_from_tile(wave, h, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
             else border_tu_split(wave, N, y0, x0, k, av.l, av.bl, av.a, av.ar);
             P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
-            p1_run(wave, P);
         }
+        p1_run(wave, P);
     }
     prof_add(shape == 0 ? (N == 32 ? PF_P1_32 : N == 16 ? PF_P1_16 : PF_P1_8) : (N == 32 ? PF_P1_16 : N == 16 ? PF_P1_8 : PF_P1_4), pt);
     wave_sync();                                        // the tokens are in memory
@@ -242,14 +242,14 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
                     if (kind == 1) {
                         border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
                         P.N = N; P.y0 = y0; P.x0 = x0;
-                        p1_run(wave, P);
+                        p1_run_cold(wave, P);
                     } else {
                         const int h = N / 2;
                         for (int k = 0; k < 4; k++) {
                             const Avail ca = child_avail(av, k);
                             P.N = h; P.y0 = y0 + (k >> 1) * h; P.x0 = x0 + (k & 1) * h;
                             border_from_tile(wave, h, P.y0, P.x0, ca.l, ca.bl, ca.a, ca.ar);
-                            p1_run(wave, P);
+                            p1_run_cold(wave, P);
                         }
                     }
                 }

@@ -29,4 +29,5 @@ if f_scale and w_scale:
     out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
 if len(sys.argv) > 6:
     out["w"], out["h"] = int(sys.argv[5]), int(sys.argv[6])
+    out["ctus"] = out["frames"] * ((out["w"] + 31) // 32) * ((out["h"] + 31) // 32)
 print(json.dumps(out, indent=1))
