@@ -16,8 +16,39 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+JLS_OUT = os.path.join(CSRC, "libimcvt_jls.so")   # JPEG-LS (BASELINE config 5)
+JLS_DEPS = ["jls_hip.hip", "jls_core.h", os.path.join("..", "..", "include", "imcvt_jls.h")]
+
+
+def build_jls(force: bool = False) -> str:
+    if force or not os.path.exists(JLS_OUT) or any(os.path.getmtime(os.path.join(CSRC, d)) > os.path.getmtime(JLS_OUT) for d in JLS_DEPS):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                        os.path.join(CSRC, "jls_hip.hip"), "-o", JLS_OUT], check=True)
+    return JLS_OUT
+
+
+HOST = os.path.join(CSRC, "host")
+CLI = os.path.join(CSRC, "imcvt")                  # the drop-in converter binary (reference: src/main.c)
+PNM_SO = os.path.join(CSRC, "libimcvt_pnm.so")     # the PNM reader / writer alone, for the host-side tests
+
+
+def build_host(force: bool = False) -> str:
+    """Host glue of the drop-in binary: PNM I/O + CLI, linked against libimcvt_hevc.so (plain g++, no device code)."""
+    srcs = [os.path.join(HOST, "imcvt_cli.cpp"), os.path.join(HOST, "pnm_io.cpp")]
+    build_jls()
+    deps = srcs + [OUT, JLS_OUT, os.path.join(CSRC, "..", "..", "include", "imcvt_hevc.h")]
+    stale = lambda o: force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps)
+    if stale(PNM_SO):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", srcs[1], "-o", PNM_SO], check=True)
+    if stale(CLI):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-DIMCVT_WITH_JLS", *srcs, "-L" + CSRC, "-limcvt_hevc", "-limcvt_jls", "-Wl,-rpath,$ORIGIN", "-o", CLI], check=True)
+    return CLI
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
+        build_host()
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
@@ -25,6 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
+    build_host(force=True)
     return OUT
 
 

@@ -1,0 +1,171 @@
+// imcvt_cli.cpp — command-line converter with the reference's interface (src/main.c): same switch parsing
+// (:87-132), same per-file progress / error / summary lines (:135-140, :177, :216-221), same exit code (number of
+// failed files, :223; -1 with the usage text when no file is given, :156-159), same output-suffix dispatch (:189-204).
+//
+// What is MI355X-native here: the reference converts one file at a time (:162), and one H.265 frame keeps a single
+// compute unit busy, so before the reference's sequential loop is replayed this driver loads every input bound for
+// .h265 / .265 / .hevc and encodes them in ONE device batch (HEVCImageEncoderBatch, include/imcvt_hevc.h §2).  The
+// loop then runs in the reference's order and only writes the already encoded streams, so stdout, exit code and file
+// contents are those of the reference.
+//
+// Scope: inputs are PNM (P1-P6); outputs are PNM, H.265 and — when built with the JPEG-LS module —
+// .jls.  PNG / BMP / QOI are outside this build: such an input fails to open, such an output suffix is reported as
+// unsupported, through the reference's own error lines.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../../include/imcvt_hevc.h"
+
+extern "C" uint8_t *loadPNMImageFile(const char *, int *, uint32_t *, uint32_t *);
+extern "C" int writePNMImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t);
+#ifdef IMCVT_WITH_JLS
+extern "C" int writeJLSImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t, int);
+#endif
+
+static const int kMaxFiles = 999;              // src/main.c:84
+
+static void usage() {
+    fputs("ImCvt (MI355X build of the H.265 intra path)\n"
+          "usage:  imcvt [-switches] <in1> -o <out1> [<in2> -o <out2>] ...\n"
+          "  <in>  : .pnm / .pgm / .ppm / .pbm (P1..P6)\n"
+          "  <out> : .pnm .pgm .ppm | .h265 .265 .hevc (gray 8-bit, encoded on the GPU)"
+#ifdef IMCVT_WITH_JLS
+          " | .jls"
+#endif
+          "\n  switches: -f  overwrite existing outputs;  -0 .. -4  H.265 (qp-4)/6"
+#ifdef IMCVT_WITH_JLS
+          " / JPEG-LS NEAR"
+#endif
+          "\n\n", stdout);
+}
+
+static char lower(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
+static bool ends_with_nocase(const char *s, const char *suffix) {             // src/main.c:33-47
+    const size_t n = strlen(s), m = strlen(suffix);
+    if (m > n) return false;
+    for (size_t i = 0; i < m; i++) if (lower(s[n - m + i]) != lower(suffix[i])) return false;
+    return true;
+}
+// src with its extension replaced by `ext` (an extension is a '.' after the last path separator), :50-73
+static std::string with_extension(const char *src, const char *ext) {
+    std::string s(src);
+    size_t cut = s.size();
+    for (size_t i = s.size(); i-- > 0;) {
+        if (s[i] == '/' || s[i] == '\\') break;
+        if (s[i] == '.') { cut = i; break; }
+    }
+    return s.substr(0, cut) + "." + ext;
+}
+static bool exists(const char *name) { FILE *f = fopen(name, "rb"); if (f) fclose(f); return f != NULL; }
+static bool is_hevc_name(const char *n) { return ends_with_nocase(n, "h265") || ends_with_nocase(n, "265") || ends_with_nocase(n, "hevc"); }
+
+struct Job { const char *src = NULL; std::string dst; bool dst_given = false; };
+struct Encoded { bool tried = false, ok = false; std::vector<unsigned char> stream; int len = 0; bool rgb = false; };
+
+int main(int argc, char **argv) {
+    bool sw[128] = {false};
+    std::vector<Job> jobs;
+    bool next_is_dst = false;
+    for (int i = 1; i < argc; i++) {                                         // src/main.c:104-129
+        const char *a = argv[i];
+        if (a[0] == '-') {
+            for (a++; *a; a++) {
+                if ((unsigned char)*a < 128) sw[(unsigned char)*a] = true;
+                if (*a == 'o') next_is_dst = true;
+            }
+        } else if ((int)jobs.size() < kMaxFiles) {
+            if (next_is_dst) {
+                next_is_dst = false;
+                if (!jobs.empty()) { jobs.back().dst = a; jobs.back().dst_given = true; }
+            } else {
+                Job j; j.src = a; jobs.push_back(j);
+            }
+        }
+    }
+    const bool force = sw['F'] || sw['f'];
+    const int level = sw['4'] ? 4 : sw['3'] ? 3 : sw['2'] ? 2 : sw['1'] ? 1 : 0;   // H.265 (qp-4)/6 and JPEG-LS NEAR share it (:154)
+    if (jobs.empty()) { usage(); return -1; }
+    for (Job &j : jobs) if (!j.dst_given) j.dst = with_extension(j.src, "png");    // :171-175
+
+    // ---- all H.265-bound inputs in one device batch (no output, no messages: the loop below reports in order)
+    const int n = (int)jobs.size();
+    std::vector<Encoded> enc(n);
+    {
+        std::vector<int> idx, hs, ws, qs, lens;
+        std::vector<std::vector<unsigned char>> gray, rcon;
+        for (int i = 0; i < n; i++) {
+            if (!is_hevc_name(jobs[i].dst.c_str())) continue;
+            int rgb = 0; uint32_t h = 0, w = 0;
+            uint8_t *px = loadPNMImageFile(jobs[i].src, &rgb, &h, &w);
+            if (!px) continue;
+            std::vector<unsigned char> g((size_t)h * w);
+            for (size_t k = 0; k < g.size(); k++) g[k] = rgb ? px[3 * k + 1] : px[k];     // green channel of RGB, src/imageio_hevc.c:24-26
+            free(px);
+            enc[i].tried = true; enc[i].rgb = rgb != 0;
+            idx.push_back(i); hs.push_back((int)h); ws.push_back((int)w); qs.push_back(level);
+            gray.push_back(std::move(g));
+        }
+        const int m = (int)idx.size();
+        if (m > 0) {
+            std::vector<unsigned char *> outs(m), rcs(m); std::vector<const unsigned char *> ins(m);
+            rcon.resize(m); lens.assign(m, 0);
+            for (int k = 0; k < m; k++) {
+                enc[idx[k]].stream.resize((size_t)imcvt_hevc_stream_bound(hs[k], ws[k]));
+                rcon[k].resize((size_t)imcvt_hevc_padded(hs[k]) * imcvt_hevc_padded(ws[k]));
+                outs[k] = enc[idx[k]].stream.data(); rcs[k] = rcon[k].data(); ins[k] = gray[k].data();
+            }
+            const int rc = HEVCImageEncoderBatch(m, outs.data(), ins.data(), rcs.data(), hs.data(), ws.data(), qs.data(), lens.data());
+            for (int k = 0; k < m; k++) { enc[idx[k]].ok = rc == 0 && lens[k] > 0; enc[idx[k]].len = lens[k]; }
+        }
+    }
+
+    // ---- the reference's loop (:162-211)
+    int converted = 0;
+    for (int i = 0; i < n; i++) {
+        const char *src = jobs[i].src, *dst = jobs[i].dst.c_str();
+        printf("(%d/%d)  %s -> %s\n", i + 1, n, src, dst);
+        if (!exists(src)) { printf("   ***ERROR: %s not exist\n", src); continue; }
+        if (!force && exists(dst)) { printf("   ***ERROR: %s already exist\n", dst); continue; }
+        int rgb = 0; uint32_t h = 0, w = 0;
+        uint8_t *px = loadPNMImageFile(src, &rgb, &h, &w);
+        if (!px) { printf("   ***ERROR: open %s failed\n", src); continue; }
+        int failed;
+        if (ends_with_nocase(dst, "pnm") || ends_with_nocase(dst, "ppm") || ends_with_nocase(dst, "pgm")) {
+            failed = writePNMImageFile(dst, px, rgb, h, w);
+#ifdef IMCVT_WITH_JLS
+        } else if (ends_with_nocase(dst, "jls")) {
+            failed = writeJLSImageFile(dst, px, rgb, h, w, level);
+#endif
+        } else if (is_hevc_name(dst)) {
+            if (enc[i].tried) {
+                if (rgb) printf("   warning: this HEVCencoder currently only support gray 8-bit image instead of RGB image. Only compress the green channel of this image.\n");
+                failed = 1;
+                if (enc[i].ok) {
+                    FILE *fp = fopen(dst, "wb");
+                    if (fp) { failed = fwrite(enc[i].stream.data(), 1, (size_t)enc[i].len, fp) != (size_t)enc[i].len; fclose(fp); }
+                }
+            } else {
+                failed = writeHEVCImageFile(dst, px, rgb, h, w, level);        // the input was not loadable when the batch was formed
+            }
+        } else {
+            free(px);
+            printf("   ***ERROR: unsupported output suffix: %s\n", dst);
+            continue;
+        }
+        free(px);
+        if (failed) { printf("   ***ERROR: write %s failed\n", dst); continue; }
+        converted++;
+    }
+    const int failures = n - converted;
+    if (n > 1) {                                                             // :216-221
+        printf("\nsummary:");
+        if (converted) printf("  %d file converted", converted);
+        if (failures) printf("  %d failed", failures);
+        printf("\n");
+    }
+    return failures;
+}

@@ -84,3 +84,45 @@ def ref_encode(img, qpd6=0):
 def cpu_encode(img, qpd6=0):
     """Checker used on the GPU box: the real reference when its prebuilt .so travelled, else the port."""
     return ref_encode(img, qpd6) if have_ref() else port_encode(img, qpd6)
+
+
+# ---- JPEG-LS (BASELINE config 5; reference src/imageio_jls.c) ------------------------------------------------------
+def jls_port_encode(img: np.ndarray, near: int = 0) -> bytes:
+    """Our C restatement (oracle/jls_oracle.c), in memory.  img: [h, w] gray8 or [h, w, 3] RGB24."""
+    p = os.path.join(HERE, "_build", "liboracle_jls.so")
+    if not os.path.exists(p):
+        build("port")
+    lib = _cache.setdefault("jls_port", _load(p))
+    lib.jls_oracle_encode.restype = C.c_longlong
+    lib.jls_oracle_encode.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    out = np.zeros(8 * w * h + 65536, dtype=np.uint8)
+    n = lib.jls_oracle_encode(img.ctypes.data_as(_u8p), int(img.ndim == 3), h, w, int(near), out.ctypes.data_as(_u8p))
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def jls_have_ref() -> bool:
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_jls.so"))
+
+
+def jls_ref_encode(img: np.ndarray, near: int = 0) -> bytes:
+    """The real reference (file based: writeJLSImageFile, src/imageio.h:20) through a temporary file."""
+    import tempfile
+    lib = _cache.setdefault("jls_ref", _load(os.path.join(HERE, "_ref", "libref_jls.so")))
+    lib.writeJLSImageFile.restype = C.c_int
+    lib.writeJLSImageFile.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    with tempfile.NamedTemporaryFile(suffix=".jls", delete=False) as f:
+        name = f.name
+    try:
+        assert lib.writeJLSImageFile(name.encode(), img.tobytes(), int(img.ndim == 3), h, w, int(near)) == 0
+        return open(name, "rb").read()
+    finally:
+        os.unlink(name)
+
+
+def jls_cpu_encode(img, near=0) -> bytes:
+    return jls_ref_encode(img, near) if jls_have_ref() else jls_port_encode(img, near)

@@ -1,0 +1,121 @@
+"""JPEG-LS path (BASELINE config 5).
+CPU: the DEVICE source (imcvt_amd/csrc/jls_core.h) compiled for the host by tests/hostemu/jls_hostemu.cpp — the serial walk
+is ordinary C++, so this is the kernel's own logic — against the golden vectors generated from the compiled reference.
+GPU (-m gpu): the HIP path through the C ABI against the same vectors, the CPU checker on seeded inputs, the 1080p / 4K
+golden digests, a device-resident batch, and the reference's file-writer entry point."""
+import base64
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_jls_oracle import KAT, SMALL, LARGE, jls_id, jls_input
+
+u8p = C.POINTER(C.c_ubyte)
+
+
+@pytest.fixture(scope="module")
+def jls_emu(built):
+    d = os.path.join(ROOT, "tests", "hostemu")
+    so, src = os.path.join(d, "libjls_hostemu.so"), os.path.join(d, "jls_hostemu.cpp")
+    core = os.path.join(ROOT, "imcvt_amd", "csrc", "jls_core.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(core)) > os.path.getmtime(so):
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", so, src], check=True)
+    lib = C.CDLL(so)
+    lib.jls_hostemu_encode.restype = C.c_longlong
+    lib.jls_hostemu_encode.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+
+    def enc(img, near):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        out = np.zeros((8 * w * h + 65536) * (3 if img.ndim == 3 else 1), np.uint8)
+        n = lib.jls_hostemu_encode(img.ctypes.data_as(u8p), int(img.ndim == 3), h, w, near, out.ctypes.data_as(u8p))
+        return out[:n].tobytes()
+    return enc
+
+
+def _check(got, e):
+    assert len(got) == e["bytes"] and hashlib.sha256(got).hexdigest() == e["sha256"]
+    if "stream_b64" in e:
+        assert got == base64.b64decode(e["stream_b64"])
+
+
+@pytest.mark.parametrize("e", SMALL + [e for e in LARGE if e["input"]["w"] == 1920], ids=jls_id)
+def test_device_source_matches_reference_vectors(jls_emu, e):
+    _check(jls_emu(jls_input(e["input"]), e["near"]), e)
+
+
+def test_library_exports_the_declared_symbols(built):
+    lib = C.CDLL(os.path.join(ROOT, "imcvt_amd", "csrc", "libimcvt_jls.so"))
+    for name in ("writeJLSImageFile", "imcvt_jls_encode", "imcvt_jls_stream_bound", "imcvt_jls_encode_device", "imcvt_jls_last_kernel_ms", "imcvt_jls_version"):
+        assert hasattr(lib, name), name
+    lib.imcvt_jls_stream_bound.restype = C.c_longlong
+    assert lib.imcvt_jls_stream_bound(1080, 1920) == 8 * 1920 * 1080 + 65536
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def jls_gpu(built):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from imcvt_amd import jls
+    jls.load_jls_library()
+    return jls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e", SMALL, ids=jls_id)
+def test_gpu_matches_reference_vectors(jls_gpu, e):
+    _check(jls_gpu.JLSencode(jls_input(e["input"]), e["near"]), e)
+
+
+@pytest.mark.gpu
+def test_gpu_large_frames_golden_digests_in_one_batch(jls_gpu):
+    big = [e for e in LARGE if e["near"] == 0]
+    got = jls_gpu.JLSencodeBatch([jls_input(e["input"]) for e in big], 0)
+    for g, e in zip(got, big):
+        _check(g, e)
+    e2 = [e for e in LARGE if e["near"] == 2][0]
+    _check(jls_gpu.JLSencode(jls_input(e2["input"]), 2), e2)
+
+
+@pytest.mark.gpu
+def test_gpu_seeded_random_vs_cpu_checker(jls_gpu):
+    from oracle import oracle
+    rng = np.random.default_rng(2024)
+    for i in range(30):
+        h, w = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        shape = (h, w, 3) if i % 4 == 3 else (h, w)
+        img = (rng.integers(0, 256, shape) if i % 3 == 0 else np.clip(rng.normal(100, 4, shape), 0, 255) if i % 3 == 1
+               else rng.integers(0, 2, shape) * 255).astype(np.uint8)
+        near = int(rng.integers(0, 5))
+        assert jls_gpu.JLSencode(img, near) == oracle.jls_cpu_encode(img, near), (i, shape, near)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_of_ragged_planes_and_file_writer(jls_gpu, tmp_path):
+    from oracle import oracle, synth
+    imgs = [synth.syn(40 + 13 * i, 30 + 7 * i, i) for i in range(20)] + [synth.flat(5, 3, 9), synth.noise(1, 200, 3), synth.noise(300, 1, 4)]
+    for near in (0, 3):
+        got = jls_gpu.JLSencodeBatch(imgs, near)
+        for g, im in zip(got, imgs):
+            assert g == oracle.jls_cpu_encode(im, near)
+    rgb = np.stack([imgs[3], imgs[3][::-1].copy(), 255 - imgs[3]], axis=-1)
+    assert jls_gpu.writeJLSImageFile(str(tmp_path / "o.jls"), rgb, 1) == 0
+    assert (tmp_path / "o.jls").read_bytes() == oracle.jls_cpu_encode(rgb, 1)
+    assert jls_gpu.writeJLSImageFile(str(tmp_path / "nodir" / "o.jls"), rgb, 1) == 1
+
+
+@pytest.mark.gpu
+def test_cli_writes_reference_jls(built, tmp_path):
+    from oracle import oracle, synth
+    img = synth.syn(100, 70, 3)
+    (tmp_path / "a.pgm").write_bytes(b"P5\n100 70\n255\n" + img.tobytes())
+    exe = os.path.join(ROOT, "imcvt_amd", "csrc", "imcvt")
+    r = subprocess.run([exe, "-2", "a.pgm", "-o", "a.jls"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == "(1/1)  a.pgm -> a.jls\n"
+    assert (tmp_path / "a.jls").read_bytes() == oracle.jls_cpu_encode(img, 2)
