@@ -811,23 +811,41 @@ struct Lv16 { int v[16]; };
 #define UNROLL_FULL _Pragma("unroll")
 #endif
 HD int tk_chunk_word(int v, int n) { return 0x8000 | (n << 8) | v; }
-// coeff_abs_level_remaining beyond the prefix-3 range: EG(k+1) escape (:1160-1167), out of line
-HDN int tok_escape(TokOut o, int k0, int wr, int v, int k) {
+// Bypass bins are coded as one run per coefficient group: sign bins and all coeff_abs_level_remaining bins of the group
+// follow each other without a context-coded bin in between (:1228-1262), and the state a bypass run leaves the coder in —
+// low, the bit position, the bytes shifted out — does not depend on how the run is cut into <= 8-bin CABACputBins calls
+// (:898-910): every call adds range * pattern below the bits already there, and CABACupdate moves out one byte whenever
+// fewer than 12 bits of headroom remain, at byte positions fixed by the total bin count.  So the run is cut into full
+// 8-bin chunks (plus one remainder) instead of the reference's per-syntax-element chunks: ~35 % fewer tokens per group,
+// the same bytes.  (Checked bit-for-bit against the golden vectors; the RD decisions read the coder only at trial ends.)
+struct BitRun { u32 acc; int nb; };             // nb (< 8 between appends) pending bins, right-aligned in acc
+// coeff_abs_level_remaining beyond the prefix-3 range: EG(k+1) escape (:1160-1167), out of line.  Appends the escape's bins to
+// the run, emitting full chunks as tokens k0.. of the writer; returns the number of tokens emitted.
+struct EscRet { int ntok; u32 acc; int nb; };
+HDN EscRet tok_escape(TokOut o, int k0, int wr, int v, int k, u32 acc, int nb) {
     TokW w; w.o = o; w.n = k0; w.wr = wr;
     int n = k; v -= 3 << k;
     for (; v >= (1 << n); n++) v -= 1 << n;
     const int t = 4 + n - k;
-    tk_bypass(w, (1 << t) - 2, t); tk_bypass(w, v, n);
-    return w.n - k0;
+    for (int part = 0; part < 2; part++) {
+        int len = part ? n : t; const u32 val = part ? (u32)v : ((1u << t) - 2u);
+        while (len > 0) {
+            const int take = imin(len, 8 - nb); len -= take;
+            acc = (acc << take) | ((val >> len) & ((1u << take) - 1u)); nb += take;
+            if (nb == 8) { tk_chunk(w, (int)acc, 8); acc = 0; nb = 0; }
+        }
+    }
+    EscRet e; e.ntok = w.n - k0; e.acc = acc; e.nb = nb;
+    return e;
 }
-struct TgB { int esc, base2, rice, j; };       // state handed from part A to part B
+struct TgB { int esc, base2, rice, j; BitRun run; };       // state handed from part A to part B
 #define TK_EMIT(pred, tok) do { const int p_ = (pred); if (WR) { if (PRIV) to_put(o, cnt, (tok)); else to_put_if(o, cnt, (tok), p_); } cnt += p_; } while (0)
 // returns the token count so far | (this group ends with c1 == 0) << 16
 template <bool WR, bool PRIV>
 HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B) {
     const Tables &T = SM.T;
     const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3, s = (cfg >> TG_S) & 3;
-    B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0;
+    B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
     TK_EMIT(!dcg && !has_last, ((CX_CSBF + (pat != 0)) << 1) | (nzm != 0));
     if (nzm == 0 && !dcg) return cnt;
     {   // significance flags, scan positions nstart..0.  Context of position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
@@ -861,34 +879,47 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
     }
     TK_EMIT(g2 >= 0, ((CX_GT2 + set) << 1) | (g2 > 0));
     esc |= (g2 > 0);
-    {   // sign bins: one or two bypass chunks
-        const int two = nnz > 8, lo = two ? nnz - 8 : 0;
-        TK_EMIT(1, two ? tk_chunk_word((signs >> lo) & 0xFF, 8) : tk_chunk_word(signs, nnz));
-        TK_EMIT(two, tk_chunk_word(signs & ((1 << lo) - 1), lo));
+    {   // sign bins open the group's bypass run: full chunks leave at once, the rest waits for the remaining-level bins
+        int nb = nnz;
+        TK_EMIT(nb >= 8, tk_chunk_word((signs >> (nb & 7)) >> (nb >= 16 ? 8 : 0) & 0xFF, 8));
+        TK_EMIT(nb >= 16, tk_chunk_word(signs & 0xFF, 8));
+        nb &= 7;                                        // nnz <= 16: at most 7 bins stay pending (nnz == 16 leaves none)
+        B.run.nb = nb; B.run.acc = (u32)signs & ((1u << nb) - 1u);
     }
     B.esc = esc;
     return cnt | ((g2 >= 0) ? 1 << 16 : 0);
 }
-// remaining absolute levels of scan positions hi..lo (:1243-1262); returns the token count so far
+// remaining absolute levels of scan positions hi..lo (:1243-1262), appended to the group's bypass run; returns the token count so far
 template <bool WR, bool PRIV, int HI, int LO>
 HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
     if (B.esc) {
         int base2 = B.base2, rice = B.rice, j = B.j;
+        u32 acc = B.run.acc; int nb = B.run.nb;
         UNROLL_FULL
         for (int n = HI; n >= LO; n--) {
             const int mg = iabs(L.v[n]), isnz = mg != 0;
             const int r = mg - (j < 8 ? base2 : 1);
             const int doit = isnz & (r >= 0), small = r < (3 << rice);
-            const int pp = r >> rice;                  // prefix of <=3 bins, suffix of rice<=4 bins: one chunk each
-            TK_EMIT(doit & small, tk_chunk_word((2 << pp) - 2, pp + 1));
-            TK_EMIT(doit & small & (rice != 0), tk_chunk_word(r & ((1 << rice) - 1), rice));
-            if (doit & !small) cnt += tok_escape(o, cnt, WR, r, rice);
+            const int pp = r >> rice;                  // prefix of pp ones and a zero (pp <= 2), then rice suffix bins: at most 7 bins
+            const int len = (doit & small) ? pp + 1 + rice : 0;
+            const u32 bins = ((((2u << pp) - 2u) << rice) | ((u32)r & ((1u << rice) - 1u))) & ((1u << len) - 1u);
+            acc = (acc << len) | bins; nb += len;
+            const int full = nb >= 8;
+            TK_EMIT(full, tk_chunk_word((int)(acc >> (nb & 7)) & 0xFF, 8));
+            nb &= 7; acc &= (1u << nb) - 1u;           // (nb was at most 7 + 7)
+            if (doit & !small) { const EscRet e = tok_escape(o, cnt, WR, r, rice, acc, nb); cnt += e.ntok; acc = e.acc; nb = e.nb; }
             rice = (doit & (mg > (3 << rice))) ? imin(rice + 1, 4) : rice;
             base2 = (isnz & (mg >= 2)) ? 2 : base2;
             j += isnz;
         }
-        B.base2 = base2; B.rice = rice; B.j = j;
+        B.base2 = base2; B.rice = rice; B.j = j; B.run.acc = acc; B.run.nb = nb;
     }
+    return cnt;
+}
+// the run's last, partial chunk
+template <bool WR, bool PRIV>
+HD int tokg_end(const TokOut &o, int cnt, TgB &B) {
+    TK_EMIT(B.run.nb > 0, tk_chunk_word((int)B.run.acc, B.run.nb));
     return cnt;
 }
 #undef TK_EMIT
@@ -896,12 +927,12 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
 HD int tok_count(const Lv16 &L, u32 nzm, int cfg) {
     TokOut o; o.tb = (u16 *)0; o.pos = 0; o.cap = 0; o.glob = 0; TgB B;
     const int ra = tokg_a<false, false>(o, 0, L, nzm, cfg, B);
-    return tokg_b<false, false, 15, 0>(o, ra & 0xFFFF, L, B) | (ra & ~0xFFFF);
+    return tokg_end<false, false>(o, tokg_b<false, false, 15, 0>(o, ra & 0xFFFF, L, B), B) | (ra & ~0xFFFF);
 }
 HD int tok_write(u16 *p, int k0, const Lv16 &L, u32 nzm, int cfg) {      // straight into the candidate's stream in global memory
     TokOut o; o.tb = p; o.pos = 0; o.cap = 0; o.glob = 1; TgB B;
     const int ra = tokg_a<true, false>(o, k0, L, nzm, cfg, B);
-    return tokg_b<true, false, 15, 0>(o, ra & 0xFFFF, L, B) | (ra & ~0xFFFF);
+    return tokg_end<true, false>(o, tokg_b<true, false, 15, 0>(o, ra & 0xFFFF, L, B), B) | (ra & ~0xFFFF);
 }
 
 // ---- lane-private token streams (CU headers, 4x4 TUs): the lane stages up to LCAP tokens in its own LDS row and hands
@@ -1001,6 +1032,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                         ls_flush(ls, w);
                         w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B);
                     }
+                    w.n = tokg_end<true, true>(w.o, w.n, B);
                 } else if (P.shape == 3) tk_last_pos(w, 0, st, 0, 0);   // PU pricing codes the residual syntax of an all-zero block (:1515)
                 ls_end(ls, w, W, c);
                 W.tnz[c] = (nzm != 0);

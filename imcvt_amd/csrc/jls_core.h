@@ -24,7 +24,7 @@
 namespace jls {
 
 struct Ctx { int a, b, c, n; };                         // :241-247
-struct Par { int near, alpha, t1, t2, t3, quant, qbeta, qbpp, limit, a_init; };
+struct Par { int near, alpha, t1, t2, t3, quant, qbeta, qbpp, limit, a_init, half, recip; };
 JD Par make_par(int near) {                             // :26-38 for 8-bit samples
     Par p; p.near = near; p.alpha = 256;
     p.t1 = 3 + 3 * near; p.t2 = 7 + 5 * near; p.t3 = 21 + 7 * near;
@@ -32,6 +32,8 @@ JD Par make_par(int near) {                             // :26-38 for 8-bit samp
     p.qbpp = 1; while ((1 << p.qbpp) < p.qbeta) p.qbpp++;
     p.limit = 32 - p.qbpp - 1;
     p.a_init = (p.qbeta + 32) / 64; if (p.a_init < 2) p.a_init = 2;
+    p.half = (p.qbeta + 1) / 2;
+    p.recip = ((1 << 20) + p.quant - 1) / p.quant;         // n / quant == (n * recip) >> 20 for 0 <= n < 1024 and odd quant <= 511 (exhaustively checked, tests/test_jls.py)
     return p;
 }
 JD int iabs(int v) { return v < 0 ? -v : v; }
@@ -41,6 +43,8 @@ JD int clampi(int v, int lo, int hi) { return imin(imax(v, lo), hi); }
 JD int jtab(int i) {                                    // :14 {0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,5,5,6,6,7,7,8..15}
     return i < 16 ? i >> 2 : i < 24 ? 4 + ((i - 16) >> 1) : i - 16;
 }
+// error quantisation (:97-102) without a division: |e| + near <= 255 + 255 here
+JD int quant_err(const Par &p, int e) { const int m = ((iabs(e) + p.near) * p.recip) >> 20; return e < 0 ? -m : m; }
 JD int grad(const Par &p, int v) {                      // :67-76
     const int m = iabs(v);
     const int g = m >= p.t3 ? 4 : m >= p.t2 ? 3 : m >= p.t1 ? 2 : m > p.near ? 1 : 0;
@@ -125,9 +129,9 @@ JD void plane_row(Plane &S, CtxMem cx, int y, const uint8_t *src, uint8_t *rec, 
             sgn = (a > b + near) ? -1 : 1;
             const int pred = t ? a : b;
             int e = sgn * (v - pred);
-            e = e < 0 ? -((near - e) / p.quant) : (near + e) / p.quant;
+            e = quant_err(p, e);
             rx = near ? clampi(pred + sgn * p.quant * e, 0, 255) : v;
-            if (e < 0) e += p.qbeta; if (e >= (p.qbeta + 1) / 2) e -= p.qbeta;
+            if (e < 0) e += p.qbeta; if (e >= p.half) e -= p.qbeta;
             Ctx r = S.ri[t];
             const int k = golomb_k(r.a + (t ? (r.n >> 1) : 0), r.n);
             const int map = (e != 0) && ((e > 0) == (k == 0 && 2 * r.b < r.n));
@@ -145,9 +149,9 @@ JD void plane_row(Plane &S, CtxMem cx, int y, const uint8_t *src, uint8_t *rec, 
             const int med = c >= hi ? lo : c <= lo ? hi : a + b - c;               // :87-94
             const int pred = clampi(med + sgn * r.c, 0, 255);
             int e = sgn * (v - pred);
-            e = e < 0 ? -((near - e) / p.quant) : (near + e) / p.quant;
+            e = quant_err(p, e);
             rx = near ? clampi(pred + sgn * p.quant * e, 0, 255) : v;
-            if (e < 0) e += p.qbeta; if (e >= (p.qbeta + 1) / 2) e -= p.qbeta;
+            if (e < 0) e += p.qbeta; if (e >= p.half) e -= p.qbeta;
             const int k = golomb_k(r.a, r.n);
             const int map = (k == 0) && (2 * r.b <= -r.n) && (near == 0);
             int me = 2 * iabs(e);

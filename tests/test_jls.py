@@ -49,6 +49,14 @@ def test_device_source_matches_reference_vectors(jls_emu, e):
     _check(jls_emu(jls_input(e["input"]), e["near"]), e)
 
 
+def test_reciprocal_quantiser_is_exact():
+    # jls_core.h quant_err: n / quant as (n * ceil(2^20 / quant)) >> 20 for every quant = 2*near+1 the ABI admits and every n it can see
+    for q in range(1, 512, 2):
+        r = ((1 << 20) + q - 1) // q
+        n = np.arange(1024, dtype=np.int64)
+        assert ((n * r) >> 20 == n // q).all() and 1023 * r < 2 ** 31
+
+
 def test_library_exports_the_declared_symbols(built):
     lib = C.CDLL(os.path.join(ROOT, "imcvt_amd", "csrc", "libimcvt_jls.so"))
     for name in ("writeJLSImageFile", "imcvt_jls_encode", "imcvt_jls_stream_bound", "imcvt_jls_encode_device", "imcvt_jls_last_kernel_ms", "imcvt_jls_version"):
