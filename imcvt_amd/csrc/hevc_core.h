@@ -16,6 +16,7 @@
 
 typedef uint8_t u8;  typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
 typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
+typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that is also accessed as bytes / 16-bit tokens
 
 #define NWAVES 3
 #define WG_THREADS (NWAVES * 64)
@@ -66,7 +67,6 @@ typedef int8_t i8;   typedef int16_t i16;  typedef int32_t i32;
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define NOUNROLL _Pragma("unroll 1")
 #endif
-typedef u32 __attribute__((may_alias)) u32a;      // a dword view of LDS data that is also accessed as bytes / 16-bit tokens
 struct alignas(16) U4 { u32 x, y, z, w; };
 // Global-memory accessors.  Pointers that come out of structs are generic ("flat") to the compiler, and FLAT
 // instructions count against lgkmcnt — every LDS wait would then also wait for a global round trip.
@@ -74,6 +74,7 @@ struct alignas(16) U4 { u32 x, y, z, w; };
 #ifdef IMCVT_HOSTEMU
 HD void g_st8(u8 *p, int v) { *p = (u8)v; }
 HD void g_st16(i16 *p, int v) { *p = (i16)v; }
+HD void g_st32(void *p, u32 v) { *(u32a *)p = v; }
 HD u8 g_ld8(const u8 *p) { return *p; }
 HD i16 g_ld16(const i16 *p) { return *p; }
 HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
@@ -87,6 +88,7 @@ HD int ctz64(u64 v) { return __builtin_ctzll(v); }
 #define GAS __attribute__((address_space(1)))
 HD void g_st8(u8 *p, int v) { *(GAS u8 *)p = (u8)v; }
 HD void g_st16(i16 *p, int v) { *(GAS i16 *)p = (i16)v; }
+HD void g_st32(void *p, u32 v) { *(GAS u32 *)p = v; }
 HD u8 g_ld8(const u8 *p) { return *(const GAS u8 *)p; }
 HD i16 g_ld16(const i16 *p) { return *(const GAS i16 *)p; }
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -450,7 +452,7 @@ HD int pred_px(const Tables &T, const BorderRef &b, int N, int lg, int mode, int
 // Prediction of one 4x4 block at (y0,x0) of an N x N predictor (same arithmetic as pred_px, :262-381), with the per-row
 // angle terms hoisted and neighbouring reference samples shared between pixels.
 HD int ref_line(const u8 *M, const u8 *Sd, int corner, int iang, int t) {     // t==0 corner, t>0 main[t-1], t<0 projected side (:353-364)
-    return t == 0 ? corner : t > 0 ? M[t - 1] : Sd[((128 - iang * t) >> 8) - 1];
+    return t == 0 ? corner : t > 0 ? M[t - 1] : Sd[((128 - mul24(iang, t)) >> 8) - 1];      // iang <= 4096, |t| <= 65
 }
 HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode, int y0, int x0, int out[4][4]) {
     const int f = uses_filtered(N, mode);
@@ -462,7 +464,7 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
         for (int i = 0; i < 4; i++) { lv[i] = L[y0 + i]; av[i] = A[x0 + i]; }
         for (int yi = 0; yi < 4; yi++) for (int xi = 0; xi < 4; xi++) {
             const int y = y0 + yi, x = x0 + xi;
-            out[yi][xi] = ((N - 1 - x) * lv[yi] + (x + 1) * an + (N - 1 - y) * av[xi] + (y + 1) * ln + N) >> (lg + 1);
+            out[yi][xi] = (mul24(N - 1 - x, lv[yi]) + mul24(x + 1, an) + mul24(N - 1 - y, av[xi]) + mul24(y + 1, ln) + N) >> (lg + 1);
         }
     } else if (mode == 1) {
         const int dc = b.dc;
@@ -484,11 +486,11 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
         const u8 *M = horiz ? L : A, *Sd = horiz ? A : L;
         const int i0 = horiz ? x0 : y0, j0 = horiz ? y0 : x0;           // i runs along the prediction direction
         for (int ii = 0; ii < 4; ii++) {
-            const int off = ang * (i0 + ii + 1), oi = off >> 5, of = off & 31, t0 = oi + j0 + 1;
+            const int off = mul24(ang, i0 + ii + 1), oi = off >> 5, of = off & 31, t0 = oi + j0 + 1;
             int p[5];
             for (int k = 0; k < 5; k++) p[k] = ref_line(M, Sd, corner, iang, t0 + k);      // M[2N] is read only with of==0
             for (int jj = 0; jj < 4; jj++) {
-                const int v = ((32 - of) * p[jj] + of * p[jj + 1] + 16) >> 5;
+                const int v = (mul24(32 - of, p[jj]) + mul24(of, p[jj + 1]) + 16) >> 5;
                 if (horiz) out[jj][ii] = v; else out[ii][jj] = v;
             }
         }
@@ -636,7 +638,7 @@ HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0) {
         for (int r = 0; r < 4; r++) {
             const int4 y = *(const int4 *)(Y + (row0 + r) * N + k0);
             for (int c = 0; c < 4; c++)
-                acc[r][c] += y.x * sx8(mw[c], 0) + y.y * sx8(mw[c], 1) + y.z * sx8(mw[c], 2) + y.w * sx8(mw[c], 3);
+                acc[r][c] += mul24(y.x, sx8(mw[c], 0)) + mul24(y.y, sx8(mw[c], 1)) + mul24(y.z, sx8(mw[c], 2)) + mul24(y.w, sx8(mw[c], 3));   // |tmp| <= 45900 (17 bits)
         }
     }
 }
@@ -657,9 +659,9 @@ HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *M, int row0, int col0) {
 }
 
 // quantiser constants of one (size, qpd6) pair (:546-554, :606-608)
-struct QConst { int sh, add, dmax, thr, dq; RdW rw; };
+struct QConst { int sh, add, dmax, thr, dq, dqs; RdW rw; };
 template <int S>
-HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q.dmax = I32MAX - Q.add; Q.thr = 9 << Q.sh >> 2; Q.dq = 1 << (5 - S + q); Q.rw = rd_weights(q); return Q; }
+HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q.dmax = I32MAX - Q.add; Q.thr = 9 << Q.sh >> 2; Q.dqs = 5 - S + q; Q.dq = 1 << Q.dqs; Q.rw = rd_weights(q); return Q; }
 
 // Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594).  in: acc = forward-transform sums before the
 // final shift; out: acc = signed levels.  Returns non-zero when the group keeps any level after the weak-group test.
@@ -678,14 +680,14 @@ HD int rdoq_group(int acc[4][4], const QConst &Q) {
         if (l0 > 0) {                                   // level 0 alone needs no pricing
             // candidates l0, l0-1, l0-2 (>= 0), the larger level winning ties (:570-578)
             const int e0 = iabs(d - (l0 << Q.sh)) >> dsh;
-            const int c0 = rd_cost_q(Q.rw, ((e0 < 46340) ? e0 * e0 : I32MAX) >> 7, level_rate(l0));   // e*e needs 32 bits
+            const int c0 = rd_cost_q(Q.rw, ((e0 < 46340) ? umul24(e0, e0) : I32MAX) >> 7, level_rate(l0));   // e*e needs 32 bits
             const int e1 = iabs(d - ((l0 - 1) << Q.sh)) >> dsh;
-            const int c1 = rd_cost_q(Q.rw, ((e1 < 46340) ? e1 * e1 : I32MAX) >> 7, level_rate(l0 - 1));
+            const int c1 = rd_cost_q(Q.rw, ((e1 < 46340) ? umul24(e1, e1) : I32MAX) >> 7, level_rate(l0 - 1));
             int best = c0; pick = l0;
             if (c1 < best) { best = c1; pick = l0 - 1; }
             if (l0 > 1) {
                 const int e2 = iabs(d - ((l0 - 2) << Q.sh)) >> dsh;
-                const int c2 = rd_cost_q(Q.rw, ((e2 < 46340) ? e2 * e2 : I32MAX) >> 7, level_rate(l0 - 2));
+                const int c2 = rd_cost_q(Q.rw, ((e2 < 46340) ? umul24(e2, e2) : I32MAX) >> 7, level_rate(l0 - 2));
                 if (c2 < best) { best = c2; pick = l0 - 2; }
             }
         }
@@ -1039,7 +1041,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
             }
             int part = 0;
             if (any) {
-                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * Q.dq);
+                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * (1 << Q.dqs));
                 // inverse DST with the 16-bit clips (:511-515): t = clip16((D^T*x + 64) >> 7) ; r = clip16((t*D + 2048) >> 12)
                 for (int j = 0; j < 4; j++) {
                     const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
@@ -1078,6 +1080,35 @@ HD void p1_run_4(int wave, const P1Args &P) {
     wave_sync_lds();
 }
 
+// some level among the first 8 non-zero ones (coding order: scan positions 15 .. 0) exceeds 1 — the flag tokg_a reports as
+// "this group ends with c1 == 0"; the next coded group's greater-1 context set depends on it (:1218-1221)
+HD int group_big(const Lv16 &L) {
+    int seen = 0, big = 0;
+    UNROLL_FULL
+    for (int n = 15; n >= 0; n--) { const int mg = iabs(L.v[n]); big |= (mg > 1) & (seen < 8); seen += (mg != 0); }
+    return big;
+}
+// A lane's staged group tokens row[0..c) to tokens o.. of a stream (dst = stream base, 16-byte aligned): dword stores, a
+// 16-bit store at an odd start and for an odd tail.
+#ifndef ROWCAP
+#define ROWCAP 45           // tokens per lane row (23 dwords: odd stride, the 46th slot is the dump slot)
+#endif
+#define ROWSTRIDE 23
+HD void row_to_stream(const u16 *row, u16 *dst, int o, int c) {
+    const u32a *rw = (const u32a *)row;
+    const int odd = o & 1;
+    if (odd && c > 0) g_st16((i16 *)(dst + o), row[0]);
+    const int nd = (c - odd) >> 1;                      // whole dwords after the odd head
+    u32a *d32 = (u32a *)(dst + o + odd);
+    u32 lo = rw[0];
+    NOUNROLL
+    for (int j = 0; j < nd; j++) {
+        const u32 hi = rw[j + 1];                       // (the row has a slot to spare: reading one dword ahead stays inside it)
+        g_st32(d32 + j, odd ? (lo >> 16) | (hi << 16) : lo);
+        lo = hi;
+    }
+    if (c > odd && ((c - odd) & 1)) g_st16((i16 *)(dst + o + c - 1), row[c - 1]);
+}
 // exclusive suffix sum of v over the lanes of this lane's segment of `lpc` consecutive lanes (wave collective)
 HD int seg_suffix_sum(int v, int l, int lpc, int *total) {
     int inc = v;
@@ -1149,7 +1180,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             const u64 cm = P.tok ? wave_ballot(any) : 0;
             uint2 dq[4];                                    // dequantised levels, packed; stored once the token buffer (which lives in res/tmp) is done with
             for (int r4 = 0; r4 < 4; r4++) {
-                for (int cc = 0; cc < 4; cc++) acc[r4][cc] = any ? clip16(acc[r4][cc] * Q.dq) : 0;
+                for (int cc = 0; cc < 4; cc++) acc[r4][cc] = any ? clip16(acc[r4][cc] * (1 << Q.dqs)) : 0;      // :613 (a shift; levels may be negative)
                 dq[r4].x = (u32)(acc[r4][0] & 0xFFFF) | (u32)acc[r4][1] << 16; dq[r4].y = (u32)(acc[r4][2] & 0xFFFF) | (u32)acc[r4][3] << 16;
             }
             if (P.tok) {
@@ -1167,42 +1198,54 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 }
                 u16 *base = P.tok + (size_t)c * TOK_CAP + tokn0;
                 const int cbf_ctx = CX_CBF_LUMA + (P.shape == 0 ? 1 : 0);
-                // pass 1: count (and learn whether this group ends with c1 == 0)
                 const long long ptk0 = prof_now();
-                int cnt = 0, big = 0;
+                // greater-1 context set carry (:1218-1221): needs only the levels, not the tokens
+                const int big = (talk && nzm != 0) ? group_big(L) : 0;
+                const u64 bmask = wave_ballot(big);
+                if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
+                // TU header (cbf_luma, last position) is written by the lane of the last coded group, first in coding order
+                int hdr = 0;
+                if (talk && seg != 0 && has_last) {
+                    TokW w; w.o.tb = (u16 *)0; w.o.pos = 0; w.o.cap = 0; w.o.glob = 0; w.n = 0; w.wr = 0;
+                    const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3));
+                    hdr = w.n;
+                }
+                // ONE pass: every lane writes its group's tokens into its own LDS row (res/tmp are dead here) and learns their
+                // number; a suffix sum over the candidate's lanes gives the place in the stream; rows leave as dword stores.
+                u16 *row = (u16 *)((u32a *)W.u.p1.res + l * ROWSTRIDE);
+                wave_sync_lds();                                            // every lane is done reading tmp
+                int cg = 0;
                 if (talk) {
-                    if (seg == 0) cnt = 1;
-                    else {
-                        TokW w; w.o.tb = (u16 *)0; w.o.pos = 0; w.o.cap = 0; w.o.glob = 0; w.n = 0; w.wr = 0;
-                        if (has_last) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
-                        const int rr = tok_count(L, nzm, cfg);
-                        cnt = w.n + (rr & 0xFFFF); big = rr >> 16;
-                    }
+                    TokOut o; o.tb = row; o.pos = 0; o.cap = ROWCAP; o.glob = 0;
+                    if (seg == 0) { to_put(o, 0, (cbf_ctx << 1) | 0); cg = 1; }
+                    else { TgB B; const int ra = tokg_a<true, true>(o, 0, L, nzm, cfg, B); cg = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, ra & 0xFFFF, L, B), B); }
                 }
                 prof_add(PF_T_SETUP, ptk0);
                 const long long ptk1 = prof_now();
-                const u64 bmask = wave_ballot(big);
-                if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
+                const int fits = wave_ballot(cg > ROWCAP) == 0;
+                int cnt = hdr + cg;
+                if (!fits) {                                                // a row overflowed (escape-heavy group): count the plain way
+                    cnt = 0;
+                    if (talk) cnt = (seg == 0) ? 1 : hdr + (tok_count(L, nzm, cfg) & 0xFFFF);
+                }
                 int total;
                 const int off = seg_suffix_sum(cnt, l, lpc, &total);
                 prof_add(PF_T_GEN, ptk1);
                 const long long ptk2 = prof_now();
-                // pass 2: write at the group's place in the candidate's stream (global memory; the lines of a run are filled
-                // by the wave within this pass).  The DC lane, last in coding order, pads the final block with idle tokens.
                 if (talk) {
                     TokW w; w.o.tb = base + off; w.o.pos = 0; w.o.cap = 0; w.o.glob = 1; w.n = 0; w.wr = 1;
-                    if (seg == 0) tk_bin(w, cbf_ctx, 0);
-                    else {
-                        if (has_last) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
-                        w.n = tok_write(w.o.tb, w.n, L, nzm, cfg) & 0xFFFF;
-                    }
-                    if (r == 0) {
+                    if (hdr) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
+                    if (fits) { row_to_stream(row, P.tok + (size_t)c * TOK_CAP, tokn0 + off + hdr, cg); w.n = hdr + cg; }
+                    else if (seg == 0) tk_bin(w, cbf_ctx, 0);
+                    else w.n = tok_write(w.o.tb, w.n, L, nzm, cfg) & 0xFFFF;
+                    if (r == 0) {                                           // the DC lane, last in coding order, pads the final block with idle tokens
                         const int e7 = (tokn0 + total) & 7;
                         for (int i = 0; i < 7; i++) to_put_if(w.o, w.n + i, (int)TOK_IDLE, e7 != 0 && e7 + i < 8);
                         W.tokn[c] = tokn0 + total; W.tnz[c] = (seg != 0);
                     }
                 }
                 prof_add(PF_T_HDR, ptk2);
+                wave_sync_lds();                                            // rows are done with before res is written again
             }
             if (live) {
                 i16 *dp = W.u.p1.res + sl * NN;

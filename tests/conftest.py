@@ -48,6 +48,12 @@ def hostemu_ovf(built):
     return _hostemu_lib("libhostemu_ovf.so", ["-DIMCVT_FORCE_OVF"])
 
 
+@pytest.fixture(scope="session")
+def hostemu_row(built):
+    """Same, with 6-token lane rows: nearly every pass overflows its token rows and takes the count-then-write path."""
+    return _hostemu_lib("libhostemu_row.so", ["-DROWCAP=6"])
+
+
 def kat_entries():
     import json
     return json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json")))

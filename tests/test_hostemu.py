@@ -48,6 +48,14 @@ def test_ring_overflow_path_matches_golden(hostemu_ovf, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_token_row_overflow_path_matches_golden(hostemu_row, e):
+    # a pass whose group tokens do not fit the lanes' LDS rows counts and writes them the plain way (hevc_core.h p1_run_t step 3)
+    stream, rcon = emu_encode(hostemu_row, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
 def test_lds_budget(hostemu):
     # two workgroups per CU need <= 80 KiB each (160 KiB LDS per CU)
     assert hostemu.hostemu_shm_bytes() <= 80 * 1024
