@@ -142,6 +142,7 @@ struct Tables {
     uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8        (:700-712)
     u32 posadd[4][3];      // sig_coeff ctx increment per in-group scan position, 2 bits each [pattern][type]  (:1115-1120)
     u64 c4tab[3];          // 4x4-TU sig_coeff ctx per scan position, 4 bits each [type]                  (:1092)
+    u32 lrate[8];          // rate model of an absolute level 0..7 in 2^-15 bit units                      (:526-535)
     u8  ang[36];           // intraPredAngle + 32                                                         (:282)
     u16 iang[36];          // |invAngle|                                                                  (:283)
 };
@@ -668,33 +669,41 @@ HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q
 // RD cost inside RDOQ: dist <= (2^31-1) >> 7 and rate <= 92000 + (32 << 15) (levels are 16-bit), so with the weights of
 // :178-181 neither product nor their sum can reach the saturation branches of :182-184 — the cost is the plain sum.
 HD int rd_cost_q(const RdW &w, int dist, int rate) { return umul24(w.wd, dist) + umul24(w.wb, rate); }
+// :526-535 without a branch: a table for levels below 8, 92000 + ((4 + 2 floor(log2(level - 5))) << 15) above
+HD int level_rate_q(const Tables &T, int level) {
+    const int l = imax(level, 0);
+    const int hi = 223072 + ((31 - clz_nz((u32)imax(l - 5, 1))) << 16);
+    const int lo = (int)T.lrate[imin(l, 7)];
+    return l < 8 ? lo : hi;
+}
+// squared error of a candidate level in the reference's fixed point (:571-573)
+HD int level_dist_q(int d, int level, int sh, int dsh) {
+    const int e = iabs(d - (level << sh)) >> dsh;
+    return (int)(((e < 46340) ? (u32)umul24(e, e) : (u32)I32MAX) >> 7);      // e < 2^16: the 24-bit multiply is exact
+}
+// Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594), written without branches: every coefficient
+// prices the levels l0, l0-1, l0-2 (results of impossible candidates are masked), the larger level winning ties (:570-578).
+// in: acc = forward-transform sums before the final shift; out: acc = signed levels.  Returns non-zero when the group keeps
+// any level after the weak-group test (:588-591).
 template <int S>
 HD int rdoq_group(int acc[4][4], const QConst &Q) {
     constexpr int b1 = S + 8, dsh = 8 - S;
+    const Tables &T = SM.T;
     int sum = 0, any = 0;
     for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
         const int cf = acc[r][cc] >> b1, av = iabs(cf);
         const int d = (av > 0x1ffff) ? Q.dmax : imin((av & 0x1ffff) << 14, Q.dmax);
         const int l0 = clip16((int)(((u32)d + (u32)Q.add) >> Q.sh));
-        int pick = 0;
-        if (l0 > 0) {                                   // level 0 alone needs no pricing
-            // candidates l0, l0-1, l0-2 (>= 0), the larger level winning ties (:570-578)
-            const int e0 = iabs(d - (l0 << Q.sh)) >> dsh;
-            const int c0 = rd_cost_q(Q.rw, ((e0 < 46340) ? umul24(e0, e0) : I32MAX) >> 7, level_rate(l0));   // e*e needs 32 bits
-            const int e1 = iabs(d - ((l0 - 1) << Q.sh)) >> dsh;
-            const int c1 = rd_cost_q(Q.rw, ((e1 < 46340) ? umul24(e1, e1) : I32MAX) >> 7, level_rate(l0 - 1));
-            int best = c0; pick = l0;
-            if (c1 < best) { best = c1; pick = l0 - 1; }
-            if (l0 > 1) {
-                const int e2 = iabs(d - ((l0 - 2) << Q.sh)) >> dsh;
-                const int c2 = rd_cost_q(Q.rw, ((e2 < 46340) ? umul24(e2, e2) : I32MAX) >> 7, level_rate(l0 - 2));
-                if (c2 < best) { best = c2; pick = l0 - 2; }
-            }
-        }
+        const int c0 = rd_cost_q(Q.rw, level_dist_q(d, l0, Q.sh, dsh), level_rate_q(T, l0));
+        const int c1 = rd_cost_q(Q.rw, level_dist_q(d, l0 - 1, Q.sh, dsh), level_rate_q(T, l0 - 1));
+        const int c2 = rd_cost_q(Q.rw, level_dist_q(d, l0 - 2, Q.sh, dsh), level_rate_q(T, l0 - 2));
+        const int t1 = (l0 > 0) & (c1 < c0);
+        const int best1 = t1 ? c1 : c0;
+        const int t2 = (l0 > 1) & (c2 < best1);
+        const int pick = t2 ? l0 - 2 : t1 ? l0 - 1 : l0;
         acc[r][cc] = (cf < 0) ? -pick : pick;
         any |= pick;
         sum += imin(d, Q.thr);
-        if (cc & 1) SCHED_FENCE();                      // let two coefficients overlap, not sixteen
     }
     return (sum < Q.thr) ? 0 : any;                     // weak group: cleared (:588-591)
 }
