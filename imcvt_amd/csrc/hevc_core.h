@@ -670,33 +670,36 @@ HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q
 // :178-181 neither product nor their sum can reach the saturation branches of :182-184 — the cost is the plain sum.
 HD int rd_cost_q(const RdW &w, int dist, int rate) { return umul24(w.wd, dist) + umul24(w.wb, rate); }
 // :526-535 without a branch: a table for levels below 8, 92000 + ((4 + 2 floor(log2(level - 5))) << 15) above
+// (= 223072 + (31 - clz(level - 5)) << 16; for level < 8 the closed form's value is discarded, whatever clz returns)
 HD int level_rate_q(const Tables &T, int level) {
-    const int l = imax(level, 0);
-    const int hi = 223072 + ((31 - clz_nz((u32)imax(l - 5, 1))) << 16);
-    const int lo = (int)T.lrate[imin(l, 7)];
-    return l < 8 ? lo : hi;
-}
-// squared error of a candidate level in the reference's fixed point (:571-573)
-HD int level_dist_q(int d, int level, int sh, int dsh) {
-    const int e = iabs(d - (level << sh)) >> dsh;
-    return (int)(((e < 46340) ? (u32)umul24(e, e) : (u32)I32MAX) >> 7);      // e < 2^16: the 24-bit multiply is exact
+    const int hi = (223072 + (31 << 16)) - (clz_nz((u32)(level - 5)) << 16);
+    const int lo = (int)T.lrate[clip3(level, 0, 7)];
+    return level < 8 ? lo : hi;
 }
 // Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594), written without branches: every coefficient
 // prices the levels l0, l0-1, l0-2 (results of impossible candidates are masked), the larger level winning ties (:570-578).
+// With x0 = d - (l0 << sh) in (-2^(sh-1), 2^(sh-1)], the three errors are |x0|, x0 + 2^sh, x0 + 2^(sh+1) (the last two are
+// positive), and |x0| >> dsh < 2^15 never reaches the 46340 clamp of :572.
 // in: acc = forward-transform sums before the final shift; out: acc = signed levels.  Returns non-zero when the group keeps
 // any level after the weak-group test (:588-591).
 template <int S>
 HD int rdoq_group(int acc[4][4], const QConst &Q) {
     constexpr int b1 = S + 8, dsh = 8 - S;
     const Tables &T = SM.T;
+    const int step = 1 << Q.sh;
     int sum = 0, any = 0;
     for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
         const int cf = acc[r][cc] >> b1, av = iabs(cf);
         const int d = (av > 0x1ffff) ? Q.dmax : imin((av & 0x1ffff) << 14, Q.dmax);
         const int l0 = clip16((int)(((u32)d + (u32)Q.add) >> Q.sh));
-        const int c0 = rd_cost_q(Q.rw, level_dist_q(d, l0, Q.sh, dsh), level_rate_q(T, l0));
-        const int c1 = rd_cost_q(Q.rw, level_dist_q(d, l0 - 1, Q.sh, dsh), level_rate_q(T, l0 - 1));
-        const int c2 = rd_cost_q(Q.rw, level_dist_q(d, l0 - 2, Q.sh, dsh), level_rate_q(T, l0 - 2));
+        const int x0 = d - (l0 << Q.sh);
+        const int e0 = iabs(x0) >> dsh, e1 = (int)((u32)(x0 + step) >> dsh), e2 = (int)((u32)(x0 + 2 * step) >> dsh);
+        const int d0 = (int)((u32)umul24(e0, e0) >> 7);
+        const int d1 = (int)(((e1 < 46340) ? (u32)umul24(e1, e1) : (u32)I32MAX) >> 7);
+        const int d2 = (int)(((e2 < 46340) ? (u32)umul24(e2, e2) : (u32)I32MAX) >> 7);
+        const int c0 = rd_cost_q(Q.rw, d0, level_rate_q(T, l0));
+        const int c1 = rd_cost_q(Q.rw, d1, level_rate_q(T, l0 - 1));
+        const int c2 = rd_cost_q(Q.rw, d2, level_rate_q(T, l0 - 2));
         const int t1 = (l0 > 0) & (c1 < c0);
         const int best1 = t1 ? c1 : c0;
         const int t2 = (l0 > 1) & (c2 < best1);
