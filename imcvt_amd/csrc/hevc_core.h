@@ -200,7 +200,7 @@ struct alignas(16) WaveMem {
     i32 nxn_cost;
     alignas(16) u16 pend[NMODE + 1][8];     // the partial last 8-token block of each candidate's stream (rest: idle tokens)
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
-        struct { u8 pred[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                   // one pipeline pass
+        struct { u8 rows_[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                  // one pipeline pass (the first KB only ever holds token rows)
         u32 raw[1792];                                                                                // per-lane token staging (4x4 blocks, CU headers): lane l at raw + 33 l
         struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
@@ -791,19 +791,41 @@ HD void tk_cu_header(TokW &w, const CuHdr &J) {
     if (J.shape != 2) tk_bin(w, CX_SPLIT_TU + (J.N == 32 ? 0 : J.N == 16 ? 1 : 2), J.shape == 1);
     tk_bin(w, CX_CBF_CHROMA, 0); tk_bin(w, CX_CBF_CHROMA, 0);
 }
-HD void tk_last_pos(TokW &w, int s, int st, int y, int x) {                                 // :1045-1086
-    const int base = (s == 0) ? 0 : (s == 1) ? 3 : (s == 2) ? 6 : 10, shf = (s == 0) ? 0 : 1;
-    const int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;
-    // group index of a coordinate: 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8*8,9*8
-    const int gx = tx < 4 ? tx : (2 * (31 - clz32((u32)tx)) + ((tx >> (30 - clz32((u32)tx))) & 1));
-    const int gy = ty < 4 ? ty : (2 * (31 - clz32((u32)ty)) + ((ty >> (30 - clz32((u32)ty))) & 1));
-    const int gmax = 2 * (s + 2) - 1;                                         // group of N-1
-    for (int i = 0; i < gx; i++) tk_bin(w, CX_LAST_X + base + (i >> shf), 1);
-    if (gx < gmax) tk_bin(w, CX_LAST_X + base + (gx >> shf), 0);
-    for (int i = 0; i < gy; i++) tk_bin(w, CX_LAST_Y + base + (i >> shf), 1);
-    if (gy < gmax) tk_bin(w, CX_LAST_Y + base + (gy >> shf), 0);
-    if (gx > 3) { const int nb_ = (gx - 2) >> 1, mn = (2 + (gx & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) tk_bypass(w, ((tx - mn) >> i) & 1, 1); }
-    if (gy > 3) { const int nb_ = (gy - 2) >> 1, mn = (2 + (gy & 1)) << nb_; for (int i = nb_ - 1; i >= 0; i--) tk_bypass(w, ((ty - mn) >> i) & 1, 1); }
+// last_sig_coeff_{x,y}_prefix / _suffix of a TU (:1045-1086) as straight-line code: the prefix bins of a coordinate are
+// "group index" ones and a closing zero (none when the group is the largest), at most 2 log2(N) - 1 of them, so they are
+// emitted by a fixed-length predicated loop; the two suffixes are adjacent bypass bins and leave as ONE chunk (<= 6 bins;
+// see BitRun below for why bypass bins may be re-chunked).
+struct LastPos { int gx, gy, gmax, cbase, shf, nsuf, suf; };
+HD int lp_group(int t) { return t < 4 ? t : (2 * (31 - clz32((u32)t)) + ((t >> (30 - clz32((u32)t))) & 1)); }   // 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8*8,9*8
+HD LastPos last_pos_prep(int s, int st, int y, int x) {
+    LastPos p;
+    p.cbase = (s == 0) ? 0 : (s == 1) ? 3 : (s == 2) ? 6 : 10; p.shf = (s == 0) ? 0 : 1;
+    const int ty = (st == 2) ? x : y, tx = (st == 2) ? y : x;       // x / y swapped for the vertical scan (:1049-1053)
+    p.gx = lp_group(tx); p.gy = lp_group(ty);
+    p.gmax = 2 * (s + 2) - 1;                                        // group of N-1
+    const int nbx = p.gx > 3 ? (p.gx - 2) >> 1 : 0, nby = p.gy > 3 ? (p.gy - 2) >> 1 : 0;
+    const int sx = tx - ((2 + (p.gx & 1)) << nbx), sy = ty - ((2 + (p.gy & 1)) << nby);
+    p.nsuf = nbx + nby;
+    p.suf = ((nbx ? sx : 0) << nby) | (nby ? sy : 0);
+    return p;
+}
+HD int last_pos_count(const LastPos &p) { return p.gx + (p.gx < p.gmax) + p.gy + (p.gy < p.gmax) + (p.nsuf > 0); }
+// emits tokens cnt.. ; S = log2(TU size) - 2 fixes the loop length.  PRIV as for tokg_a below.
+template <int S, bool PRIV>
+HD int last_pos_emit(const TokOut &o, int cnt, const LastPos &p) {
+    constexpr int gmax = 2 * (S + 2) - 1, shf = (S == 0) ? 0 : 1;
+    for (int i = 0; i < gmax; i++) {
+        const int pr = i <= p.gx, tok = ((CX_LAST_X + p.cbase + (i >> shf)) << 1) | (i < p.gx);
+        if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr);
+        cnt += pr;
+    }
+    for (int i = 0; i < gmax; i++) {
+        const int pr = i <= p.gy, tok = ((CX_LAST_Y + p.cbase + (i >> shf)) << 1) | (i < p.gy);
+        if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr);
+        cnt += pr;
+    }
+    { const int pr = p.nsuf > 0, tok = 0x8000 | (p.nsuf << 8) | p.suf; if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr); cnt += pr; }
+    return cnt;
 }
 
 // Tokens of one coefficient group (the body of the group loop of :1172-1268), as straight-line code over the group's
@@ -1036,7 +1058,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
                 if (nzm != 0) {
                     const int in = T.incg[st][hibit(nzm)];
-                    tk_last_pos(w, 0, st, in >> 2, in & 3);
+                    w.n = last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, in >> 2, in & 3));
                     ls_flush(ls, w);                        // <= 7 tokens stay staged: each part below then fits the row
                     TgB B;
                     w.n = tokg_a<true, true>(w.o, w.n, L, nzm, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
@@ -1047,7 +1069,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                         w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B);
                     }
                     w.n = tokg_end<true, true>(w.o, w.n, B);
-                } else if (P.shape == 3) tk_last_pos(w, 0, st, 0, 0);   // PU pricing codes the residual syntax of an all-zero block (:1515)
+                } else if (P.shape == 3) w.n = last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));   // PU pricing codes the residual syntax of an all-zero block (:1515)
                 ls_end(ls, w, W, c);
                 W.tnz[c] = (nzm != 0);
             }
@@ -1103,9 +1125,13 @@ HD int group_big(const Lv16 &L) {
 // A lane's staged group tokens row[0..c) to tokens o.. of a stream (dst = stream base, 16-byte aligned): dword stores, a
 // 16-bit store at an odd start and for an odd tail.
 #ifndef ROWCAP
-#define ROWCAP 45           // tokens per lane row (23 dwords: odd stride, the 46th slot is the dump slot)
+#define ROWCAP 53           // tokens per lane row (measured on syn q0: 0.003 % of the groups need more); slot 53 is the dump slot
 #endif
-#define ROWSTRIDE 23
+#define ROWSTRIDE 27         // dwords: odd, so the lanes' rows start in different LDS banks; 64 rows = 6912 bytes of the 7168-byte pass buffer
+// slot header rows (cbf_luma + 2 x (2 log2 N - 1) prefix bins + one suffix chunk + dump slot) live in W.pend, which only
+// the lane-private streams of 4x4 TUs use: 16 x 7, 4 x 9 or 1 x 11 dwords <= 144 dwords
+#define HDRCAP_S(S) (2 + 2 * (2 * ((S) + 2) - 1))
+#define HDRSTRIDE_S(S) ((HDRCAP_S(S) + 1 + 1) / 2 | 1)
 HD void row_to_stream(const u16 *row, u16 *dst, int o, int c) {
     const u32a *rw = (const u32a *)row;
     const int odd = o & 1;
@@ -1149,16 +1175,17 @@ HD void p1_run_t(int wave, const P1Args &P) {
         const int st = scan_type_of(N, mode);
         const int gp = cg_pos(st, s, r), by = gp >> 3, bx = gp & 7;
         const int tokn0 = (P.tok && live) ? W.tokn[c] : 0;
+        u32 predw[4] = { 0, 0, 0, 0 };                  // this lane's 4x4 block of the prediction, a packed row per dword (kept in registers until step 5)
         // ---- step 1: prediction and residual
         if (live) {
-            u8 *pp = W.u.p1.pred + sl * NN; i16 *rp = W.u.p1.res + sl * NN;
+            i16 *rp = W.u.p1.res + sl * NN;
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4];
             pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
             for (int yi = 0; yi < 4; yi++) {
                 const int y = by * 4 + yi;
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
-                *(u32a *)(pp + y * N + bx * 4) = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
+                predw[yi] = (u32)pr[yi][0] | (u32)pr[yi][1] << 8 | (u32)pr[yi][2] << 16 | (u32)pr[yi][3] << 24;
                 uint2 rw_;
                 rw_.x = (u32)(((int)(ow & 255) - pr[yi][0]) & 0xFFFF) | (u32)((int)((ow >> 8) & 255) - pr[yi][1]) << 16;
                 rw_.y = (u32)(((int)((ow >> 16) & 255) - pr[yi][2]) & 0xFFFF) | (u32)((int)(ow >> 24) - pr[yi][3]) << 16;
@@ -1216,15 +1243,13 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 const u64 bmask = wave_ballot(big);
                 if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
                 // TU header (cbf_luma, last position) is written by the lane of the last coded group, first in coding order
-                int hdr = 0;
-                if (talk && seg != 0 && has_last) {
-                    TokW w; w.o.tb = (u16 *)0; w.o.pos = 0; w.o.cap = 0; w.o.glob = 0; w.n = 0; w.wr = 0;
-                    const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3));
-                    hdr = w.n;
-                }
+                const int lead = talk && seg != 0 && has_last;
+                const int lin = lead ? T.incg[st][hibit(nzm)] : 0;
+                const LastPos lp = last_pos_prep(s, st, by * 4 + (lin >> 2), bx * 4 + (lin & 3));
+                const int hdr = lead ? 1 + last_pos_count(lp) : 0;
                 // ONE pass: every lane writes its group's tokens into its own LDS row (res/tmp are dead here) and learns their
                 // number; a suffix sum over the candidate's lanes gives the place in the stream; rows leave as dword stores.
-                u16 *row = (u16 *)((u32a *)W.u.p1.res + l * ROWSTRIDE);
+                u16 *row = (u16 *)(W.u.raw + l * ROWSTRIDE);          // the whole pass buffer is dead here: the prediction sits in registers
                 wave_sync_lds();                                            // every lane is done reading tmp
                 int cg = 0;
                 if (talk) {
@@ -1246,10 +1271,19 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 const long long ptk2 = prof_now();
                 if (talk) {
                     TokW w; w.o.tb = base + off; w.o.pos = 0; w.o.cap = 0; w.o.glob = 1; w.n = 0; w.wr = 1;
-                    if (hdr) { const int in = T.incg[st][hibit(nzm)]; tk_bin(w, cbf_ctx, 1); tk_last_pos(w, s, st, by * 4 + (in >> 2), bx * 4 + (in & 3)); }
-                    if (fits) { row_to_stream(row, P.tok + (size_t)c * TOK_CAP, tokn0 + off + hdr, cg); w.n = hdr + cg; }
-                    else if (seg == 0) tk_bin(w, cbf_ctx, 0);
-                    else w.n = tok_write(w.o.tb, w.n, L, nzm, cfg) & 0xFFFF;
+                    if (fits) {
+                        if (lead) {                                         // header tokens: staged in the slot's header row, like the group rows
+                            TokOut ho; ho.tb = (u16 *)((u32a *)&W.pend[0][0] + sl * HDRSTRIDE_S(s)); ho.pos = 0; ho.cap = HDRCAP_S(s); ho.glob = 0;
+                            to_put(ho, 0, (cbf_ctx << 1) | 1);
+                            last_pos_emit<s, true>(ho, 1, lp);
+                            row_to_stream(ho.tb, P.tok + (size_t)c * TOK_CAP, tokn0 + off, hdr);
+                        }
+                        row_to_stream(row, P.tok + (size_t)c * TOK_CAP, tokn0 + off + hdr, cg); w.n = hdr + cg;
+                    } else if (seg == 0) tk_bin(w, cbf_ctx, 0);
+                    else {
+                        if (lead) { tk_bin(w, cbf_ctx, 1); w.n = last_pos_emit<s, false>(w.o, w.n, lp); }
+                        w.n = tok_write(w.o.tb, w.n, L, nzm, cfg) & 0xFFFF;
+                    }
                     if (r == 0) {                                           // the DC lane, last in coding order, pads the final block with idle tokens
                         const int e7 = (tokn0 + total) & 7;
                         for (int i = 0; i < 7; i++) to_put_if(w.o, w.n + i, (int)TOK_IDLE, e7 != 0 && e7 + i < 8);
@@ -1281,14 +1315,13 @@ HD void p1_run_t(int wave, const P1Args &P) {
         wave_sync_lds();
         // ---- step 5: rec = clip8(clip16((itmp * C + 2048) >> 12) + pred) ; SSE                (:515 inverse, :146,:165)
         if (live) {
-            const u8 *pp = W.u.p1.pred + sl * NN;
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 2048;
             mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, CT, by * 4, bx * 4);
             int part = 0;
             for (int r4 = 0; r4 < 4; r4++) {
                 const int y = by * 4 + r4;
-                const u32 pw = *(const u32a *)(pp + y * N + bx * 4);
+                const u32 pw = predw[r4];
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
                 for (int cc = 0; cc < 4; cc++) {
                     const int x = bx * 4 + cc;
