@@ -9,5 +9,5 @@ pass() { local name=$1; shift; timeout 600 rocprofv3 --pmc "$@" -d $O/pmc_${TAG}
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS
 pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 cd $R
-for p in sq1 sq2; do d=$(find $O/pmc_${TAG}_$p -name '*.db' | head -1); [ -n "$d" ] && python tools/rocpd_pmc.py $d 131072; done 2>&1 | awk '$3 ~ /^[0-9]+$/ && !seen[$1]++' > $O/${TAG}_pmc_sq.txt
+for p in sq1 sq2; do d=$(find $O/pmc_${TAG}_$p -name '*.db' | head -1); [ -n "$d" ] && python tools/rocpd_pmc.py $d 131072; done 2>&1 | awk "{k=\$1; last[k]=\$0} END{for (k in last) print last[k]}" | sort > $O/${TAG}_pmc_sq.txt
 cat $O/${TAG}_pmc_sq.txt
