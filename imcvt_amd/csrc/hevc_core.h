@@ -542,51 +542,71 @@ HDN void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int 
 // Per-mode borders of TU k (1..3) of the four-TU shape of the CU at (y0,x0,N): samples inside the CU come
 // from that mode's own reconstruction of TUs < k (:1459,1466), the rest from the tile.  Only the variant the mode
 // predicts from is stored (mode c of size h uses either the unfiltered or the [1 2 1]-filtered border, :274-289).
-struct TuSrc { const u8 *col0, *col2, *row0, *row1, *ab, *lf; int k, h, hl, hbl, ha, har, uc; };
+// Written without lane-divergent branches: which source a sample comes from is an index / pointer select, the [1 2 1]
+// filter is always evaluated and selected by the mode's flag (availability flags and K are wave-uniform).
+struct TuSrc { const u8 *col0, *col2, *row0, *row1, *ab, *lf; int h, hl, hbl, ha, har, uc; };
+template <int K>
 HD int tu_left(const TuSrc &s, int i) {          // unfiltered left / below-left sample i (0..2h-1)
     const int h = s.h;
-    if (s.k == 1) return (i < h) ? s.col0[i] : s.col0[h - 1];
-    if (s.k == 2) return (i < h) ? (s.hl ? s.lf[i * RS] : s.uc) : (s.hbl ? s.lf[i * RS] : (s.hl ? s.lf[(h - 1) * RS] : s.uc));
-    return (i < h) ? s.col2[i] : s.col2[h - 1];
+    if (K == 1) return s.col0[imin(i, h - 1)];
+    if (K == 3) return s.col2[imin(i, h - 1)];
+    const int inside = i < h;
+    const int idx = (inside | s.hbl) ? i : h - 1, use = inside ? s.hl : (s.hbl | s.hl);      // rows beyond the tile are never addressed: idx stays below h without below-left
+    const int v = s.lf[idx * RS];
+    return use ? v : s.uc;
 }
+template <int K>
 HD int tu_above(const TuSrc &s, int i) {         // unfiltered above / above-right sample i
     const int h = s.h;
-    if (s.k == 1) return (i < h) ? (s.ha ? s.ab[i] : s.uc) : (s.har ? s.ab[i] : (s.ha ? s.ab[h - 1] : s.uc));
-    if (s.k == 2) return (i < h) ? s.row0[i] : s.row1[i - h];
-    return (i < h) ? s.row1[i] : s.row1[h - 1];
+    if (K == 2) { const u8 *q = (i < h) ? s.row0 + i : s.row1 + (i - h); return *q; }
+    if (K == 3) return s.row1[imin(i, h - 1)];
+    const int inside = i < h;
+    const int idx = (inside | s.har) ? i : h - 1, use = inside ? s.ha : (s.har | s.ha);
+    const int v = s.ab[idx];
+    return use ? v : s.uc;
 }
-HDN void border_tu_split(int wave, int N, int y0, int x0, int k, int hl, int hbl, int ha, int har) {
+template <int K>
+HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int har) {
     const int h = N / 2, n2 = N;   // 2*h entries per side
     LANES(l) {
-        for (int e = l; e < NMODE * n2; e += 64) {
-            const int c = e / n2, i = e - c * n2;
-            BorderS &b = SM.X.bc[c];
-            TuSrc s;
-            s.k = k; s.h = h; s.hl = hl; s.hbl = hbl; s.ha = ha; s.har = har;
-            s.col0 = SM.X.t3col[c][0]; s.col2 = SM.X.t3col[c][2]; s.row0 = SM.X.t3row[c][0]; s.row1 = SM.X.t3row[c][1];
-            s.ab = &SM.rec[y0][x0 + h + 1];                       // row y0-1, starting at column x0+h
-            s.lf = &SM.rec[y0 + h + 1][x0];                       // column x0-1, starting at row y0+h
-            s.uc = (k == 1) ? (ha ? s.ab[-1] : s.col0[0]) : (k == 2) ? (hl ? s.lf[-RS] : s.row0[0]) : s.row0[h - 1];
-            const int filt = uses_filtered(h, c);
-            int lv_ = tu_left(s, i), av_ = tu_above(s, i);
-            if (filt && i != n2 - 1) {                             // [1 2 1]/4, ends unfiltered (:246-256)
-                const int lp = (i == 0) ? s.uc : tu_left(s, i - 1), ap = (i == 0) ? s.uc : tu_above(s, i - 1);
-                lv_ = (2 + 2 * lv_ + lp + tu_left(s, i + 1)) >> 2;
-                av_ = (2 + 2 * av_ + ap + tu_above(s, i + 1)) >> 2;
-            }
-            b.l[i] = (u8)lv_; b.a[i] = (u8)av_;
-            if (i == 0) {
-                b.c = (u8)(filt ? (2 + tu_left(s, 0) + tu_above(s, 0) + 2 * s.uc) >> 2 : s.uc);
-                b.l[n2] = 0; b.a[n2] = 0;
-                if (c == 1) {                                       // only the DC mode reads dc (unfiltered border)
-                    int dc = h;
-                    for (int j = 0; j < h; j++) dc += tu_left(s, j) + tu_above(s, j);
-                    b.dc = (i16)(dc / (2 * h));
+        NOUNROLL
+        for (int e0 = 0; e0 < NMODE * n2; e0 += 64) {
+            const int e = e0 + l;
+            if (e < NMODE * n2) {
+                const int c = e / n2, i = e - c * n2;
+                BorderS &b = SM.X.bc[c];
+                TuSrc s;
+                s.h = h; s.hl = hl; s.hbl = hbl; s.ha = ha; s.har = har;
+                s.col0 = SM.X.t3col[c][0]; s.col2 = SM.X.t3col[c][2]; s.row0 = SM.X.t3row[c][0]; s.row1 = SM.X.t3row[c][1];
+                s.ab = &SM.rec[y0][x0 + h + 1];                       // row y0-1, starting at column x0+h
+                s.lf = &SM.rec[y0 + h + 1][x0];                       // column x0-1, starting at row y0+h
+                s.uc = (K == 1) ? (ha ? s.ab[-1] : s.col0[0]) : (K == 2) ? (hl ? s.lf[-RS] : s.row0[0]) : s.row0[h - 1];
+                const int filt = uses_filtered(h, c);
+                const int lc = tu_left<K>(s, i), ac = tu_above<K>(s, i);
+                const int lp = (i == 0) ? s.uc : tu_left<K>(s, imax(i - 1, 0)), ap = (i == 0) ? s.uc : tu_above<K>(s, imax(i - 1, 0));
+                const int ln = tu_left<K>(s, imin(i + 1, n2 - 1)), an = tu_above<K>(s, imin(i + 1, n2 - 1));
+                const int fsel = filt & (i != n2 - 1);                 // [1 2 1]/4, ends unfiltered (:246-256)
+                b.l[i] = (u8)(fsel ? (2 + 2 * lc + lp + ln) >> 2 : lc);
+                b.a[i] = (u8)(fsel ? (2 + 2 * ac + ap + an) >> 2 : ac);
+                if (i == 0) {
+                    b.c = (u8)(filt ? (2 + lc + ac + 2 * s.uc) >> 2 : s.uc);
+                    b.l[n2] = 0; b.a[n2] = 0;
+                    if (c == 1) {                                       // only the DC mode reads dc (unfiltered border)
+                        int dc = h;
+                        for (int j = 0; j < h; j++) dc += tu_left<K>(s, j) + tu_above<K>(s, j);
+                        b.dc = (i16)(dc / (2 * h));
+                    }
                 }
             }
         }
     }
     wave_sync();
+}
+HDN void border_tu_split(int wave, int N, int y0, int x0, int k, int hl, int hbl, int ha, int har) {
+    (void)wave;
+    if (k == 1) border_tu_split_k<1>(N, y0, x0, hl, hbl, ha, har);
+    else if (k == 2) border_tu_split_k<2>(N, y0, x0, hl, hbl, ha, har);
+    else border_tu_split_k<3>(N, y0, x0, hl, hbl, ha, har);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1450,8 +1470,19 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
             for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
                 code_token_q(a, cx, lm->lq, qn, tok_of(cur, j));
             NOUNROLL
-            for (int i = 0; WAVE_ANY(i < qn); i++)          // the bytes this block pushed out of `low`
-                if (i < qn) lead_step(a, sink, (int)lm->lq[i]);
+            for (int i = 0; WAVE_ANY(i < qn); i++) {        // the bytes this block pushed out of `low` (:863-878): the common case is
+                const int act = i < qn;                     // straight-line (one byte buffered, no 0xFF run, no emulation prevention)
+                const int lead = (int)lm->lq[i];
+                const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
+                const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
+                u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : (u8 *)&lm->lq[LEADQ - 1];
+                *dst = (u8)v1;
+                a.cnt += fast;
+                a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
+                a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
+                const int rare = act & !fast;
+                if (WAVE_ANY(rare)) { if (rare) carry_rare(a, sink, lead); }
+            }
         }
 #ifdef IMCVT_HOSTEMU
         cur = nxt;
