@@ -16,7 +16,13 @@
 #ifdef IMCVT_JLS_HOST
 #define JD static inline
 #define JHD static inline
+#define JLS_LDS
+#define JLS_GLB
 #else
+// Row buffers and contexts live in LDS, the output in global memory: saying so keeps the walker on ds_* / global_*
+// instructions (a generic pointer would make every access a FLAT operation that waits on both memory counters).
+#define JLS_LDS __attribute__((address_space(3)))
+#define JLS_GLB __attribute__((address_space(1)))
 #define JD __device__ __forceinline__
 #define JHD __host__ __device__ __forceinline__        // file framing is also done by the host shim (RGB: three scans, one frame)
 #endif
@@ -53,10 +59,10 @@ JD int grad(const Par &p, int v) {                      // :67-76
 
 // MSB-first bit packer with the JPEG-LS stuffing rule: the byte after a 0xFF carries 7 bits (:162-174)
 struct Bits {
-    uint8_t *out; long long len;
+    JLS_GLB uint8_t *out; long long len;
     unsigned long long acc; int cnt, cap;              // cnt pending bits in acc (low end), cap = bits the next byte takes
 };
-JD void bits_init(Bits &w, uint8_t *out) { w.out = out; w.len = 0; w.acc = 0; w.cnt = 0; w.cap = 8; }
+JD void bits_init(Bits &w, uint8_t *out) { w.out = (JLS_GLB uint8_t *)out; w.len = 0; w.acc = 0; w.cnt = 0; w.cap = 8; }
 JD void bits_drain(Bits &w) {
     while (w.cnt >= w.cap) {
         const unsigned v = (unsigned)(w.acc >> (w.cnt - w.cap)) & ((1u << w.cap) - 1u);
@@ -91,15 +97,18 @@ struct Plane {
     Par p; Bits bw; Ctx ri[2];
     int run_idx, w, prev2_first;                        // prev2_first: reconstruction of (y-2, 0)
 };
-template <class CtxMem>
+typedef JLS_LDS Ctx *CtxMem;
+typedef JLS_LDS uint8_t *RowMem;
+typedef const JLS_LDS uint8_t *CRowMem;
+JD void ctx_store(CtxMem p, const Ctx &c) { p->a = c.a; p->b = c.b; p->c = c.c; p->n = c.n; }
+JD Ctx ctx_load(CtxMem p) { Ctx c; c.a = p->a; c.b = p->b; c.c = p->c; c.n = p->n; return c; }
 JD void plane_begin(Plane &S, CtxMem cx, int w, int near, uint8_t *out) {
     S.p = make_par(near); S.w = w; S.run_idx = 0; S.prev2_first = 0;
     bits_init(S.bw, out);
-    for (int i = 0; i < 364; i++) { Ctx c; c.a = S.p.a_init; c.b = 0; c.c = 0; c.n = 1; cx[i] = c; }
+    for (int i = 0; i < 364; i++) { Ctx c; c.a = S.p.a_init; c.b = 0; c.c = 0; c.n = 1; ctx_store(cx + i, c); }
     for (int i = 0; i < 2; i++) { S.ri[i].a = S.p.a_init; S.ri[i].b = 0; S.ri[i].c = 0; S.ri[i].n = 1; }
 }
-template <class CtxMem>
-JD void plane_row(Plane &S, CtxMem cx, int y, const uint8_t *src, uint8_t *rec, const uint8_t *prev) {
+JD void plane_row(Plane &S, CtxMem cx, int y, CRowMem src, RowMem rec, CRowMem prev) {
     const Par &p = S.p;
     const int w = S.w, near = p.near;
     int in_run = 0, run_len = 0;
@@ -143,7 +152,7 @@ JD void plane_row(Plane &S, CtxMem cx, int y, const uint8_t *src, uint8_t *rec, 
             r.n++;
             S.ri[t] = r;
         } else {                                                                   // regular mode (:346-394)
-            Ctx r = cx[q - 1];
+            Ctx r = ctx_load(cx + (q - 1));
             run_len = 0;
             const int lo = imin(a, b), hi = imax(a, b);
             const int med = c >= hi ? lo : c <= lo ? hi : a + b - c;               // :87-94
@@ -163,7 +172,7 @@ JD void plane_row(Plane &S, CtxMem cx, int y, const uint8_t *src, uint8_t *rec, 
             if (r.b <= -r.n) { r.b = imax(r.b + r.n, -r.n + 1); r.c--; }
             else if (r.b > 0) { r.b = imin(r.b - r.n, 0); r.c++; }
             r.c = clampi(r.c, -128, 127);
-            cx[q - 1] = r;
+            ctx_store(cx + (q - 1), r);
         }
         rec[x] = (uint8_t)rx;
         c = b; b = d; d = d_next; a = rx; v = v_next;

@@ -23,7 +23,7 @@ struct PlaneJob {
 __global__ __launch_bounds__(JLS_THREADS) void jls_encode_planes(const PlaneJob *jobs, int njobs, int *counter) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int next;
-    jls::Ctx *cx = (jls::Ctx *)lds;                                   // 364 contexts, 16 bytes each
+    jls::CtxMem cx = (jls::CtxMem)(JLS_LDS uint8_t *)lds;              // 364 contexts, 16 bytes each
     const int tid = (int)threadIdx.x;
     for (;;) {
         if (tid == 0) next = atomicAdd(counter, 1);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(JLS_THREADS) void jls_encode_planes(const PlaneJob 
         if (j >= njobs) break;
         const PlaneJob job = jobs[j];
         const int w = job.w, rs = (w + 1 + 15) & ~15;                  // row buffers: w + 1 samples, 16-byte multiples
-        uint8_t *src = lds + 364 * sizeof(jls::Ctx), *rec = src + rs, *prev = rec + rs;
+        jls::RowMem src = (jls::RowMem)lds + 364 * sizeof(jls::Ctx), rec = src + rs, prev = rec + rs;
         jls::Plane S;
         int hdr = 0;
         if (tid == 0) {
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(JLS_THREADS) void jls_encode_planes(const PlaneJob 
             jls::plane_begin(S, cx, w, job.near, job.out + hdr);
         }
         for (int y = 0; y < job.h; y++) {
-            { uint8_t *t = prev; prev = rec; rec = t; }               // last row's reconstruction becomes the row above
-            const uint8_t *g = job.src + (size_t)y * w * job.stride;
+            { jls::RowMem t = prev; prev = rec; rec = t; }              // last row's reconstruction becomes the row above
+            const JLS_GLB uint8_t *g = (const JLS_GLB uint8_t *)job.src + (size_t)y * w * job.stride;
             for (int x = tid; x < w; x += JLS_THREADS) src[x] = g[(size_t)x * job.stride];      // 64 consecutive samples per instruction
             __syncthreads();
             if (tid == 0) jls::plane_row(S, cx, y, src, rec, prev);
