@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 KAT = kat_entries()
 SMALL = [e for e in KAT if e["input"].get("w", 0) < 1920]
 LARGE = [e for e in KAT if e["input"].get("w", 0) == 1920]
+UHD = [e for e in KAT if e["input"].get("w", 0) == 3840]
 
 
 @pytest.fixture(scope="module")
@@ -93,6 +94,16 @@ def test_full_hd_frames_golden_digest(amd):
         assert dims == (1088, 1920)
         assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"], kat_id(e)
         assert hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
+def test_4k_frame_golden_digest(amd):
+    """BASELINE config 3: one 3840x2160 frame (8160 CTUs, one workgroup walks them serially) against the reference's digest."""
+    from oracle import synth
+    e = UHD[0]
+    s, r, dims = amd.HEVCImageEncoder(synth.syn(3840, 2160, e["input"]["arg"]), e["qpd6"])
+    assert dims == (2176, 3840)
+    assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"]
+    assert hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
 def test_batch_equals_single_and_is_order_independent(amd):
