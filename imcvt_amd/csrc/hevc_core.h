@@ -132,7 +132,6 @@ enum { CX_SPLIT_CU = 0, CX_PART = 3, CX_PREV_INTRA = 4, CX_CHROMA_PRED = 5, CX_S
 // ---------------------------------------------------------------------------------------------------
 struct Tables {
     i8  C[1360];           // forward matrices, row-major [i][k]; offsets {0,16,80,336} for N=4,8,16,32   (:391-464)
-    i8  CT[1360];          // their transposes [k][i]
     u8  cgpos_d[4][64];    // diagonal: [log2N-2][g] -> (gy<<3)|gx, coefficient-group scan order           (:1126-1150)
     u8  cgrank_d[4][64];   // inverse: [s][gy*8+gx] -> g
     u8  cgpos_hv[2][4];    // horizontal / vertical group order of an 8x8 TU (4 groups); 4x4 TUs have one group
@@ -633,17 +632,19 @@ HD int lo16(u32 w) { return (int)(i16)(w & 0xFFFFu); }
 HD int hi16(u32 w) { return (int)w >> 16; }
 
 // acc[r][c] += sum_kk M[row0+r][k0+kk] * X[k0+kk][col0+c]      (M: i8 matrix rows, X: i16 rows of stride N)
-template <int N>
-HD void mac_MX(int acc[4][4], const i8 *M, const i16 *X, int row0, int col0) {
+// TR: M is the TRANSPOSE of the stored matrix C (M[i][k] = C[k][i]) — the same 4x4 byte block of C is fetched as four row
+// words and indexed the other way round, so no transposed copy of the matrices is kept in LDS.
+template <int N, bool TR>
+HD void mac_MX(int acc[4][4], const i8 *C, const i16 *X, int row0, int col0) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
-        for (int r = 0; r < 4; r++) mw[r] = *(const u32a *)(M + (row0 + r) * N + k0);
+        for (int r = 0; r < 4; r++) mw[r] = TR ? *(const u32a *)(C + (k0 + r) * N + row0) : *(const u32a *)(C + (row0 + r) * N + k0);
         for (int kk = 0; kk < 4; kk++) {
             const uint2 xw = *(const uint2 *)(X + (k0 + kk) * N + col0);
             const int x0 = lo16(xw.x), x1 = hi16(xw.x), x2 = lo16(xw.y), x3 = hi16(xw.y);
             for (int r = 0; r < 4; r++) {
-                const int m = sx8(mw[r], kk);
+                const int m = TR ? sx8(mw[kk], r) : sx8(mw[r], kk);
                 acc[r][0] += m * x0; acc[r][1] += m * x1; acc[r][2] += m * x2; acc[r][3] += m * x3;
             }
         }
@@ -663,18 +664,18 @@ HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0) {
         }
     }
 }
-// same with i16 rows
+// acc[r][c] += sum_kk Y[row0+r][k0+kk] * C[k0+kk][col0+c]      (Y: i16 rows; the multiplier is C itself, i.e. the transpose of mac_YM32's)
 template <int N>
-HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *M, int row0, int col0) {
+HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *C, int row0, int col0) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
-        for (int c = 0; c < 4; c++) mw[c] = *(const u32a *)(M + (col0 + c) * N + k0);
+        for (int kk = 0; kk < 4; kk++) mw[kk] = *(const u32a *)(C + (k0 + kk) * N + col0);
         for (int r = 0; r < 4; r++) {
             const uint2 yw = *(const uint2 *)(Y + (row0 + r) * N + k0);
             const int y0 = lo16(yw.x), y1 = hi16(yw.x), y2 = lo16(yw.y), y3 = hi16(yw.y);
             for (int c = 0; c < 4; c++)
-                acc[r][c] += y0 * sx8(mw[c], 0) + y1 * sx8(mw[c], 1) + y2 * sx8(mw[c], 2) + y3 * sx8(mw[c], 3);
+                acc[r][c] += y0 * sx8(mw[0], c) + y1 * sx8(mw[1], c) + y2 * sx8(mw[2], c) + y3 * sx8(mw[3], c);
         }
     }
 }
@@ -1181,7 +1182,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
     constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
-    const i8 *C = T.C + mat_off(s), *CT = T.CT + mat_off(s);
+    const i8 *C = T.C + mat_off(s);
     const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
     constexpr int a1 = s + 1, ra = 1 << a1 >> 1, rb = 1 << (a1 + 7) >> 1;
     const QConst Q = qconst<s>(P.q);
@@ -1217,7 +1218,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
         if (live) {
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = ra;
-            mac_MX<N>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
+            mac_MX<N, false>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
             i32 *tp = W.u.p1.tmp + sl * NN;
             for (int r4 = 0; r4 < 4; r4++) {
                 int4 o; o.x = acc[r4][0] >> a1; o.y = acc[r4][1] >> a1; o.z = acc[r4][2] >> a1; o.w = acc[r4][3] >> a1;
@@ -1323,7 +1324,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
         if (live) {
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 64;
-            mac_MX<N>(acc, CT, W.u.p1.res + sl * NN, by * 4, bx * 4);
+            mac_MX<N, true>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
             i16 *ip = (i16 *)W.u.p1.tmp + sl * NN;       // tmp (i32) was last read in step 3; reuse it as i16
             for (int r4 = 0; r4 < 4; r4++) {
                 uint2 o;
@@ -1337,7 +1338,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
         if (live) {
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 2048;
-            mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, CT, by * 4, bx * 4);
+            mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
             int part = 0;
             for (int r4 = 0; r4 < 4; r4++) {
                 const int y = by * 4 + r4;

@@ -49,7 +49,7 @@ inline void build_tables(Tables &T, ColdTables &K) {
         const int n = 4 << s, off = s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336;
         for (int i = 0; i < n; i++) for (int k = 0; k < n; k++) {
             const int v = (s == 0) ? kDst4[i * 4 + k] : dct_entry(n, i, k);
-            T.C[off + i * n + k] = (i8)v; T.CT[off + k * n + i] = (i8)v;
+            T.C[off + i * n + k] = (i8)v;
         }
     }
     // in-group 4x4 patterns: up-right diagonal, horizontal, vertical
