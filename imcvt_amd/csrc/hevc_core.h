@@ -270,7 +270,7 @@ struct alignas(16) Shm {
 #endif
     FourTU X;
     alignas(4) u8 cx0[CTX_STRIDE];       // fresh context states of this frame's qpd6 (:1505)
-    alignas(16) u8 wraw[2 * sizeof(WaveMem) + WAVE2_BYTES];   // wave slices; the last (4x4-only) one is truncated
+    alignas(16) u8 wraw[NWAVES * sizeof(WaveMem)];   // wave slices (wave 2 runs full pipeline passes for the 16x16 / 32x32 CUs too)
 };
 
 // The workgroup's LDS image is one file-scope object, so non-inlined callees still address it with ds_* ops.
@@ -565,13 +565,13 @@ HD int tu_above(const TuSrc &s, int i) {         // unfiltered above / above-rig
     return use ? v : s.uc;
 }
 template <int K>
-HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int har) {
+HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int har, int c_lo, int c_hi) {
     const int h = N / 2, n2 = N;   // 2*h entries per side
     LANES(l) {
         NOUNROLL
-        for (int e0 = 0; e0 < NMODE * n2; e0 += 64) {
+        for (int e0 = c_lo * n2; e0 < c_hi * n2; e0 += 64) {
             const int e = e0 + l;
-            if (e < NMODE * n2) {
+            if (e < c_hi * n2) {
                 const int c = e / n2, i = e - c * n2;
                 BorderS &b = SM.X.bc[c];
                 TuSrc s;
@@ -601,11 +601,10 @@ HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int ha
     }
     wave_sync();
 }
-HDN void border_tu_split(int wave, int N, int y0, int x0, int k, int hl, int hbl, int ha, int har) {
-    (void)wave;
-    if (k == 1) border_tu_split_k<1>(N, y0, x0, hl, hbl, ha, har);
-    else if (k == 2) border_tu_split_k<2>(N, y0, x0, hl, hbl, ha, har);
-    else border_tu_split_k<3>(N, y0, x0, hl, hbl, ha, har);
+HDN void border_tu_split(int N, int y0, int x0, int k, int hl, int hbl, int ha, int har, int c_lo, int c_hi) {      // modes c_lo .. c_hi-1
+    if (k == 1) border_tu_split_k<1>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
+    else if (k == 2) border_tu_split_k<2>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
+    else border_tu_split_k<3>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -622,8 +621,10 @@ struct P1Args {
     int out_kind;        // what to keep of the reconstruction
     int only_mode;       // -1: all 35 modes, else just this one (winner reconstruction)
     int shape;           // CU shape the TU belongs to (0: one TU, 1: four TUs, 2: NxN, 3: PU pricing) — picks the cbf_luma context
-    u16 *tok;            // the wave's token streams ([TOK_SLOTS][TOK_CAP]); null: no tokens (winner reconstruction)
+    u16 *tok;            // the OWNER's token streams ([TOK_SLOTS][TOK_CAP]); null: no tokens (winner reconstruction)
     int q;
+    int own;             // wave whose candidate set this is (its tokn / tnz / sse arrays and token streams); the executing wave lends lanes and its pass buffer
+    int c_lo, c_hi;      // candidates (modes) handled by this call
 };
 
 // sign-extended byte kk of a packed word / i16 halves of a packed word
@@ -1183,19 +1184,20 @@ HD void p1_run_t(int wave, const P1Args &P) {
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
     const i8 *C = T.C + mat_off(s);
-    const int ncand = (P.only_mode >= 0) ? 1 : NMODE;
+    WaveMem &WO = WM(P.own);
+    const int ncand = P.c_hi;
     constexpr int a1 = s + 1, ra = 1 << a1 >> 1, rb = 1 << (a1 + 7) >> 1;
     const QConst Q = qconst<s>(P.q);
 
     NOUNROLL
-    for (int c0 = 0; c0 < ncand; c0 += G) {
+    for (int c0 = P.c_lo; c0 < ncand; c0 += G) {
       LANES(l) {
         // lane <-> coefficient group: slot sl of this pass, group of scan rank r of that candidate's TU
         const int sl = l / lpc, r = l % lpc, c = c0 + sl, live = c < ncand;
         const int mode = (P.only_mode >= 0) ? P.only_mode : (live ? c : 0);
         const int st = scan_type_of(N, mode);
         const int gp = cg_pos(st, s, r), by = gp >> 3, bx = gp & 7;
-        const int tokn0 = (P.tok && live) ? W.tokn[c] : 0;
+        const int tokn0 = (P.tok && live) ? WO.tokn[c] : 0;
         u32 predw[4] = { 0, 0, 0, 0 };                  // this lane's 4x4 block of the prediction, a packed row per dword (kept in registers until step 5)
         // ---- step 1: prediction and residual
         if (live) {
@@ -1308,7 +1310,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                     if (r == 0) {                                           // the DC lane, last in coding order, pads the final block with idle tokens
                         const int e7 = (tokn0 + total) & 7;
                         for (int i = 0; i < 7; i++) to_put_if(w.o, w.n + i, (int)TOK_IDLE, e7 != 0 && e7 + i < 8);
-                        W.tokn[c] = tokn0 + total; W.tnz[c] = (seg != 0);
+                        WO.tokn[c] = tokn0 + total; WO.tnz[c] = (seg != 0);
                     }
                 }
                 prof_add(PF_T_HDR, ptk2);
@@ -1356,7 +1358,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                     }
                 }
             }
-            if (P.only_mode < 0) lds_add(&W.sse[c], part);
+            if (P.only_mode < 0) lds_add(&WO.sse[c], part);
         }
         wave_sync_lds();
       }

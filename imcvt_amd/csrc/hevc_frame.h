@@ -30,50 +30,68 @@ HD u8 *lane_bytes(const Scratch &sc, int wave, int lane) { return sc.bytes + ((s
 HD int nb_size(int uy, int ux) { return SM.mapsz[uy + 1][ux + 1]; }
 HD int nb_mode(const int uy, int ux) { return SM.mapmode[uy + 1][ux + 1]; }
 
-// ---- one candidate set: 2Nx2N with one TU (shape 0) or four TUs (shape 1); wave-uniform call --------------------
-HDN void eval_2Nx2N(int wave, int depth, int shape, int N, int y0, int x0, int avm) {
+// ---- the 2Nx2N candidate sets of a CU: one TU (shape 0, owned by wave 0) and four TUs (shape 1, owned by wave 1) -------------
+// Wave-uniform call.  An 8x8 CU is evaluated by the two owners alone (wave 2 runs the NxN chain meanwhile).  For a 16x16 /
+// 32x32 CU all three waves call this: wave 2, which has no candidate set of its own there, runs the pipeline passes of the
+// upper modes of BOTH sets (modes are independent; a four-TU mode's TU chain stays inside one wave), writing tokens, SSE
+// and token counts straight into the owners' arrays; the owners then price all 35 of their candidates.
+struct P1Item { int own, shape, lo, hi; };
+HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? 22 : 26) : (shape == 0 ? 24 : 32); }   // passes come out balanced over the three waves
+HDN void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
-    const int q = F.job.q, h = N / 2;
-    u16 *tok = wave_tok(F.sc, wave);
+    const int q = F.job.q, h = N / 2, big = N >= 16;
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
     const int uy = y0 >> 2, ux = x0 >> 2;
     const int big_l = N > nb_size(uy, ux - 1), big_a = N > nb_size(uy - 1, ux);
     const int ml = nb_mode(uy, ux - 1), ma = nb_mode(uy - 1, ux);
-    LANES(l) {
-        if (l < NMODE) {                                // every candidate's stream opens with its coding_unit header
-            W.sse[l] = 0; W.tokn[l] = 0;
-            blk_idle((u32a *)W.pend[l]);
-            CuHdr J;
-            J.N = N; J.shape = shape; J.ctx_split = (N >= 16) ? CX_SPLIT_CU + big_l + big_a : -1;
-            J.mode[0] = l; J.ml[0] = ml; J.ma[0] = ma;
-            LaneStream ls;
-            TokW w = ls_begin(ls, W, l, lane_row(W, l), tok + (size_t)l * TOK_CAP);
-            tk_cu_header(w, J);
-            ls_end(ls, w, W, l);
+    if (wave < 2) {
+        u16 *tok = wave_tok(F.sc, wave);
+        LANES(l) {
+            if (l < NMODE) {                            // every candidate's stream opens with its coding_unit header
+                W.sse[l] = 0; W.tokn[l] = 0;
+                blk_idle((u32a *)W.pend[l]);
+                CuHdr J;
+                J.N = N; J.shape = wave; J.ctx_split = (N >= 16) ? CX_SPLIT_CU + big_l + big_a : -1;
+                J.mode[0] = l; J.ml[0] = ml; J.ma[0] = ma;
+                LaneStream ls;
+                TokW w = ls_begin(ls, W, l, lane_row(W, l), tok + (size_t)l * TOK_CAP);
+                tk_cu_header(w, J);
+                ls_end(ls, w, W, l);
+            }
         }
     }
-    wave_sync_lds();
+    if (big) wg_sync_p(); else wave_sync_lds();         // wave 2 starts from the owners' header counts
+    P1Item it[2]; int nit = 1;
+    if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = NMODE; }
+    else if (wave < 2) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = split_mode(N, wave); }
+    else { nit = 2; for (int i = 0; i < 2; i++) { it[i].own = i; it[i].shape = i; it[i].lo = split_mode(N, i); it[i].hi = NMODE; } }
     P1Args P;
-    P.q = q; P.only_mode = -1; P.shape = shape; P.tok = tok;
+    P.q = q; P.only_mode = -1;
     long long pt = prof_now();
-    const int ntu = (shape == 0) ? 1 : 4;
-    for (int k = 0; k < ntu; k++) {
-        if (shape == 0) {
-            border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
-            P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
-        } else {
-            const Avail ca = child_avail(av, k);
-            const int yk = y0 + (k >> 1) * h, xk = x0 + (k & 1) * h;
-            if (k == 0) border_from_tile(wave, h, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
-            else border_tu_split(wave, N, y0, x0, k, av.l, av.bl, av.a, av.ar);
-            P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
+    for (int ii = 0; ii < nit; ii++) {
+        const int shape = it[ii].shape;
+        P.own = it[ii].own; P.c_lo = it[ii].lo; P.c_hi = it[ii].hi; P.shape = shape; P.tok = wave_tok(F.sc, it[ii].own);
+        const int ntu = (shape == 0) ? 1 : 4;
+        for (int k = 0; k < ntu; k++) {
+            if (shape == 0) {
+                border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
+                P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
+            } else {
+                const Avail ca = child_avail(av, k);
+                const int yk = y0 + (k >> 1) * h, xk = x0 + (k & 1) * h;
+                if (k == 0) border_from_tile(wave, h, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
+                else border_tu_split(N, y0, x0, k, av.l, av.bl, av.a, av.ar, P.c_lo, P.c_hi);
+                P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
+            }
+            p1_run(wave, P);
         }
-        p1_run(wave, P);
     }
-    prof_add(shape == 0 ? (N == 32 ? PF_P1_32 : N == 16 ? PF_P1_16 : PF_P1_8) : (N == 32 ? PF_P1_16 : N == 16 ? PF_P1_8 : PF_P1_4), pt);
-    wave_sync();                                        // the tokens are in memory
+    prof_add(wave == 2 ? PF_P1_4 : wave == 0 ? (N == 32 ? PF_P1_32 : N == 16 ? PF_P1_16 : PF_P1_8) : (N == 32 ? PF_P1_16 : N == 16 ? PF_P1_8 : PF_P1_4), pt);
+    if (big) wg_sync_p(); else wave_sync();             // the tokens are in memory
+    if (wave >= 2) return;
     // trial coders: lane m prices mode m from the CU's entry state
+    u16 *tok = wave_tok(F.sc, wave);
     const RdW rw = rd_weights(q);
     pt = prof_now();
     LANES(l) {
@@ -112,6 +130,7 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
         border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
         P1Args P;
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
+        P.own = wave; P.c_lo = 0; P.c_hi = NMODE;
         p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         wave_sync();
@@ -191,9 +210,8 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES(w) {
-        if (w == 0) eval_2Nx2N(0, depth, 0, N, y0, x0, avm);
-        else if (w == 1) eval_2Nx2N(1, depth, 1, N, y0, x0, avm);
-        else if (w == 2 && N == 8) eval_NxN(2, y0, x0, avm);
+        if (w < 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
+        else eval_NxN(2, y0, x0, avm);
     }
     wg_sync_p();
     WAVES(w) LANES(l) {
@@ -239,6 +257,7 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
                     const int wave = 0;
                     P1Args P;
                     P.q = F.job.q; P.only_mode = mode; P.shape = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.tok = (u16 *)0;
+                    P.own = 0; P.c_lo = 0; P.c_hi = 1;
                     if (kind == 1) {
                         border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
                         P.N = N; P.y0 = y0; P.x0 = x0;
