@@ -36,7 +36,13 @@ HD int nb_mode(const int uy, int ux) { return SM.mapmode[uy + 1][ux + 1]; }
 // upper modes of BOTH sets (modes are independent; a four-TU mode's TU chain stays inside one wave), writing tokens, SSE
 // and token counts straight into the owners' arrays; the owners then price all 35 of their candidates.
 struct P1Item { int own, shape, lo, hi; };
-HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? 22 : 26) : (shape == 0 ? 24 : 32); }   // passes come out balanced over the three waves
+#ifndef SPL32_0
+#define SPL32_0 23
+#define SPL32_1 24
+#define SPL16_0 24
+#define SPL16_1 32
+#endif
+HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? SPL32_0 : SPL32_1) : (shape == 0 ? SPL16_0 : SPL16_1); }   // passes come out balanced over the three waves
 HDN void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
