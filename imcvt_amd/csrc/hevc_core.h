@@ -890,7 +890,7 @@ HDN EscRet tok_escape(TokOut o, int k0, int wr, int v, int k, u32 acc, int nb) {
         while (len > 0) {
             const int take = imin(len, 8 - nb); len -= take;
             acc = (acc << take) | ((val >> len) & ((1u << take) - 1u)); nb += take;
-            if (nb == 8) { tk_chunk(w, (int)acc, 8); acc = 0; nb = 0; }
+            if (nb == 8) { tk_chunk(w, (int)(acc & 0xFFu), 8); acc = 0; nb = 0; }
         }
     }
     EscRet e; e.ntok = w.n - k0; e.acc = acc; e.nb = nb;
@@ -959,12 +959,13 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
             const int r = mg - (j < 8 ? base2 : 1);
             const int doit = isnz & (r >= 0), small = r < (3 << rice);
             const int pp = r >> rice;                  // prefix of pp ones and a zero (pp <= 2), then rice suffix bins: at most 7 bins
-            const int len = (doit & small) ? pp + 1 + rice : 0;
-            const u32 bins = ((((2u << pp) - 2u) << rice) | ((u32)r & ((1u << rice) - 1u))) & ((1u << len) - 1u);
-            acc = (acc << len) | bins; nb += len;
+            const int ds = doit & small;
+            const int len = ds ? pp + 1 + rice : 0;
+            const u32 bins = ds ? ((((2u << pp) - 2u) << rice) | ((u32)r & ((1u << rice) - 1u))) : 0u;
+            acc = (acc << len) | bins; nb += len;      // bits above the nb pending ones are stale (already emitted) and never looked at
             const int full = nb >= 8;
             TK_EMIT(full, tk_chunk_word((int)(acc >> (nb & 7)) & 0xFF, 8));
-            nb &= 7; acc &= (1u << nb) - 1u;           // (nb was at most 7 + 7)
+            nb &= 7;                                   // (nb was at most 7 + 7)
             if (doit & !small) { const EscRet e = tok_escape(o, cnt, WR, r, rice, acc, nb); cnt += e.ntok; acc = e.acc; nb = e.nb; }
             rice = (doit & (mg > (3 << rice))) ? imin(rice + 1, 4) : rice;
             base2 = (isnz & (mg >= 2)) ? 2 : base2;
@@ -977,7 +978,7 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
 // the run's last, partial chunk
 template <bool WR, bool PRIV>
 HD int tokg_end(const TokOut &o, int cnt, TgB &B) {
-    TK_EMIT(B.run.nb > 0, tk_chunk_word((int)B.run.acc, B.run.nb));
+    TK_EMIT(B.run.nb > 0, tk_chunk_word((int)(B.run.acc & ((1u << B.run.nb) - 1u)), B.run.nb));
     return cnt;
 }
 #undef TK_EMIT
