@@ -130,3 +130,19 @@ def test_device_resident_batch_matches_host_abi(amd):
         ws, wr, _ = amd.HEVCImageEncoder(f, q)
         assert s == ws and (r == wr).all()
     enc.close()
+
+
+@pytest.mark.parametrize("flag", ["-DIMCVT_FORCE_OVF", "-DROWCAP=6"], ids=["ring-overflow-path", "token-row-overflow-path"])
+def test_rare_paths_on_the_device(amd, flag, tmp_path):
+    """The paths that practically never run — a trial coder whose byte ring overflows is repeated on the safe path; a pass
+    whose group tokens do not fit the lanes' LDS rows counts and writes them the plain way — forced by a build flag, on the
+    real hardware (the host emulation checks their logic; lock-step execution is what only the GPU has)."""
+    import subprocess, sys
+    from conftest import ROOT
+    so = str(tmp_path / "libimcvt_hevc_variant.so")
+    src = os.path.join(ROOT, "imcvt_amd", "csrc", "hevc_hip.hip")
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                    flag, src, "-o", so], check=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity.py")], env=dict(os.environ, IMCVT_HEVC_LIB=so),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FAILURES: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
