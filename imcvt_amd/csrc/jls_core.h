@@ -12,6 +12,7 @@
 // the serial walk is ordinary C++, so that test runs the very same source.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef IMCVT_JLS_HOST
 #define JD static inline
@@ -30,6 +31,9 @@
 namespace jls {
 
 struct Ctx { int a, b, c, n; };                         // :241-247
+// A context as it is kept in LDS: A stays below 2^15 (|error| <= 128 per sample, halved every 32..64 samples), the stored B lies in
+// (-N, 0], C in [-128, 127], N <= 64 — eight bytes, one 64-bit LDS access each way.
+struct PCtx { uint16_t a; int8_t b, c; uint8_t n, pad_[3]; };
 struct Par { int near, alpha, t1, t2, t3, quant, qbeta, qbpp, limit, a_init, half, recip; };
 JD Par make_par(int near) {                             // :26-38 for 8-bit samples
     Par p; p.near = near; p.alpha = 256;
@@ -97,11 +101,18 @@ struct Plane {
     Par p; Bits bw; Ctx ri[2];
     int run_idx, w, prev2_first;                        // prev2_first: reconstruction of (y-2, 0)
 };
-typedef JLS_LDS Ctx *CtxMem;
+typedef JLS_LDS PCtx *CtxMem;
 typedef JLS_LDS uint8_t *RowMem;
 typedef const JLS_LDS uint8_t *CRowMem;
-JD void ctx_store(CtxMem p, const Ctx &c) { p->a = c.a; p->b = c.b; p->c = c.c; p->n = c.n; }
-JD Ctx ctx_load(CtxMem p) { Ctx c; c.a = p->a; c.b = p->b; c.c = p->c; c.n = p->n; return c; }
+JD void ctx_store(CtxMem p, const Ctx &c) {
+    typedef unsigned long long JLS_LDS *W64;
+    *(W64)p = (unsigned long long)(uint32_t)(((uint32_t)c.a & 0xFFFFu) | ((uint32_t)c.b & 0xFFu) << 16 | ((uint32_t)c.c & 0xFFu) << 24) | (unsigned long long)((uint32_t)c.n & 0xFFu) << 32;
+}
+JD Ctx ctx_load(CtxMem p) {
+    typedef const unsigned long long JLS_LDS *W64;
+    const unsigned long long v = *(W64)p; const uint32_t lo = (uint32_t)v;
+    Ctx c; c.a = (int)(lo & 0xFFFFu); c.b = (int)(int8_t)(lo >> 16); c.c = (int)(int8_t)(lo >> 24); c.n = (int)((uint32_t)(v >> 32) & 0xFFu); return c;
+}
 JD void plane_begin(Plane &S, CtxMem cx, int w, int near, uint8_t *out) {
     S.p = make_par(near); S.w = w; S.run_idx = 0; S.prev2_first = 0;
     bits_init(S.bw, out);

@@ -8,16 +8,17 @@
 #include "../../imcvt_amd/csrc/jls_core.h"
 
 static long long encode_plane(const uint8_t *src0, int stride, int h, int w, int near, uint8_t *out) {
-    std::vector<jls::Ctx> cx(364);
+    std::vector<jls::PCtx> cx(364);
     const int rs = (w + 1 + 15) & ~15;
     std::vector<uint8_t> buf(3 * (size_t)rs);
-    uint8_t *src = buf.data(), *rec = src + rs, *prev = rec + rs;
+    uint8_t *src = buf.data(), *rec = src + rs, *prev = rec + rs;            // near == 0: the row is its own reconstruction, as in the kernel
     jls::Plane S;
     jls::plane_begin(S, cx.data(), w, near, out);
     for (int y = 0; y < h; y++) {
         uint8_t *t = prev; prev = rec; rec = t;
-        for (int x = 0; x < w; x++) src[x] = src0[((size_t)y * w + x) * stride];
-        jls::plane_row(S, cx.data(), y, src, rec, prev);
+        uint8_t *in = near ? src : rec;
+        for (int x = 0; x < w; x++) in[x] = src0[((size_t)y * w + x) * stride];
+        jls::plane_row(S, cx.data(), y, in, rec, prev);
     }
     return jls::plane_end(S);
 }
