@@ -63,25 +63,29 @@ JD int grad(const Par &p, int v) {                      // :67-76
 
 // MSB-first bit packer with the JPEG-LS stuffing rule: the byte after a 0xFF carries 7 bits (:162-174)
 struct Bits {
-    JLS_GLB uint8_t *out; long long len;
-    unsigned long long acc; int cnt, cap;              // cnt pending bits in acc (low end), cap = bits the next byte takes
+    JLS_GLB uint8_t *out; int len;
+    unsigned acc; int cnt, cap;                        // cnt pending bits in acc (low end, stale bits above), cap = bits the next byte takes
 };
 JD void bits_init(Bits &w, uint8_t *out) { w.out = (JLS_GLB uint8_t *)out; w.len = 0; w.acc = 0; w.cnt = 0; w.cap = 8; }
 JD void bits_drain(Bits &w) {
     while (w.cnt >= w.cap) {
-        const unsigned v = (unsigned)(w.acc >> (w.cnt - w.cap)) & ((1u << w.cap) - 1u);
+        const unsigned v = (w.acc >> (w.cnt - w.cap)) & ((1u << w.cap) - 1u);
         w.out[w.len++] = (uint8_t)v;
         w.cnt -= w.cap;
         w.cap = (v == 0xFFu) ? 7 : 8;
     }
 }
-JD void put_bits(Bits &w, unsigned v, int n) {          // n <= 32; v has no bits above n
+JD void put_bits24(Bits &w, unsigned v, int n) {        // n <= 24: with at most 7 bits pending the 32-bit accumulator holds them
     w.acc = (w.acc << n) | v; w.cnt += n;
     bits_drain(w);
 }
+JD void put_bits(Bits &w, unsigned v, int n) {          // n <= 32; v has no bits above n
+    if (n > 24) { put_bits24(w, v >> 24, n - 24); v &= 0xFFFFFFu; n = 24; }
+    put_bits24(w, v, n);
+}
 JD void bits_flush(Bits &w) {                           // :183-190 — also the empty 7-bit byte after a 0xFF
     if (w.cnt > 0 || w.cap == 7) {
-        const unsigned v = (unsigned)(w.acc << (w.cap - w.cnt)) & ((1u << w.cap) - 1u);
+        const unsigned v = (w.acc << (w.cap - w.cnt)) & ((1u << w.cap) - 1u);
         w.out[w.len++] = (uint8_t)v;
         w.cnt = 0; w.cap = 8;
     }
@@ -91,7 +95,14 @@ JD void golomb(Bits &w, const Par &p, int limit, int v, int k) {   // :193-203
     if (q < limit) { put_bits(w, 1u, q + 1); if (k) put_bits(w, (unsigned)v & ((1u << k) - 1u), k); }
     else { put_bits(w, 1u, limit + 1); put_bits(w, (unsigned)(v - 1) & ((1u << p.qbpp) - 1u), p.qbpp); }
 }
-JD int golomb_k(int a, int n) { int k = 0; while ((n << k) < a) k++; return k; }   // :114-121
+// smallest k with (n << k) >= a (:114-121), without the loop: the bit lengths give it to within one
+JD int bitlen(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
+JD int golomb_k(int a, int n) {
+    if (a <= n) return 0;
+    const int k0 = bitlen((unsigned)(a - 1)) - bitlen((unsigned)n);         // 2^(k0-1) n < ... : (n << k0) may still be short of a by one doubling
+    const int k = k0 < 0 ? 0 : k0;
+    return ((n << k) < a) ? k + 1 : k;
+}
 
 // The serial walk of one plane.  State that crosses rows lives here; the row buffers are the caller's:
 //   src  [w]      row y of the source plane
