@@ -156,6 +156,11 @@ def main():
             "compute_view": {"transform_GMAC_per_launch": round(macs / 1e9, 1), "achieved_TMAC_s": round(macs / k_avg / 1e12, 4),
                              "note": "path is integer-ALU / serial-CABAC bound, not HBM bound (SURVEY F6, DESIGN.md §5)"},
         }
+        ip = os.path.join(ROOT, "profiles", "pmc_issue.json")             # SQ counter passes (tools/gpu_prof.sh): what actually bounds the kernel
+        if os.path.exists(ip):
+            iv = json.load(open(ip))
+            line["issue_view"] = {"bound": "valu issue", "valu_busy_frac": iv["valu_busy_frac"], "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"],
+                                  "waves_per_simd": iv["waves_per_simd"], "source": iv["source"]}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.qpd6)
         print(json.dumps(line), flush=True)
