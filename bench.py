@@ -77,7 +77,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("IMCVT_BENCH_FORCE_DIST") == "1"      # (the env knob exercises the RCCL path on a 1-GPU box)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -98,7 +99,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -165,7 +166,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.qpd6)
         print(json.dumps(line), flush=True)
     enc.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

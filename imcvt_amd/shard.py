@@ -20,7 +20,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
     """Wall time of the slowest rank (the job's time).  Works on gloo (CPU) and nccl/RCCL (GPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
