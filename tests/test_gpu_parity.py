@@ -71,7 +71,8 @@ def test_edge_cases(amd):
     from oracle import oracle
     # 1x1, single row/column, exact CTU multiples, one past a multiple, extreme values
     imgs = [np.array([[7]], np.uint8), np.arange(70, dtype=np.uint8).reshape(1, 70), np.arange(45, dtype=np.uint8).reshape(45, 1),
-            np.zeros((32, 64), np.uint8), np.full((64, 32), 255, np.uint8), (np.indices((33, 65)).sum(0) % 2 * 255).astype(np.uint8)]
+            np.zeros((32, 64), np.uint8), np.full((64, 32), 255, np.uint8), (np.indices((33, 65)).sum(0) % 2 * 255).astype(np.uint8),
+            (np.arange(3 * 8200) % 251).astype(np.uint8).reshape(3, 8200), (np.arange(3 * 8200) % 241).astype(np.uint8).reshape(8200, 3)]   # beyond 8192: cropped (:1580-1581)
     for q in (0, 4):
         for img, (s, r, dims) in zip(imgs, amd.HEVCImageEncoderBatch(imgs, q)):
             ws, wr, wd = oracle.cpu_encode(img, q)

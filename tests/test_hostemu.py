@@ -56,6 +56,28 @@ def test_token_row_overflow_path_matches_golden(hostemu_row, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+def test_sizes_beyond_8192_are_cropped_like_the_reference(hostemu):
+    # :1580-1581 pads min(dim, 8192) while the source keeps its own stride (:1621): one CTU row / column of 257 CTUs' worth
+    from oracle import oracle, synth
+    for h, w in ((3, 8200), (8200, 3)):
+        img = synth.noise(w, h, 5)
+        stream, rcon = emu_encode(hostemu, img, 3) if max(h, w) <= 8192 else _emu_big(hostemu, img, 3)
+        ws, wr, dims = oracle.cpu_encode(img, 3)
+        assert stream == ws and (rcon == wr).all() and rcon.shape == dims
+
+
+def _emu_big(lib, img, q):
+    h, w = img.shape
+    hp, wp = (min(h, 8192) + 31) // 32 * 32, (min(w, 8192) + 31) // 32 * 32
+    out = np.zeros(2 * (w + 32) * (h + 32) + 65536, np.uint8)
+    rc = np.zeros(hp * wp, np.uint8)
+    ys, xs = C.c_int(h), C.c_int(w)
+    n = lib.hostemu_HEVCImageEncoder(out.ctypes.data_as(u8p), np.ascontiguousarray(img).ctypes.data_as(u8p), rc.ctypes.data_as(u8p),
+                                     C.byref(ys), C.byref(xs), q, None, 0)
+    assert (ys.value, xs.value) == (hp, wp)
+    return out[:n].tobytes(), rc.reshape(hp, wp)
+
+
 def test_lds_budget(hostemu):
     # two workgroups per CU need <= 80 KiB each (160 KiB LDS per CU)
     assert hostemu.hostemu_shm_bytes() <= 80 * 1024
