@@ -28,13 +28,14 @@ W, H = 1920, 1080
 
 
 def _gen(seed):
-    from oracle import synth
+    from imcvt_amd import synth
     return synth.syn(W, H, seed)
 
 
 def _cpu_strip(seed):
     """CPU baseline unit: one 1920x256 strip of syn() — same content class and CTU work as the bench frames."""
-    from oracle import oracle, synth
+    from imcvt_amd import synth
+    from oracle import oracle              # cpu_baseline leg: the CPU checker is what is timed here
     img = synth.syn(W, 256, seed)
     t = time.perf_counter()
     oracle.cpu_encode(img, 0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick GPU parity run: HIP path vs the CPU checker on small seeded inputs, then golden digests for a 1080p frame."""
+"""[developer check script — TEST INFRASTRUCTURE like tests/: uses the CPU checker under oracle/ to verify what it times] Quick GPU parity run: HIP path vs the CPU checker on small seeded inputs, then golden digests for a 1080p frame."""
 import hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

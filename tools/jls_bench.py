@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""JPEG-LS throughput probe (BASELINE config 5): n gray planes syn(w,h,seed), NEAR=near, device-resident, one launch.
+"""[developer check script — TEST INFRASTRUCTURE like tests/: uses the CPU checker under oracle/ to verify what it times] JPEG-LS throughput probe (BASELINE config 5): n gray planes syn(w,h,seed), NEAR=near, device-resident, one launch.
 Prints kernel times, Mpx/s, and checks the first planes against the CPU checker / golden digest."""
 import hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

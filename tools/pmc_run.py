@@ -6,7 +6,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, imcvt_amd
-from oracle import synth
+from imcvt_amd import synth
 w, h, n, q = (int(a) for a in (sys.argv[1:5] + ["256", "128", "768", "0"][len(sys.argv) - 1:]))
 enc = imcvt_amd.DeviceEncoder()
 frames = [torch.from_numpy(synth.syn(w, h, s % 16)).cuda() for s in range(n)]

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import imcvt_amd
-from oracle import synth
+from imcvt_amd import synth
 w, h, n, q = (int(a) for a in (sys.argv[1:5] + ["512", "256", "1", "0"][len(sys.argv) - 1:]))
 enc = imcvt_amd.DeviceEncoder()
 frames = [torch.from_numpy(synth.syn(w, h, s)).cuda() for s in range(n)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick throughput probe: n frames of w x h (default 1024 x 512x256, q0), 3 launches; first frames checked against the CPU checker."""
+"""[developer check script — TEST INFRASTRUCTURE like tests/: uses the CPU checker under oracle/ to verify what it times] Quick throughput probe: n frames of w x h (default 1024 x 512x256, q0), 3 launches; first frames checked against the CPU checker."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
