@@ -147,3 +147,18 @@ def test_rare_paths_on_the_device(amd, flag, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity.py")], env=dict(os.environ, IMCVT_HEVC_LIB=so),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "FAILURES: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_more_frames_than_workgroup_slots(amd):
+    """A batch larger than the 1024 resident workgroups: the persistent workgroups keep pulling frames from the queue."""
+    from oracle import oracle, synth
+    imgs = [synth.syn(32 + (i % 3), 32, i % 7) for i in range(1100)]
+    res = amd.HEVCImageEncoderBatch(imgs, 2)
+    want = {}
+    for i in (0, 1, 2, 3, 4, 5, 6, 1023, 1024, 1099):
+        key = (imgs[i].shape, i % 7)
+        if key not in want:
+            want[key] = oracle.cpu_encode(imgs[i], 2)
+        s, r, _ = res[i]
+        assert s == want[key][0] and (r == want[key][1]).all(), i
+    assert len({bytes(res[i][0]) for i in range(0, 1100, 21)}) >= 1 and all(len(s) > 0 for s, _, _ in res)
