@@ -30,17 +30,18 @@ def build_jls(force: bool = False) -> str:
 
 HOST = os.path.join(CSRC, "host")
 CLI = os.path.join(CSRC, "imcvt")                  # the drop-in converter binary (reference: src/main.c)
-PNM_SO = os.path.join(CSRC, "libimcvt_pnm.so")     # the PNM reader / writer alone, for the host-side tests
+PNM_SO = os.path.join(CSRC, "libimcvt_pnm.so")     # the image-file readers / writers alone (PNM, PNG, BMP, QOI), for the host-side tests
+IO_SRC = ["pnm_io.cpp", "png_io.cpp", "bmp_io.cpp", "qoi_io.cpp"]
 
 
 def build_host(force: bool = False) -> str:
-    """Host glue of the drop-in binary: PNM I/O + CLI, linked against libimcvt_hevc.so (plain g++, no device code)."""
-    srcs = [os.path.join(HOST, "imcvt_cli.cpp"), os.path.join(HOST, "pnm_io.cpp")]
+    """Host glue of the drop-in binary: image-file I/O + CLI, linked against libimcvt_hevc.so (plain g++, no device code)."""
+    srcs = [os.path.join(HOST, "imcvt_cli.cpp")] + [os.path.join(HOST, f) for f in IO_SRC]
     build_jls()
     deps = srcs + [OUT, JLS_OUT, os.path.join(CSRC, "..", "..", "include", "imcvt_hevc.h")]
     stale = lambda o: force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps)
     if stale(PNM_SO):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", srcs[1], "-o", PNM_SO], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *srcs[1:], "-o", PNM_SO], check=True)
     if stale(CLI):
         subprocess.run(["g++", "-O2", "-std=c++17", "-DIMCVT_WITH_JLS", *srcs, "-L" + CSRC, "-limcvt_hevc", "-limcvt_jls", "-Wl,-rpath,$ORIGIN", "-o", CLI], check=True)
     return CLI

@@ -8,9 +8,8 @@
 // loop then runs in the reference's order and only writes the already encoded streams, so stdout, exit code and file
 // contents are those of the reference.
 //
-// Scope: inputs are PNM (P1-P6); outputs are PNM, H.265 and — when built with the JPEG-LS module —
-// .jls.  PNG / BMP / QOI are outside this build: such an input fails to open, such an output suffix is reported as
-// unsupported, through the reference's own error lines.
+// Scope: inputs are tried as PNM, PNG, BMP, QOI in the reference's order (:183-186); outputs are PNM,
+// PNG, BMP, QOI, H.265 and — when built with the JPEG-LS module — .jls (pnm_io / png_io / bmp_io / qoi_io.cpp).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,7 +20,13 @@
 #include "../../../include/imcvt_hevc.h"
 
 extern "C" uint8_t *loadPNMImageFile(const char *, int *, uint32_t *, uint32_t *);
+extern "C" uint8_t *loadBMPImageFile(const char *, int *, uint32_t *, uint32_t *);
+extern "C" uint8_t *loadQOIImageFile(const char *, int *, uint32_t *, uint32_t *);
+extern "C" uint8_t *imcvt_load_png(const char *, int *, uint32_t *, uint32_t *, int quiet);
 extern "C" int writePNMImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t);
+extern "C" int writePNGImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t);
+extern "C" int writeBMPImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t);
+extern "C" int writeQOIImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t);
 #ifdef IMCVT_WITH_JLS
 extern "C" int writeJLSImageFile(const char *, const uint8_t *, int, uint32_t, uint32_t, int);
 #endif
@@ -31,8 +36,8 @@ static const int kMaxFiles = 999;              // src/main.c:84
 static void usage() {
     fputs("ImCvt (MI355X build of the H.265 intra path)\n"
           "usage:  imcvt [-switches] <in1> -o <out1> [<in2> -o <out2>] ...\n"
-          "  <in>  : .pnm / .pgm / .ppm / .pbm (P1..P6)\n"
-          "  <out> : .pnm .pgm .ppm | .h265 .265 .hevc (gray 8-bit, encoded on the GPU)"
+          "  <in>  : PNM (P1..P6), PNG (8-bit gray / RGB / RGBA), BMP, QOI — recognised by content\n"
+          "  <out> : .pnm .pgm .ppm .png .bmp .qoi | .h265 .265 .hevc (gray 8-bit, encoded on the GPU)"
 #ifdef IMCVT_WITH_JLS
           " | .jls"
 #endif
@@ -62,6 +67,15 @@ static std::string with_extension(const char *src, const char *ext) {
 }
 static bool exists(const char *name) { FILE *f = fopen(name, "rb"); if (f) fclose(f); return f != NULL; }
 static bool is_hevc_name(const char *n) { return ends_with_nocase(n, "h265") || ends_with_nocase(n, "265") || ends_with_nocase(n, "hevc"); }
+
+// the reference's loader chain (:183-186); quiet: no stdout lines (the PNG loader has some)
+static uint8_t *load_image(const char *src, int *rgb, uint32_t *h, uint32_t *w, bool quiet) {
+    uint8_t *px = loadPNMImageFile(src, rgb, h, w);
+    if (!px) px = imcvt_load_png(src, rgb, h, w, quiet);
+    if (!px) px = loadBMPImageFile(src, rgb, h, w);
+    if (!px) px = loadQOIImageFile(src, rgb, h, w);
+    return px;
+}
 
 struct Job { const char *src = NULL; std::string dst; bool dst_given = false; };
 struct Encoded { bool tried = false, ok = false; std::vector<unsigned char> stream; int len = 0; bool rgb = false; };
@@ -100,7 +114,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < n; i++) {
             if (!is_hevc_name(jobs[i].dst.c_str())) continue;
             int rgb = 0; uint32_t h = 0, w = 0;
-            uint8_t *px = loadPNMImageFile(jobs[i].src, &rgb, &h, &w);
+            uint8_t *px = load_image(jobs[i].src, &rgb, &h, &w, true);
             if (!px) continue;
             std::vector<unsigned char> g((size_t)h * w);
             for (size_t k = 0; k < g.size(); k++) g[k] = rgb ? px[3 * k + 1] : px[k];     // green channel of RGB, src/imageio_hevc.c:24-26
@@ -131,11 +145,17 @@ int main(int argc, char **argv) {
         if (!exists(src)) { printf("   ***ERROR: %s not exist\n", src); continue; }
         if (!force && exists(dst)) { printf("   ***ERROR: %s already exist\n", dst); continue; }
         int rgb = 0; uint32_t h = 0, w = 0;
-        uint8_t *px = loadPNMImageFile(src, &rgb, &h, &w);
+        uint8_t *px = load_image(src, &rgb, &h, &w, false);
         if (!px) { printf("   ***ERROR: open %s failed\n", src); continue; }
         int failed;
         if (ends_with_nocase(dst, "pnm") || ends_with_nocase(dst, "ppm") || ends_with_nocase(dst, "pgm")) {
             failed = writePNMImageFile(dst, px, rgb, h, w);
+        } else if (ends_with_nocase(dst, "png")) {
+            failed = writePNGImageFile(dst, px, rgb, h, w);
+        } else if (ends_with_nocase(dst, "bmp")) {
+            failed = writeBMPImageFile(dst, px, rgb, h, w);
+        } else if (ends_with_nocase(dst, "qoi")) {
+            failed = writeQOIImageFile(dst, px, rgb, h, w);
 #ifdef IMCVT_WITH_JLS
         } else if (ends_with_nocase(dst, "jls")) {
             failed = writeJLSImageFile(dst, px, rgb, h, w, level);
