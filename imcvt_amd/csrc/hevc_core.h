@@ -1179,6 +1179,13 @@ HD int seg_suffix_sum(int v, int l, int lpc, int *total) {
     return inc - v;
 }
 
+// -DIMCVT_MARK: comment markers in the ISA at the pipeline's step boundaries (tools/isa_regions.py counts the instructions
+// between them); nothing otherwise
+#if defined(IMCVT_MARK) && !defined(IMCVT_HOSTEMU)
+#define MARK(x) asm volatile("; MARK " x ::: "memory")
+#else
+#define MARK(x)
+#endif
 template <int LG>
 HD void p1_run_t(int wave, const P1Args &P) {
     constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
@@ -1200,12 +1207,14 @@ HD void p1_run_t(int wave, const P1Args &P) {
         const int gp = cg_pos(st, s, r), by = gp >> 3, bx = gp & 7;
         const int tokn0 = (P.tok && live) ? WO.tokn[c] : 0;
         u32 predw[4] = { 0, 0, 0, 0 };                  // this lane's 4x4 block of the prediction, a packed row per dword (kept in registers until step 5)
+        MARK("pass_setup");
         // ---- step 1: prediction and residual
         if (live) {
             i16 *rp = W.u.p1.res + sl * NN;
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4];
             pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
+            MARK("predict");
             for (int yi = 0; yi < 4; yi++) {
                 const int y = by * 4 + yi;
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
@@ -1217,6 +1226,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
+        MARK("residual");
         // ---- step 2: tmp = (C * res + ra) >> a                                              (:514 forward)
         if (live) {
             int acc[4][4];
@@ -1229,6 +1239,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
+        MARK("fwd_stage1");
         // ---- step 3: coef = (tmp * C^T + rb) >> b ; RDOQ ; tokens ; dequantise                 (:515, :540-614, :1172-1268)
         {
             int acc[4][4];
@@ -1236,7 +1247,9 @@ HD void p1_run_t(int wave, const P1Args &P) {
             if (live) {
                 for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = rb;
                 mac_YM32<N>(acc, W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
+                MARK("fwd_stage2");
                 any = rdoq_group<s>(acc, Q);
+                MARK("rdoq");
             }
             Lv16 L; u32 nzm = 0;
             if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
@@ -1261,6 +1274,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 }
                 u16 *base = P.tok + (size_t)c * TOK_CAP + tokn0;
                 const int cbf_ctx = CX_CBF_LUMA + (P.shape == 0 ? 1 : 0);
+                MARK("scan_dequant_cfg");
                 const long long ptk0 = prof_now();
                 // greater-1 context set carry (:1218-1221): needs only the levels, not the tokens
                 const int big = (talk && nzm != 0) ? group_big(L) : 0;
@@ -1281,6 +1295,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                     if (seg == 0) { to_put(o, 0, (cbf_ctx << 1) | 0); cg = 1; }
                     else { TgB B; const int ra = tokg_a<true, true>(o, 0, L, nzm, cfg, B); cg = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, ra & 0xFFFF, L, B), B); }
                 }
+                MARK("group_tokens");
                 prof_add(PF_T_SETUP, ptk0);
                 const long long ptk1 = prof_now();
                 const int fits = wave_ballot(cg > ROWCAP) == 0;
@@ -1314,6 +1329,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                         WO.tokn[c] = tokn0 + total; WO.tnz[c] = (seg != 0);
                     }
                 }
+                MARK("tokens_to_stream");
                 prof_add(PF_T_HDR, ptk2);
                 wave_sync_lds();                                            // rows are done with before res is written again
             }
@@ -1323,6 +1339,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
+        MARK("dequant_store");
         // ---- step 4: itmp = clip16((C^T * deq + 64) >> 7)                                    (:514 inverse)
         if (live) {
             int acc[4][4];
@@ -1337,6 +1354,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
+        MARK("inv_stage1");
         // ---- step 5: rec = clip8(clip16((itmp * C + 2048) >> 12) + pred) ; SSE                (:515 inverse, :146,:165)
         if (live) {
             int acc[4][4];
@@ -1361,6 +1379,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
             if (P.only_mode < 0) lds_add(&WO.sse[c], part);
         }
+        MARK("inv_stage2_recon_sse");
         wave_sync_lds();
       }
     }
