@@ -1038,6 +1038,13 @@ HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag) {
     return nzm;
 }
 
+// -DIMCVT_MARK: comment markers in the ISA at the pipeline's step boundaries (tools/isa_regions.py counts the instructions
+// between them); nothing otherwise
+#if defined(IMCVT_MARK) && !defined(IMCVT_HOSTEMU)
+#define MARK(x) asm volatile("; MARK " x ::: "memory")
+#else
+#define MARK(x)
+#endif
 // ---- 4x4 blocks: one lane owns the whole block, so the pipeline runs entirely in registers (DST constants are
 // immediates, no LDS intermediates, no wave syncs between the stages) and the lane writes the TU's tokens itself.
 HD void p1_run_4(int wave, const P1Args &P) {
@@ -1051,7 +1058,9 @@ HD void p1_run_4(int wave, const P1Args &P) {
             const int mode = (P.only_mode >= 0) ? P.only_mode : c;
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4], x[4][4], t[4][4];
+            MARK("b4_setup");
             pred_block4(T, br, 4, 2, mode, 0, 0, pr);
+            MARK("b4_predict");
             for (int yi = 0; yi < 4; yi++) {
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
                 for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
@@ -1071,7 +1080,9 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
                 x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
             }
+            MARK("b4_residual_dst");
             const int any = rdoq_group<0>(x, Q);
+            MARK("b4_rdoq");
             const int st = scan_type_of(4, mode);
             if (P.tok) {                                    // the TU's tokens: cbf_luma, last position, the one group
                 Lv16 L; u32 nzm = 0;
@@ -1096,6 +1107,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 ls_end(ls, w, W, c);
                 W.tnz[c] = (nzm != 0);
             }
+            MARK("b4_tokens");
             int part = 0;
             if (any) {
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * (1 << Q.dqs));
@@ -1132,6 +1144,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 }
             }
             if (P.only_mode < 0) W.sse[c] += part;         // this lane is the only writer of sse[c] in this pass
+            MARK("b4_inverse_recon_sse");
         }
     }
     wave_sync_lds();
@@ -1179,13 +1192,6 @@ HD int seg_suffix_sum(int v, int l, int lpc, int *total) {
     return inc - v;
 }
 
-// -DIMCVT_MARK: comment markers in the ISA at the pipeline's step boundaries (tools/isa_regions.py counts the instructions
-// between them); nothing otherwise
-#if defined(IMCVT_MARK) && !defined(IMCVT_HOSTEMU)
-#define MARK(x) asm volatile("; MARK " x ::: "memory")
-#else
-#define MARK(x)
-#endif
 template <int LG>
 HD void p1_run_t(int wave, const P1Args &P) {
     constexpr int N = 1 << LG, s = LG - 2, nb = N >> 2, lpc = nb * nb, G = 64 / lpc, NN = N * N;
