@@ -141,7 +141,7 @@ struct Tables {
     uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8        (:700-712)
     u32 posadd[4][3];      // sig_coeff ctx increment per in-group scan position, 2 bits each [pattern][type]  (:1115-1120)
     u64 c4tab[3];          // 4x4-TU sig_coeff ctx per scan position, 4 bits each [type]                  (:1092)
-    u32 lrate[8];          // rate model of an absolute level 0..7 in 2^-15 bit units                      (:526-535)
+    u32 ldelta[8];         // steps of the level rate model below level 8: (rate(l)-rate(l-1))/16 | (rate(l)-rate(l-2))/16 << 16  (:526-535)
     u8  ang[36];           // intraPredAngle + 32                                                         (:282)
     u16 iang[36];          // |invAngle|                                                                  (:283)
 };
@@ -686,46 +686,44 @@ struct QConst { int sh, add, dmax, thr, dq, dqs; RdW rw; };
 template <int S>
 HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q.dmax = I32MAX - Q.add; Q.thr = 9 << Q.sh >> 2; Q.dqs = 5 - S + q; Q.dq = 1 << Q.dqs; Q.rw = rd_weights(q); return Q; }
 
-// Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594).  in: acc = forward-transform sums before the
-// final shift; out: acc = signed levels.  Returns non-zero when the group keeps any level after the weak-group test.
-// RD cost inside RDOQ: dist <= (2^31-1) >> 7 and rate <= 92000 + (32 << 15) (levels are 16-bit), so with the weights of
-// :178-181 neither product nor their sum can reach the saturation branches of :182-184 — the cost is the plain sum.
-HD int rd_cost_q(const RdW &w, int dist, int rate) { return umul24(w.wd, dist) + umul24(w.wb, rate); }
-// :526-535 without a branch: a table for levels below 8, 92000 + ((4 + 2 floor(log2(level - 5))) << 15) above
-// (= 223072 + (31 - clz(level - 5)) << 16; for level < 8 the closed form's value is discarded, whatever clz returns)
-HD int level_rate_q(const Tables &T, int level) {
-    const int hi = (223072 + (31 << 16)) - (clz_nz((u32)(level - 5)) << 16);
-    const int lo = (int)T.lrate[clip3(level, 0, 7)];
-    return level < 8 ? lo : hi;
-}
 // Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594), written without branches: every coefficient
 // prices the levels l0, l0-1, l0-2 (results of impossible candidates are masked), the larger level winning ties (:570-578).
 // With x0 = d - (l0 << sh) in (-2^(sh-1), 2^(sh-1)], the three errors are |x0|, x0 + 2^sh, x0 + 2^(sh+1) (the last two are
 // positive), and |x0| >> dsh < 2^15 never reaches the 46340 clamp of :572.
+// The three costs are compared through their differences to the first: with dist <= (2^31-1) >> 7, rate <= 92000 + (32 << 15)
+// and the weights of :178-181 no product or sum reaches the saturation branches of :182-184, so
+//     cost(l0-k) < cost(l0)  <=>  wd * (dist_k - dist_0) - wb * (rate(l0) - rate(l0-k)) < 0
+// exactly.  The rate model (:526-535) is non-decreasing and all its steps are multiples of 16: T.ldelta holds, for l0 <= 7, the
+// steps rate(l0) - rate(l0-1) and rate(l0) - rate(l0-2) in units of 16 (two 16-bit fields); from l0 = 8 on both are
+// differences of floor(log2(level - 5)), i.e. of leading-zero counts, times 2^16.
 // in: acc = forward-transform sums before the final shift; out: acc = signed levels.  Returns non-zero when the group keeps
 // any level after the weak-group test (:588-591).
 template <int S>
 HD int rdoq_group(int acc[4][4], const QConst &Q) {
     constexpr int b1 = S + 8, dsh = 8 - S;
     const Tables &T = SM.T;
-    const int step = 1 << Q.sh;
+    const int step = 1 << Q.sh, wd = Q.rw.wd, nwb16 = -(Q.rw.wb << 4);
     int sum = 0, any = 0;
     for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
         const int cf = acc[r][cc] >> b1, av = iabs(cf);
-        const int d = (av > 0x1ffff) ? Q.dmax : imin((av & 0x1ffff) << 14, Q.dmax);
-        const int l0 = clip16((int)(((u32)d + (u32)Q.add) >> Q.sh));
+        const u32 dd = (u32)imin(av, 0x20000) << 14;                             // :556-558 (2^31 when av exceeds 17 bits: clamped next)
+        const int d = (int)(dd < (u32)Q.dmax ? dd : (u32)Q.dmax);
+        const int l0 = imin((int)(((u32)d + (u32)Q.add) >> Q.sh), 32767);     // the 16-bit clip of :560 (the value is not negative)
         const int x0 = d - (l0 << Q.sh);
         const int e0 = iabs(x0) >> dsh, e1 = (int)((u32)(x0 + step) >> dsh), e2 = (int)((u32)(x0 + 2 * step) >> dsh);
         const int d0 = (int)((u32)umul24(e0, e0) >> 7);
         const int d1 = (int)(((e1 < 46340) ? (u32)umul24(e1, e1) : (u32)I32MAX) >> 7);
         const int d2 = (int)(((e2 < 46340) ? (u32)umul24(e2, e2) : (u32)I32MAX) >> 7);
-        const int c0 = rd_cost_q(Q.rw, d0, level_rate_q(T, l0));
-        const int c1 = rd_cost_q(Q.rw, d1, level_rate_q(T, l0 - 1));
-        const int c2 = rd_cost_q(Q.rw, d2, level_rate_q(T, l0 - 2));
-        const int t1 = (l0 > 0) & (c1 < c0);
-        const int best1 = t1 ? c1 : c0;
-        const int t2 = (l0 > 1) & (c2 < best1);
-        const int pick = t2 ? l0 - 2 : t1 ? l0 - 1 : l0;
+        const u32 tw = T.ldelta[imin(l0, 7)];
+        const int z0 = clz_nz((u32)(l0 - 5)), z1 = clz_nz((u32)(l0 - 6)), z2 = clz_nz((u32)(l0 - 7));   // (discarded below 8, whatever clz returns)
+        const int big = l0 >= 8;
+        const int dl1 = big ? (z1 - z0) << 12 : (int)(tw & 0xFFFFu), dl2 = big ? (z2 - z0) << 12 : (int)(tw >> 16);
+        const int k1 = mul24(nwb16, dl1) + umul24(wd, d1 - d0);                  // cost(l0-1) - cost(l0)
+        const int k2 = mul24(nwb16, dl2) + umul24(wd, d2 - d0);                  // cost(l0-2) - cost(l0)
+        const int t1 = (l0 > 0) & (k1 < 0);
+        const int best1 = t1 ? k1 : 0;
+        const int t2 = (l0 > 1) & (k2 < best1);
+        const int pick = l0 - (t2 ? 2 : t1);
         acc[r][cc] = (cf < 0) ? -pick : pick;
         any |= pick;
         sum += imin(d, Q.thr);

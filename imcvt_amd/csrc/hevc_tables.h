@@ -89,7 +89,7 @@ inline void build_tables(Tables &T, ColdTables &K) {
     static const u8 c4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };     // reference :1092
     for (int t = 0; t < 3; t++) { u64 w = 0; for (int k = 0; k < 16; k++) w |= (u64)c4[T.incg[t][k]] << (4 * k); T.c4tab[t] = w; }
     { const u32 lr[8] = { 0, 70000, 90000, 92000, 157536, 190304, 92000 + (4u << 15), 92000 + (6u << 15) };       // reference :526-535
-      for (int l = 0; l < 8; l++) T.lrate[l] = lr[l]; }
+      for (int l = 0; l < 8; l++) T.ldelta[l] = (lr[l] - lr[l > 0 ? l - 1 : 0]) / 16 | (lr[l] - lr[l > 1 ? l - 2 : 0]) / 16 << 16; }
     for (int q = 0; q < 5; q++) {
         const int qp = q * 6 + 4;
         for (int i = 0; i < NCTX; i++) {
