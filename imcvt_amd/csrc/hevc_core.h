@@ -894,6 +894,12 @@ HDN EscRet tok_escape(TokOut o, int k0, int wr, int v, int k, u32 acc, int nb) {
     EscRet e; e.ntok = w.n - k0; e.acc = acc; e.nb = nb;
     return e;
 }
+// some lane of the wave (in host emulation: this lane) needs the rare path
+#ifdef IMCVT_HOSTEMU
+#define WAVE_ANY(c) (c)
+#else
+#define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#endif
 struct TgB { int esc, base2, rice, j; BitRun run; };       // state handed from part A to part B
 #define TK_EMIT(pred, tok) do { const int p_ = (pred); if (WR) { if (PRIV) to_put(o, cnt, (tok)); else to_put_if(o, cnt, (tok), p_); } cnt += p_; } while (0)
 // returns the token count so far | (this group ends with c1 == 0) << 16
@@ -945,7 +951,12 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
     B.esc = esc;
     return cnt | ((g2 >= 0) ? 1 << 16 : 0);
 }
-// remaining absolute levels of scan positions hi..lo (:1243-1262), appended to the group's bypass run; returns the token count so far
+// remaining absolute levels of scan positions hi..lo (:1243-1262), appended to the group's bypass run; returns the token count so far.
+// Both binarisations are "l1 ones, a zero, the low m bits of val" (:1150-1167):
+//     r <  3 << rice :  l1 = r >> rice,         m = rice, val = r                                  (at most 7 bins)
+//     r >= 3 << rice :  l1 = 3 + n - rice,      m = n,    val = r - (2 << rice),  n = floor(log2 val)   (the EG(rice+1) escape)
+// so one straight-line append serves both; with at most 7 bins pending, a code word of up to 24 bins leaves as (up to) three
+// full chunks here.  Longer ones (levels beyond ~2^11 at a small Rice parameter) take the out-of-line path.
 template <bool WR, bool PRIV, int HI, int LO>
 HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
     if (B.esc) {
@@ -956,15 +967,21 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
             const int mg = iabs(L.v[n]), isnz = mg != 0;
             const int r = mg - (j < 8 ? base2 : 1);
             const int doit = isnz & (r >= 0), small = r < (3 << rice);
-            const int pp = r >> rice;                  // prefix of pp ones and a zero (pp <= 2), then rice suffix bins: at most 7 bins
-            const int ds = doit & small;
-            const int len = ds ? pp + 1 + rice : 0;
-            const u32 bins = ds ? ((((2u << pp) - 2u) << rice) | ((u32)r & ((1u << rice) - 1u))) : 0u;
-            acc = (acc << len) | bins; nb += len;      // bits above the nb pending ones are stale (already emitted) and never looked at
-            const int full = nb >= 8;
-            TK_EMIT(full, tk_chunk_word((int)(acc >> (nb & 7)) & 0xFF, 8));
-            nb &= 7;                                   // (nb was at most 7 + 7)
-            if (doit & !small) { const EscRet e = tok_escape(o, cnt, WR, r, rice, acc, nb); cnt += e.ntok; acc = e.acc; nb = e.nb; }
+            const int v2 = r - (2 << rice), ne = 31 - clz_nz((u32)v2 | 1u);      // (ne is only used when r >= 3 << rice, where v2 >= 1 << rice)
+            const int m = small ? rice : ne, val = small ? r : v2;
+            const int l1 = small ? (r >> rice) : 3 + ne - rice;
+            const int len = doit ? l1 + m + 1 : 0;
+            const int wide = nb + len > 31;                                        // never for the short form
+            const int inl = (len != 0) & !wide;
+            const int s1 = inl ? l1 : 0, s2 = inl ? m + 1 : 0;
+            acc = (acc << s1) | ((1u << s1) - 1u);                                 // bits above the nb pending ones are stale (already emitted) and never looked at
+            acc = (acc << s2) | (inl ? (u32)val & ((1u << m) - 1u) : 0u);
+            nb += s1 + s2;
+            TK_EMIT(nb >= 8, tk_chunk_word((int)(acc >> ((nb - 8) & 31)) & 0xFF, 8));
+            TK_EMIT(nb >= 16, tk_chunk_word((int)(acc >> ((nb - 16) & 31)) & 0xFF, 8));
+            TK_EMIT(nb >= 24, tk_chunk_word((int)(acc >> ((nb - 24) & 31)) & 0xFF, 8));
+            nb &= 7;
+            if (WAVE_ANY(wide)) { if (wide) { const EscRet e = tok_escape(o, cnt, WR, r, rice, acc, nb); cnt += e.ntok; acc = e.acc; nb = e.nb; } }
             rice = (doit & (mg > (3 << rice))) ? imin(rice + 1, 4) : rice;
             base2 = (isnz & (mg >= 2)) ? 2 : base2;
             j += isnz;
@@ -1402,11 +1419,6 @@ HDN void p1_run_cold(int wave, const P1Args P) { p1_run(wave, P); }     // the w
 // every wave step is exactly one token per live lane.  Bit-exactness: same bins, same order, same <=8-bin
 // bypass chunking as :898-1268 (the tokens), same coder arithmetic as :858-932.
 // ---------------------------------------------------------------------------------------------------
-#ifdef IMCVT_HOSTEMU
-#define WAVE_ANY(c) (c)
-#else
-#define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
-#endif
 
 // one token on the lane's coder
 template <class S>
