@@ -955,8 +955,12 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
 // Both binarisations are "l1 ones, a zero, the low m bits of val" (:1150-1167):
 //     r <  3 << rice :  l1 = r >> rice,         m = rice, val = r                                  (at most 7 bins)
 //     r >= 3 << rice :  l1 = 3 + n - rice,      m = n,    val = r - (2 << rice),  n = floor(log2 val)   (the EG(rice+1) escape)
-// so one straight-line append serves both; with at most 7 bins pending, a code word of up to 24 bins leaves as (up to) three
-// full chunks here.  Longer ones (levels beyond ~2^11 at a small Rice parameter) take the out-of-line path.
+// so one straight-line append serves both; with at most 7 bins pending, a code word of up to 16 bins leaves as (up to) two
+// full chunks here.  Longer ones (levels beyond ~100 at Rice parameter 0; measured faster than a third chunk slot on the
+// synthetic and the natural test pictures) take the out-of-line path.
+#ifndef TOKB_INLINE_BINS
+#define TOKB_INLINE_BINS 23     // pending + code word bins handled inline: two full chunks + 7 pending (tests build with 14: every escape out of line)
+#endif
 template <bool WR, bool PRIV, int HI, int LO>
 HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
     if (B.esc) {
@@ -971,7 +975,7 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
             const int m = small ? rice : ne, val = small ? r : v2;
             const int l1 = small ? (r >> rice) : 3 + ne - rice;
             const int len = doit ? l1 + m + 1 : 0;
-            const int wide = nb + len > 31;                                        // never for the short form
+            const int wide = nb + len > TOKB_INLINE_BINS;                          // never for the short form (at most 7 + 7 bins)
             const int inl = (len != 0) & !wide;
             const int s1 = inl ? l1 : 0, s2 = inl ? m + 1 : 0;
             acc = (acc << s1) | ((1u << s1) - 1u);                                 // bits above the nb pending ones are stale (already emitted) and never looked at
@@ -979,7 +983,6 @@ HD int tokg_b(const TokOut &o, int cnt, const Lv16 &L, TgB &B) {
             nb += s1 + s2;
             TK_EMIT(nb >= 8, tk_chunk_word((int)(acc >> ((nb - 8) & 31)) & 0xFF, 8));
             TK_EMIT(nb >= 16, tk_chunk_word((int)(acc >> ((nb - 16) & 31)) & 0xFF, 8));
-            TK_EMIT(nb >= 24, tk_chunk_word((int)(acc >> ((nb - 24) & 31)) & 0xFF, 8));
             nb &= 7;
             if (WAVE_ANY(wide)) { if (wide) { const EscRet e = tok_escape(o, cnt, WR, r, rice, acc, nb); cnt += e.ntok; acc = e.acc; nb = e.nb; } }
             rice = (doit & (mg > (3 << rice))) ? imin(rice + 1, 4) : rice;

@@ -49,6 +49,12 @@ def hostemu_ovf(built):
 
 
 @pytest.fixture(scope="session")
+def hostemu_esc(built):
+    """Same, with every escape code word of the token generator taking the out-of-line path (tokg_b's rare branch)."""
+    return _hostemu_lib("libhostemu_esc.so", ["-DTOKB_INLINE_BINS=14"])
+
+
+@pytest.fixture(scope="session")
 def hostemu_row(built):
     """Same, with 6-token lane rows: nearly every pass overflows its token rows and takes the count-then-write path."""
     return _hostemu_lib("libhostemu_row.so", ["-DROWCAP=6"])

@@ -49,6 +49,14 @@ def test_ring_overflow_path_matches_golden(hostemu_ovf, e):
 
 
 @pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_out_of_line_escape_path_matches_golden(hostemu_esc, e):
+    # remaining-level code words longer than the inline slots take tok_escape (hevc_core.h tokg_b): same streams
+    stream, rcon = emu_encode(hostemu_esc, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
 def test_token_row_overflow_path_matches_golden(hostemu_row, e):
     # a pass whose group tokens do not fit the lanes' LDS rows counts and writes them the plain way (hevc_core.h p1_run_t step 3)
     stream, rcon = emu_encode(hostemu_row, kat_input(e["input"]), e["qpd6"])
