@@ -851,7 +851,7 @@ HD int last_pos_emit(const TokOut &o, int cnt, const LastPos &p) {
 // Tokens of one coefficient group (the body of the group loop of :1172-1268), as straight-line code over the group's
 // 16 levels held in registers in scan order: every potential token is one LDS store to a computed slot (the dump slot
 // when the token does not exist), the greater-1 context and Rice parameter recurrences are select chains.  Only
-// Exp-Golomb escapes (levels beyond 3 << rice) branch.
+// remaining-level code words longer than 16 bins branch (tokg_b).
 //   cfg : bit1 DC group | bit2 group holds the last significant coefficient | bit3 greater-1 context set carry (previous
 //         coded group ended with c1 == 0) | bits4-5 neighbour pattern (below << 1 | right) | bits6-7 scan type
 //         | bits8-9 log2(TU size) - 2
