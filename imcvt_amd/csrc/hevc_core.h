@@ -1508,9 +1508,11 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
         if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / lm rows belong to lane 0
             ring_sync(sink, a.cnt);                         // full 16-byte runs of output leave the ring
             int qn = 0;
+            MARK("p2_ring_sync");
             UNROLL_FULL
             for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
                 code_token_q(a, cx, lm->lq, qn, tok_of(cur, j));
+            MARK("p2_eight_tokens");
             NOUNROLL
             for (int i = 0; WAVE_ANY(i < qn); i++) {        // the bytes this block pushed out of `low` (:863-878): the common case is
                 const int act = i < qn;                     // straight-line (one byte buffered, no 0xFF run, no emulation prevention)
