@@ -1,23 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — Mpixels/s of H.265 intra encode (gray8), frame-sharded over N GPUs (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch: every rank encodes FRAMES independent 1920x1080 gray8
-frames syn(1920,1080,seed) (BASELINE config 4's frames, seeds rank*FRAMES+i) that are already
-resident in HBM, through the device-resident C ABI (imcvt_hevc_encode_device).  Frames are independent, so
-ranks share nothing on the data path (no collective); the job is weak-scaled (per-GPU batch fixed).
+Workload (default) = BASELINE configs[3] as written: ONE batch of 512 independent 1920x1080 gray8 frames
+syn(1920,1080,seed), seed = 0..511, qpd6 = 0, split over the N ranks (strong scaling: rank r owns a
+contiguous block of 512/N frames).  A "step" = one pass of the hot path over that batch: every rank encodes its frames,
+already resident in HBM, through the device-resident C ABI (imcvt_hevc_encode_device), then the encoded streams are
+gathered to rank 0 over RCCL (all-gather of lengths + one point-to-point send per peer, imcvt_amd/shard.py) — the one
+exchange step the job has.  `--scaling weak --frames F` keeps F frames per GPU instead (seeds rank*F+i).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--qpd6 Q] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--total-frames T] [--frames F] [--qpd6 Q]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  value = input pixels (W*H) of all ranks / max-over-ranks wall time of the K steps.
-roofline: HBM-bound view the metric asks for — algorithmic bytes (W*H read + Wp*Hp reconstruction written +
-stream bytes written) per launch / HIP-event duration of the kernel on its launch stream.
-cpu_baseline: the CPU checker (real reference when oracle/_ref travelled, else the pinned port) on a bounded sample.
+Started plain with --gpus N > 1 it launches its N ranks itself (torch.distributed.run on 127.0.0.1).
+Rank 0 prints ONE JSON line.  value = input pixels (W*H) of all ranks' frames x K / max-over-ranks wall time of the K steps.
+
+Checks on what was timed (failing any aborts the run): every frame's stream digest is equal between the last warm-up
+step and the last timed step; every stream gathered on rank 0 equals the REAL reference's digest
+(tests/golden/bench512_kat.json for seeds 0..511, hevc_kat.json for seeds 0..7) — frames without a golden digest are
+compared with the CPU checker on a sample, or the line says "unverified".
+
+roofline: the HBM view the metric asks for — algorithmic bytes (W*H read + Wp*Hp reconstruction written + stream bytes
+written) per launch / HIP-event duration of the kernel on its launch stream.
+roofline_issue: the bound that binds (VALU issue).  cpu_baseline: the CPU checker on a bounded sample (N=1 only).
+latency_view: one 1080p frame and one 4K frame alone on the GPU (BASELINE configs 1 and 2), kernel ms (N=1 only).
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,13 +44,14 @@ def _gen(seed):
     return synth.syn(W, H, seed)
 
 
-def _cpu_strip(seed):
+def _cpu_strip(args):
     """CPU baseline unit: one 1920x256 strip of syn() — same content class and CTU work as the bench frames."""
+    seed, q = args
     from imcvt_amd import synth
     from oracle import oracle              # cpu_baseline leg: the CPU checker is what is timed here
     img = synth.syn(W, 256, seed)
     t = time.perf_counter()
-    oracle.cpu_encode(img, 0)
+    oracle.cpu_encode(img, q)
     return time.perf_counter() - t
 
 
@@ -48,24 +61,57 @@ def cpu_baseline(qpd6):
     cores = max(1, min(os.cpu_count() or 1, 32))
     t0 = time.perf_counter()
     pool = Pool(cores)
-    pool.map(_cpu_strip, range(cores), chunksize=1)
+    pool.map(_cpu_strip, [(s, qpd6) for s in range(cores)], chunksize=1)
     wall = time.perf_counter() - t0
     pool.close(); pool.join()       # let workers exit normally (a terminate() under rocprofv3 hangs in its signal handler)
     px = cores * W * 256
     return {"value": round(px / wall / 1e6, 4), "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if oracle.have_ref() else "port",
-            "sample": f"{cores} x syn(1920,256,seed) strips (8 CTU rows each), one process per core, qpd6=0, {wall:.1f} s wall"}
+            "sample": f"{cores} x syn(1920,256,seed) strips (8 CTU rows each), one process per core, qpd6={qpd6}, {wall:.1f} s wall"}
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _digests(outs, lens):
+    return [hashlib.sha256(o[:n].cpu().numpy().tobytes()).hexdigest() for o, n in zip(outs, lens)]
+
+
+def golden_digests(qpd6):
+    """seed -> (bytes, sha256) from the committed reference-generated fixtures."""
+    g = {}
+    p = os.path.join(ROOT, "tests", "golden", "bench512_kat.json")
+    if os.path.exists(p):
+        d = json.load(open(p))
+        if d.get("qpd6") == qpd6 and d["input"] == {"kind": "syn", "w": W, "h": H}:
+            g.update({int(k): (v["bytes"], v["sha256"]) for k, v in d["frames"].items()})
+    for e in json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json"))):
+        i = e["input"]
+        if i.get("kind") == "syn" and (i.get("w"), i.get("h")) == (W, H) and e["qpd6"] == qpd6:
+            g[int(i["arg"])] = (e["bytes"], e["sha256"])
+    return g
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 4 frames; just under the 4 x 256 resident-frame capacity of one MI355X)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--total-frames", type=int, default=512, help="strong scaling: frames of the whole job (BASELINE configs[3]: 512)")
+    ap.add_argument("--frames", type=int, default=1000, help="weak scaling: frames per GPU per step")
     ap.add_argument("--qpd6", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-view", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plain: launch the N ranks ourselves, one per GPU, rendezvous on 127.0.0.1
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import numpy as np
     import torch
@@ -74,7 +120,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -84,17 +131,23 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as g
-    g.build()
+    if rank == 0:
+        g.build()
+    if use_dist:
+        dist.barrier()
     import imcvt_amd
+    from imcvt_amd import shard
     from multiprocessing import Pool
 
-    F = args.frames
-    from imcvt_amd import shard
-    seeds = list(shard.frame_range(rank, world, F))
-    pool = Pool(max(1, min(os.cpu_count() or 1, 16)))
+    strong = args.scaling == "strong"
+    seeds = list(shard.split_frames(args.total_frames, rank, world)) if strong else list(shard.frame_range(rank, world, args.frames))
+    F = len(seeds)
+    total_frames = args.total_frames if strong else args.frames * world
+    pool = Pool(max(1, min((os.cpu_count() or 1) // max(1, world), 16)))
     frames_np = pool.map(_gen, seeds, chunksize=4)
     pool.close(); pool.join()
-    big = torch.from_numpy(np.stack(frames_np)).to(dev)            # [F, H, W] resident in HBM before any timing
+    big = torch.from_numpy(np.stack(frames_np)).to(dev) if F else torch.empty((0, H, W), dtype=torch.uint8, device=dev)   # resident in HBM before any timing
+    del frames_np
     enc = imcvt_amd.DeviceEncoder()
     batch = enc.make_batch([big[i] for i in range(F)], args.qpd6)
 
@@ -104,65 +157,111 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        enc.encode(batch)
-    sync_all()
+    gathered = None
     kernel_ms = []
+
+    def step(timed):
+        nonlocal gathered
+        enc.encode(batch)
+        if timed:
+            kernel_ms.append(enc.last_kernel_ms())      # HIP events on the launch stream (synchronises it)
+        if use_dist:                                    # the exchange step: encoded streams to rank 0 over RCCL
+            lens = batch["lens"].cpu().tolist()
+            gathered = shard.gather_streams(shard.pack_streams(batch["outs"], lens), lens, dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    first = _digests(batch["outs"], batch["lens"].cpu().tolist()) if args.warmup else None
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        enc.encode(batch)
-        kernel_ms.append(enc.last_kernel_ms())          # HIP events on the launch stream (synchronises it)
+        step(True)
     sync_all()
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, dev)
 
-    # correctness of what was just timed: digests of this rank's first frames against the reference's golden digests
-    lens = batch["lens"].cpu().numpy()
-    kat = {(e["input"].get("w"), e["input"].get("h"), e["input"].get("arg"), e["qpd6"]): e
-           for e in json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json"))) if e["input"].get("kind") == "syn"}
+    # ---- correctness of what was just timed
+    lens = batch["lens"].cpu().tolist()
+    last = _digests(batch["outs"], lens)
+    if first is not None and first != last:
+        raise SystemExit(f"rank {rank}: {sum(a != b for a, b in zip(first, last))} of {F} frames changed between steps — result invalid")
+    gold = golden_digests(args.qpd6)
     checked = ok = 0
-    for i, s in enumerate(seeds[:8]):
-        e = kat.get((W, H, s, args.qpd6))
-        if e:
-            checked += 1
-            ok += hashlib.sha256(batch["outs"][i][:int(lens[i])].cpu().numpy().tobytes()).hexdigest() == e["sha256"]
-    if checked and ok != checked:
-        raise SystemExit(f"rank {rank}: {checked - ok} of {checked} frames differ from the reference digests — result invalid")
+    verified = ""
+    if rank == 0:
+        if use_dist and gathered is not None:            # what arrived on rank 0, in global frame order
+            all_seeds, all_dig, all_len = [], [], []
+            for r, (ls, packed) in enumerate(gathered):
+                rs = list(shard.split_frames(args.total_frames, r, world)) if strong else list(shard.frame_range(r, world, args.frames))
+                assert len(rs) == len(ls)
+                all_seeds += rs; all_len += ls
+                all_dig += [hashlib.sha256(v.cpu().numpy().tobytes()).hexdigest() for v in shard.unpack_streams(ls, packed)]
+            if all_dig[:F] != last:
+                raise SystemExit("rank 0: gathered streams differ from the local ones — result invalid")
+        else:
+            all_seeds, all_dig, all_len = seeds, last, lens
+        for s, d, n in zip(all_seeds, all_dig, all_len):
+            if s in gold:
+                checked += 1
+                ok += (gold[s] == (n, d))
+        if checked and ok != checked:
+            raise SystemExit(f"{checked - ok} of {checked} streams differ from the reference digests — result invalid")
+        verified = f"{ok}/{len(all_seeds)} streams sha256-equal to reference digests"
+        if checked < len(all_seeds):                      # no golden digest for some frames: check a sample against the CPU checker
+            from oracle import oracle                     # (checker only, outside the timed region)
+            todo = [i for i, s in enumerate(seeds) if s not in gold][:2]
+            for i in todo:
+                ws, wr, _ = oracle.cpu_encode(big[i].cpu().numpy(), args.qpd6)
+                if hashlib.sha256(ws).hexdigest() != last[i]:
+                    raise SystemExit(f"frame seed {seeds[i]} differs from the CPU checker — result invalid")
+            verified += f"; {len(todo)} more byte-equal to the CPU checker; {len(all_seeds) - checked - len(todo)} unverified"
 
     if rank == 0:
-        px_step = F * W * H * world
+        px_step = total_frames * W * H
         value = px_step * args.steps / dt / 1e6
         k_avg = sum(kernel_ms) / len(kernel_ms) / 1e3                      # seconds per launch (rank 0)
         hp, wp = imcvt_amd.padded(H), imcvt_amd.padded(W)
-        algo_bytes = F * (W * H + hp * wp) + int(lens.sum())               # per launch on one GPU
+        ctus = F * (hp // 32) * (wp // 32)
+        algo_bytes = F * (W * H + hp * wp) + int(sum(lens))                # per launch on one GPU
         achieved = algo_bytes / k_avg / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # written by tools/pmc_traffic.py from rocprofv3 --pmc passes (calibrated)
+        traffic, traffic_src = None, "not collected in this run (rocprofv3 --pmc passes: tools/pmc_traffic.py)"
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # calibrated FETCH_SIZE / WRITE_SIZE of a counter run
         if os.path.exists(tp):
             t = json.load(open(tp))
             if t.get("qpd6") == args.qpd6 and t.get("hbm_bytes_per_launch") and t.get("ctus"):
-                # measured per launch of t["ctus"] CTUs of the same content class; CTUs are the unit of work (frames are independent)
-                traffic = int(t["hbm_bytes_per_launch"] * (F * (hp // 32) * (wp // 32)) / t["ctus"])
+                traffic = int(t["hbm_bytes_per_launch"] * ctus / t["ctus"])
+                traffic_src = (f"extrapolated by CTU count from {tp[len(ROOT) + 1:]}: {t.get('frames')} frames of {t.get('width')}x{t.get('height')}, "
+                               f"{t['ctus']} CTUs, {t['hbm_bytes_per_launch']} B per launch")
         macs = 12320 * hp * wp * F                                          # transform MACs per launch
+        mode = f"{'strong' if strong else 'weak'}: {total_frames} frames over {world} GPU(s), {F} on rank 0"
         line = {
-            "metric": "Mpixels/s HEVC intra encode (gray8), bit-exact vs CPU", "value": round(value, 3), "unit": "Mpixels/s",
+            "metric": "Mpixels/s HEVC intra encode (gray8), bit-exact vs CPU" if checked else "Mpixels/s HEVC intra encode (gray8)",
+            "value": round(value, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 (u8 pixels, i8 transform matrices, i32 accumulate)",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "i32 (u8 pixels, i8 transform matrices, i32 accumulate)",
             "data": "synthetic syn(1920,1080,seed), SURVEY App. C",
-            "config": {"workload": f"BASELINE configs[3]: batch of {F} independent 1920x1080 gray8 frames per GPU -> .h265, qpd6={args.qpd6}, frame-sharded",
-                       "frames_per_gpu": F, "global_frames": F * world, "width": W, "height": H, "qpd6": args.qpd6,
-                       "parallelism": f"frames x{world} (no data-path collective)", "stream_bytes_per_frame": int(lens.mean()),
-                       "verified": f"{ok}/{checked} streams sha256-equal to reference digests"},
+            "config": {"workload": f"BASELINE configs[3]: batch of {total_frames} independent 1920x1080 gray8 frames -> .h265, qpd6={args.qpd6}, frame-sharded ({mode})",
+                       "global_frames": total_frames, "frames_rank0": F, "width": W, "height": H, "qpd6": args.qpd6,
+                       "parallelism": f"frames x{world}; streams gathered to rank 0 over RCCL (send/recv)" if use_dist else "frames x1 (single GPU, no collective)",
+                       "stream_bytes_per_frame": int(sum(lens) / max(1, F)), "verified": verified,
+                       "step_to_step": "all frames digest-equal between the last warm-up step and the last timed step" if first is not None else "not checked (no warm-up)",
+                       "encoder": imcvt_amd.load_library().imcvt_hevc_version().decode()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 8),
-                         "traffic": traffic, "kernel": "hevc_encode_frames", "kernel_ms": round(k_avg * 1e3, 2), "algorithmic_bytes": algo_bytes},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "hevc_encode_frames", "kernel_ms": round(k_avg * 1e3, 2), "algorithmic_bytes": algo_bytes},
             "compute_view": {"transform_GMAC_per_launch": round(macs / 1e9, 1), "achieved_TMAC_s": round(macs / k_avg / 1e12, 4),
                              "note": "path is integer-ALU / serial-CABAC bound, not HBM bound (SURVEY F6, DESIGN.md §5)"},
         }
         ip = os.path.join(ROOT, "profiles", "pmc_issue.json")             # SQ counter passes (tools/gpu_prof.sh): what actually bounds the kernel
         if os.path.exists(ip):
             iv = json.load(open(ip))
-            line["issue_view"] = {"bound": "valu issue", "valu_busy_frac": iv["valu_busy_frac"], "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"],
-                                  "waves_per_simd": iv["waves_per_simd"], "source": iv["source"]}
+            insts = iv["valu_wave_insts_per_ctu"] * ctus
+            peak = 256 * 4 * 2.4e9 / 2                                     # wave-instructions/s: 256 CUs x 4 SIMD-32, 2 cycles per wave64 VALU instruction
+            line["roofline_issue"] = {"bound": "valu issue", "achieved": round(insts / k_avg / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-inst/s",
+                                      "frac": round(insts / k_avg / peak, 4), "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"],
+                                      "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": "instruction count per CTU from " + iv["source"] + "; time from this run"}
+        if world == 1 and not args.no_latency_view:
+            line["latency_view"] = latency_view(enc, dev, args.qpd6)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.qpd6)
         print(json.dumps(line), flush=True)
@@ -170,6 +269,26 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def latency_view(enc, dev, qpd6):
+    """BASELINE configs 1 and 2: ONE frame alone on the GPU (kernel ms from HIP events, inputs resident)."""
+    import torch
+    from imcvt_amd import synth
+    out = {}
+    gold = {(e["input"].get("w"), e["input"].get("arg"), e["qpd6"]): e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json"))) if e["input"].get("kind") == "syn"}
+    for name, (w, h) in (("1080p", (1920, 1080)), ("4k", (3840, 2160))):
+        img = torch.from_numpy(synth.syn(w, h, 0)).to(dev)
+        b = enc.make_batch([img], qpd6)
+        enc.encode(b)
+        ms = enc.last_kernel_ms()
+        n = int(b["lens"][0].item())
+        e = gold.get((w, 0, qpd6))
+        okd = (hashlib.sha256(b["outs"][0][:n].cpu().numpy().tobytes()).hexdigest() == e["sha256"]) if e else None
+        if okd is False:
+            raise SystemExit(f"latency_view {name}: stream differs from the reference digest")
+        out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(w * h / ms / 1e3, 3), "bytes": n, "sha256_equal_to_reference": okd}
+    return out
 
 
 if __name__ == "__main__":

@@ -1,6 +1,9 @@
 """Frame sharding for multi-GPU runs (one process per GPU).  Frames are independent units: rank r of
-`world` owns a contiguous block of the global frame list; nothing is exchanged on the data path.  The only
-collectives are bookkeeping: a MAX-reduce of the wall time and, if a driver wants it, a gather of stream lengths."""
+`world` owns a contiguous block of the global frame list (the reference's seam is its serial file loop,
+src/main.c:162-211); nothing is exchanged while encoding.  Cross-rank traffic is the bookkeeping (a MAX-reduce of the
+wall time) and the one real exchange step the job has: the gather of the encoded streams to rank 0 — an all-gather of
+the per-frame lengths, then one point-to-point send per peer of its packed streams (variable size; over RCCL each
+peer uses its own xGMI link to the root)."""
 
 
 def frame_range(rank: int, world: int, frames_per_rank: int):
@@ -28,12 +31,62 @@ def max_over_ranks(seconds: float, device=None) -> float:
 
 
 def gather_lengths(lengths, device=None):
-    """All ranks' per-frame stream lengths, rank-major (list of lists)."""
+    """All ranks' per-frame stream lengths, rank-major (list of lists).  Ranks may own different numbers of frames."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [list(lengths)]
-    t = torch.tensor(list(lengths), dtype=torch.int64, device=device if device is not None else "cpu")
-    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dev = device if device is not None else "cpu"
+    world = dist.get_world_size()
+    lengths = list(lengths)
+    cnt = torch.tensor([len(lengths)], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    cnts = [int(c.item()) for c in cnts]
+    m = max(cnts + [1])
+    t = torch.tensor(lengths + [0] * (m - len(lengths)), dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
-    return [o.cpu().tolist() for o in out]
+    return [o.cpu().tolist()[:cnts[r]] for r, o in enumerate(out)]
+
+
+def pack_streams(outs, lengths):
+    """One contiguous uint8 tensor holding this rank's streams back to back (outs[i][:lengths[i]], frame order)."""
+    import torch
+    if not outs:
+        return torch.empty(0, dtype=torch.uint8)
+    return torch.cat([o[:n] for o, n in zip(outs, lengths)])
+
+
+def gather_streams(packed, lengths, device=None):
+    """The job's exchange step: every rank's packed streams arrive on rank 0.
+
+    packed: this rank's streams back to back (pack_streams), on `device` for RCCL or on the CPU for gloo.
+    Returns on rank 0 a list over ranks of (lengths, packed tensor) — rank 0's own entry is its input — and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    lengths = list(lengths)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [(lengths, packed)]
+    all_lens = gather_lengths(lengths, device)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank != 0:
+        if packed.numel():
+            dist.send(packed, dst=0)
+        return None
+    res = [(lengths, packed)]
+    for r in range(1, world):
+        buf = torch.empty(sum(all_lens[r]), dtype=torch.uint8, device=packed.device)
+        if buf.numel():
+            dist.recv(buf, src=r)
+        res.append((all_lens[r], buf))
+    return res
+
+
+def unpack_streams(lengths, packed):
+    """Inverse of pack_streams: list of 1-D uint8 views."""
+    out, pos = [], 0
+    for n in lengths:
+        out.append(packed[pos:pos + n])
+        pos += n
+    return out

@@ -25,50 +25,50 @@ def _xs(s: int) -> int:
     return s
 
 
-def _xorshift_stream(seed: int, n: int) -> np.ndarray:
-    """n successive xorshift32 states after seed0(seed) (state AFTER each step)."""
-    # xorshift32 is linear over GF(2): state_k = A^k state_0.  Vectorise with a jump table: generate the
-    # first B states serially, then advance whole blocks with the B-step matrix applied via bit tricks.
-    # For the sizes used here (<= 8.3 M pixels) a chunked serial generator in numpy-uint32 is enough:
-    out = np.empty(n, dtype=np.uint32)
-    s = seed0(seed)
-    B = 4096
-    # serial for first block
-    first = min(B, n)
-    for i in range(first):
-        s = _xs(s)
-        out[i] = s
-    if n <= B:
-        return out
-    # Build the B-step linear map as 32 basis images, then apply it column-wise to previous block.
-    basis = np.empty(32, dtype=np.uint32)
+_JUMP = {}       # log2(steps) -> the `steps`-step linear map of xorshift32 as 32 basis images
+
+
+def _apply_map(basis: np.ndarray, src: np.ndarray) -> np.ndarray:
+    acc = np.zeros(src.shape, dtype=np.uint32)
     for b in range(32):
-        v = 1 << b
-        for _ in range(B):
-            v = _xs(v)
-        basis[b] = v
-    pos = B
-    prev = out[:B]
-    while pos < n:
-        m = min(B, n - pos)
-        src = prev[:m]
-        acc = np.zeros(m, dtype=np.uint32)
-        for b in range(32):
-            mask = ((src >> np.uint32(b)) & np.uint32(1)).astype(bool)
-            acc[mask] ^= basis[b]
-        out[pos:pos + m] = acc
-        prev = out[pos:pos + m] if m == B else prev
-        pos += m
-    return out
+        acc ^= basis[b] * ((src >> np.uint32(b)) & np.uint32(1))
+    return acc
+
+
+def _jump_map(k: int) -> np.ndarray:
+    """Basis images of A^(2^k) (A = one xorshift32 step, linear over GF(2)), by repeated squaring."""
+    if k not in _JUMP:
+        if k == 0:
+            _JUMP[0] = np.array([_xs(1 << b) for b in range(32)], dtype=np.uint32)
+        else:
+            prev = _jump_map(k - 1)
+            _JUMP[k] = _apply_map(prev, prev)
+    return _JUMP[k]
+
+
+def _xorshift_stream(seed: int, n: int) -> np.ndarray:
+    """n successive xorshift32 states after seed0(seed) (state AFTER each step).
+    state_k = A^k state_0, so the second half of a 2^(j+1)-state prefix is the 2^j-step map applied to the first half:
+    the stream is built by doubling, 32 vector passes per doubling."""
+    out = np.empty(max(n, 1), dtype=np.uint32)
+    out[0] = _xs(seed0(seed))
+    have, k = 1, 0
+    while have < n:
+        m = min(have, n - have)
+        out[have:have + m] = _apply_map(_jump_map(k), out[:m])
+        have += m
+        k += 1
+    return out[:n]
 
 
 def syn(w: int, h: int, seed: int) -> np.ndarray:
     s = _xorshift_stream(seed, w * h).reshape(h, w)
-    y, x = np.mgrid[0:h, 0:w]
+    y = np.arange(h, dtype=np.int32)[:, None]
+    x = np.arange(w, dtype=np.int32)[None, :]
     g = ((3 * x + 5 * y) >> 4) & 0xFF
     t = (((x >> 4) ^ (y >> 4)) * 37) & 0x3F
-    n = (s & 0x0F).astype(np.int64)
-    return np.minimum(255, (g >> 1) + t + n + 32).astype(np.uint8)
+    v = (g >> 1) + t + 32 + (s & np.uint32(0x0F)).astype(np.int32)
+    return np.minimum(255, v).astype(np.uint8)
 
 
 def noise(w: int, h: int, seed: int) -> np.ndarray:

@@ -59,3 +59,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt and "libref_" not in txt, f
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference checkout exists only in the dev container")
+def test_reference_main_links_against_the_library_unchanged(built, tmp_path):
+    """the reference's own main.c + format modules, minus HEVCe.c and imageio_hevc.c, link against
+    libimcvt_hevc.so with no source change; writeHEVCImageFile resolves to the library, and the binary fails loudly
+    (reference error line, exit code 1) on a machine without a device."""
+    import subprocess
+    csrc = os.path.join(ROOT, "imcvt_amd", "csrc")
+    inc = tmp_path / "inc"
+    inc.mkdir()
+    os.symlink(os.path.join(REF_SRC, "uPNG", "uPNG.h"), inc / "upng.h")      # the reference's own case bug (SURVEY F8), not ours
+    exe = str(tmp_path / "ImCvt")
+    srcs = [os.path.join(REF_SRC, f) for f in ("main.c", "imageio_pnm.c", "imageio_png.c", "imageio_bmp.c", "imageio_qoi.c", "imageio_jls.c", "uPNG/uPNG.c")]
+    subprocess.run(["gcc", *srcs, "-O1", "-w", "-I", str(inc), "-o", exe, "-L" + csrc, "-limcvt_hevc", "-Wl,-rpath," + csrc], check=True)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    assert "writeHEVCImageFile" in nm and "HEVCImageEncoder" not in nm.replace("writeHEVCImageFile", "")
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libimcvt_hevc.so" in ldd and "not found" not in ldd
+    if not os.path.exists("/dev/kfd"):
+        src = tmp_path / "in.pgm"
+        src.write_bytes(b"P5\n8 8\n255\n" + bytes(64))
+        r = subprocess.run([exe, str(src), "-o", str(tmp_path / "out.h265")], capture_output=True, text=True)
+        assert r.returncode == 1 and "***ERROR" in r.stdout and "no CPU fallback" in r.stderr
+        assert not (tmp_path / "out.h265").exists()

@@ -1,5 +1,6 @@
-"""The N>1 path on CPU: two gloo ranks shard a frame list, agree on the job time (MAX) and gather per-frame
-stream lengths — the only cross-rank traffic the multi-GPU bench has (frames are independent).
+"""The N>1 path on CPU: two gloo ranks shard a frame list, agree on the job time (MAX), gather per-frame stream
+lengths and — the job's one exchange step — gather the encoded streams themselves to rank 0 (imcvt_amd/shard.py, the same
+code bench.py runs over RCCL).  Frames are independent, so nothing else crosses ranks.
 The per-rank "encoder" here is the CPU checker, used as test infrastructure to give the shards real payloads."""
 import os
 import socket
@@ -22,12 +23,25 @@ def _worker(rank, world, port, q):
     from oracle import oracle, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import torch
     mine = shard.frame_range(rank, world, 3)
     lens = [len(oracle.port_encode(synth.syn(40, 24, s), 2)[0]) for s in mine]
     t = shard.max_over_ranks(1.0 + rank)                 # slowest rank defines the job time
     all_lens = shard.gather_lengths(lens)
+    # strong-scaled job of 7 frames (4 + 3): encoded streams gathered to rank 0, as bench.py does over RCCL
+    own = list(shard.split_frames(7, rank, world))
+    streams = [oracle.port_encode(synth.syn(40, 24, s), 1)[0] for s in own]
+    outs = [torch.from_numpy(np.frombuffer(b + bytes(5), dtype=np.uint8).copy()) for b in streams]   # buffers longer than the streams, like the device ones
+    slens = [len(b) for b in streams]
+    got = shard.gather_streams(shard.pack_streams(outs, slens), slens)
+    gathered = None
+    if rank == 0:
+        gathered = [bytes(v.numpy().tobytes()) for ls, packed in got for v in shard.unpack_streams(ls, packed)]
+    else:
+        assert got is None
     dist.barrier()
-    q.put((rank, list(mine), lens, t, all_lens))
+    q.put((rank, list(mine), lens, t, all_lens, gathered))
     dist.destroy_process_group()
 
 
@@ -47,6 +61,8 @@ def test_two_rank_frame_sharding(built):
     want = [len(oracle.port_encode(synth.syn(40, 24, s), 2)[0]) for s in range(6)]
     for r in res:
         assert sum(r[4], []) == want                                           # every rank sees all lengths, in frame order
+    # rank 0 holds all 7 streams of the strong-scaled job, byte-equal to a single-process run, in frame order
+    assert res[0][5] == [oracle.port_encode(synth.syn(40, 24, s), 1)[0] for s in range(7)] and res[1][5] is None
     # strong-scaling partition covers a list exactly once
     for n in (0, 1, 7, 512):
         got = [i for k in range(3) for i in shard.split_frames(n, k, 3)]
