@@ -41,6 +41,13 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD int clz32(u32 v) { return v ? __builtin_clz(v) : 32; }
   HD u64 wave_ballot(int p) { return emu_ballot(p); }
   HD int wave_shfl(int v, int src_lane) { return emu_shfl(v, src_lane); }
+  // cross-workgroup flags (teams): the emulated workgroups are fibers of one thread, so plain accesses are coherent
+  static void emu_yield();
+  HD i32 flag_load(const i32 *p) { return *(const volatile i32 *)p; }
+  HD void flag_poll_pause() { emu_yield(); }
+  HD void flag_acquire() {}
+  HD void flag_release_store(i32 *p, i32 v) { *(volatile i32 *)p = v; }
+  HD void drain_stores() {}
 #else
   #define HD __device__ __forceinline__
   #define HDN __device__ __noinline__
@@ -58,6 +65,20 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_max(i32 *p, i32 v) { return atomicMax(p, v); }
   HD u32 lds_or(u32 *p, u32 v) { return atomicOr(p, v); }
   HD int clz32(u32 v) { return __clz((int)v); }
+  // Cross-workgroup hand-off (teams, hevc_frame.h).  Per-XCD L2s are not coherent with each other and a CU's L1 is never
+  // refreshed by another CU's stores, so: the producer drains its stores, writes the XCD's dirty L2 lines back (agent-scope
+  // release) and only then stores the flag; the consumer polls the flag with relaxed agent-scope loads (L1 bypassed) and
+  // invalidates its CU's L1 (agent-scope acquire) before any payload load.  The explicit vmcnt(0) keeps the flag from
+  // overtaking the write-back (the compiler may drop the fence's own wait when its scoreboard looks empty).
+  HD i32 flag_load(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  HD void flag_poll_pause() { __builtin_amdgcn_s_sleep(4); }
+  HD void flag_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+  HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  HD void flag_release_store(i32 *p, i32 v) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #endif
 
 #if defined(IMCVT_HOSTEMU)
@@ -76,6 +97,7 @@ HD void g_st8(u8 *p, int v) { *p = (u8)v; }
 HD void g_st16(i16 *p, int v) { *p = (i16)v; }
 HD void g_st32(void *p, u32 v) { *(u32a *)p = v; }
 HD u8 g_ld8(const u8 *p) { return *p; }
+HD u32 g_ld32(const void *p) { return *(const u32a *)p; }
 HD i16 g_ld16(const i16 *p) { return *p; }
 HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
 HD void g_st128(void *p, const U4 &v) { *(U4 *)p = v; }
@@ -90,6 +112,7 @@ HD void g_st8(u8 *p, int v) { *(GAS u8 *)p = (u8)v; }
 HD void g_st16(i16 *p, int v) { *(GAS i16 *)p = (i16)v; }
 HD void g_st32(void *p, u32 v) { *(GAS u32 *)p = v; }
 HD u8 g_ld8(const u8 *p) { return *(const GAS u8 *)p; }
+HD u32 g_ld32(const void *p) { return *(const GAS u32 *)p; }
 HD i16 g_ld16(const i16 *p) { return *(const GAS i16 *)p; }
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 HD U4 g_ld128(const void *p) { const u32x4 v = *(const GAS u32x4 *)p; U4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
@@ -207,6 +230,7 @@ struct alignas(16) WaveMem {
 };
 #define WAVE2_BYTES (sizeof(WaveMem) - 7168 + W2_PAD + NMODE * 16)
 
+#define TRIAL_BYTES 3584
 // Per-frame job and per-workgroup scratch (global memory)
 struct FrameJob {
     const u8 *img;   // h*w gray8
@@ -216,7 +240,6 @@ struct FrameJob {
     i32 hdr_len;     // header bytes already placed at out[0..hdr_len)
     i32 *out_len;    // result
 };
-#define TRIAL_BYTES 3584
 #define TOK_CAP 7040             // u16 per candidate stream: 18 (CU header) + 4 x 25 (cbf + last position per TU) + 64 groups x 108, rounded to 16 bytes
 #define TOK_SLOTS (NMODE + 1)
 struct Scratch {
@@ -238,12 +261,45 @@ static inline void scratch_carve(Scratch &sc, u8 *base) {
     sc.trace = nullptr; sc.trace_cap = 0; sc.prof = nullptr;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Teams: a frame encoded by several cooperating workgroups (hevc_frame.h).  The candidate sets of a 16x16 / 32x32 CU
+// start from the coder state at the CU's ENTRY (:1363-1364, :1422, :1455) and predict from samples outside the CU
+// (:196-257), so they do not depend on the CU's children: helper workgroups evaluate them while the main workgroup walks
+// the 8x8 CUs.  Requests and results travel through one mailbox per request kind in global memory.
+// ---------------------------------------------------------------------------------------------------
+enum { SLOT_16 = 0, SLOT_32 = 1, MAIL_SLOTS = 2 };
+enum { OP_WORK = 0, OP_EXIT = 1 };
+struct alignas(16) HelpReq {                     // main -> helper: everything the candidate sets of one CU start from
+    i32 op, frame, cy, cx;                       // job index, CTU origin
+    i32 N, y0, x0, avm;                          // the CU inside the CTU, neighbour availability
+    i32 szl, sza, ml, ma;                        // CU size / mode of the left and above neighbour cells (split flag context, MPM)
+    Arith a; i32 pad_;                           // coder state at the CU's entry
+    alignas(4) u8 ctx[CTX_STRIDE];               // contexts at the CU's entry
+};
+struct alignas(16) HelpRes {                     // helper -> main: the best unsplit candidate ("last minimum" of the 70)
+    i32 cost, kind, mode, nbytes;                // kind 1: one TU, 2: four TUs; nbytes: bytes the winning trial emitted
+    FinState fin; i32 pad_;                      // coder state the winning trial ended in
+    alignas(4) u8 ctx[CTX_STRIDE];               // its contexts
+    alignas(16) u8 rec[1024];                    // its reconstruction, N x N row-major
+    alignas(16) u8 bytes[TRIAL_BYTES];           // its bytes
+};
+struct alignas(256) MailSlot {
+    i32 req_flag; i32 pad0_[63];                 // sequence number of the request in `req` (flags on their own lines)
+    i32 res_flag; i32 pad1_[63];                 // sequence number of the result in `res`
+    HelpReq req;
+    HelpRes res;
+};
+struct TeamMail { MailSlot s[MAIL_SLOTS]; };
+
 struct FrameCtx {
     FrameJob job;
     Scratch sc;
     i32 out_pos;        // bytes of finished CTUs (incl. headers)
     i32 ctu_y, ctu_x;   // pixel origin of the current CTU
     i32 trace_n;
+    i32 frame;          // index of the job being encoded
+    TeamMail *mail;     // this team's mailboxes (null: the workgroup encodes its frames alone)
+    i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
 };
 
 struct FourTU {                  // state of the four-TU shape (one wave evaluates it at a time)
@@ -265,6 +321,7 @@ struct alignas(16) Shm {
     i32 split_cost[3];
     i32 win_kind, win_mode;      // decision broadcast
     i32 red[NWAVES];             // small reductions
+    i32 next_frame;              // job index pulled from the queue
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
 #endif

@@ -22,6 +22,7 @@ HD Avail child_avail(const Avail &p, int k) {       // Z-order availability of q
     return c;
 }
 #define F (SM.F)
+#define HDR_MAX 96       // bytes reserved per frame for the stream headers the host prepares (:664-690)
 
 HD u16 *wave_tok(const Scratch &sc, int wave) { return sc.tok + (size_t)wave * TOK_SLOTS * TOK_CAP; }
 HD u8 *lane_bytes(const Scratch &sc, int wave, int lane) { return sc.bytes + ((size_t)wave * NMODE + lane) * TRIAL_BYTES; }
@@ -210,10 +211,36 @@ HDN void eval_NxN(int wave, int y0, int x0, int avm) {
     prof_add(PF_P2_NXN, ptn);
 }
 
+// ---- the winner's reconstruction (only the winner's is ever needed, so candidates do not store theirs): the winning
+// 2Nx2N shape is run once more, writing the tile.  All waves call this; wave 0 works.
+HDN void rebuild_winner(int kind, int mode, int N, int y0, int x0, int avm) {
+    const Avail av = unpack_avail(avm);
+    WAVES(w) {
+        if (w == 0) {
+            const int wave = 0;
+            P1Args P;
+            P.q = F.job.q; P.only_mode = mode; P.shape = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.tok = (u16 *)0;
+            P.own = 0; P.c_lo = 0; P.c_hi = 1;
+            if (kind == 1) {
+                border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
+                P.N = N; P.y0 = y0; P.x0 = x0;
+                p1_run_cold(wave, P);
+            } else {
+                const int h = N / 2;
+                for (int k = 0; k < 4; k++) {
+                    const Avail ca = child_avail(av, k);
+                    P.N = h; P.y0 = y0 + (k >> 1) * h; P.x0 = x0 + (k & 1) * h;
+                    border_from_tile(wave, h, P.y0, P.x0, ca.l, ca.bl, ca.a, ca.ar);
+                    p1_run_cold(wave, P);
+                }
+            }
+        }
+    }
+}
+
 // ---- one CU after its children (if any) are done: evaluate the unsplit shapes, decide, commit ---------------------
 // All waves call this with identical arguments.
 HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
-    const Avail av = unpack_avail(avm);
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES(w) {
         if (w < 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
@@ -257,36 +284,15 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
         }
         wg_sync_p();
         const long long ptr_ = prof_now();
-        if (kind != 3) {                                    // rebuild the winner's reconstruction in the tile
-            WAVES(w) {
-                if (w == 0) {
-                    const int wave = 0;
-                    P1Args P;
-                    P.q = F.job.q; P.only_mode = mode; P.shape = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.tok = (u16 *)0;
-                    P.own = 0; P.c_lo = 0; P.c_hi = 1;
-                    if (kind == 1) {
-                        border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
-                        P.N = N; P.y0 = y0; P.x0 = x0;
-                        p1_run_cold(wave, P);
-                    } else {
-                        const int h = N / 2;
-                        for (int k = 0; k < 4; k++) {
-                            const Avail ca = child_avail(av, k);
-                            P.N = h; P.y0 = y0 + (k >> 1) * h; P.x0 = x0 + (k & 1) * h;
-                            border_from_tile(wave, h, P.y0, P.x0, ca.l, ca.bl, ca.a, ca.ar);
-                            p1_run_cold(wave, P);
-                        }
-                    }
-                }
-            }
-        }
+        if (kind != 3) rebuild_winner(kind, mode, N, y0, x0, avm);     // the winner's reconstruction into the tile
         prof_add(PF_RECON, ptr_);
         wg_sync_p();
     }
 }
 
 // snapshot the live coder as the entry state of `depth`, optionally after coding split_cu_flag=1 (:1363-1364, :1403)
-HDN void enter_cu(int depth, int N, int y0, int x0, int code_split) {
+HDN void post_request(int depth, int N, int y0, int x0, int avm);
+HDN void enter_cu(int depth, int N, int y0, int x0, int code_split, int avm) {
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
@@ -294,6 +300,7 @@ HDN void enter_cu(int depth, int N, int y0, int x0, int code_split) {
         if (tid == 64) SM.entry_a[depth] = SM.live;
     }
     wg_sync();
+    if (F.mail && N >= 16) post_request(depth, N, y0, x0, avm);     // team: a helper starts on this CU's 70 unsplit candidates now
     if (code_split) {
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
@@ -334,6 +341,197 @@ HDN void price_split(int depth, int N, int y0, int x0) {
     wg_sync();
 }
 
+
+// =====================================================================================================================
+// Teams: one frame, several workgroups.
+// The 70 unsplit candidates of a 16x16 / 32x32 CU start from the coder state at the CU's entry and predict from samples
+// outside the CU, so nothing in them depends on the CU's children (reference :1363-1364, :1419-1483).  In a team the main
+// workgroup posts that entry state when it enters the CU, walks the children itself, and picks up the helper's answer —
+// the last minimum among the 70, with its coder state, contexts, bytes and reconstruction — when it has priced the split
+// (:1408-1409).  The decision is the reference's: split cost first, then the candidates in order, each accepted with
+// `best >= cost`, i.e. the last minimum of the 70 wins iff it does not exceed the split cost.
+// =====================================================================================================================
+// All threads call these.  publish: everything this workgroup stored so far is visible to whoever then sees flag == v.
+HD void team_publish(i32 *flag, i32 v) {
+    drain_stores();
+    wg_sync();
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) flag_release_store(flag, v); }
+}
+// await: returns once flag == v; loads issued afterwards see what the publisher stored before publishing
+HD void team_await(i32 *flag, i32 v) {
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) {
+            while (flag_load(flag) != v) flag_poll_pause();
+            flag_acquire();
+        }
+    }
+    wg_sync();
+}
+HD int slot_of(int N) { return N == 32 ? SLOT_32 : SLOT_16; }
+
+// main: post the entry state of the CU at (y0,x0,N) — call right after enter_cu's snapshot, before the split flag is coded
+HDN void post_request(int depth, int N, int y0, int x0, int avm) {
+    const int slot = slot_of(N);
+    MailSlot *m = &F.mail->s[slot];
+    const int uy = y0 >> 2, ux = x0 >> 2;
+    WAVES(w) LANES(l) {
+        const int tid = w * 64 + l;
+        if (tid < CTX_STRIDE / 4) g_st32(m->req.ctx + 4 * tid, *(const u32a *)&SM.entry_cx[depth][4 * tid]);
+        if (tid == 64) {
+            i32 *r = (i32 *)&m->req;
+            const Arith a = SM.entry_a[depth];
+            const i32 v[20] = { OP_WORK, F.frame, F.ctu_y, F.ctu_x, N, y0, x0, avm, nb_size(uy, ux - 1), nb_size(uy - 1, ux), nb_mode(uy, ux - 1), nb_mode(uy - 1, ux),
+                                a.range, a.low, a.nbits, a.nbytes, a.bufbyte, a.zeros, a.cnt, 0 };
+            for (int i = 0; i < 20; i++) g_st32(r + i, (u32)v[i]);
+        }
+        if (tid == 0) F.seq[slot]++;
+    }
+    team_publish(&m->req_flag, F.seq[slot] + 0);       // (F.seq is read after the barrier inside)
+}
+HDN void post_exit(int slot) {
+    MailSlot *m = &F.mail->s[slot];
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { g_st32(&m->req.op, (u32)OP_EXIT); F.seq[slot]++; } }
+    team_publish(&m->req_flag, F.seq[slot] + 0);
+}
+
+// main: the CU's children are done and the split is priced — take the helper's answer and decide (:1439, :1475)
+HDN void decide_remote(int depth, int N, int y0, int x0) {
+    const int slot = slot_of(N);
+    MailSlot *m = &F.mail->s[slot];
+    u8 *live_sink = F.job.out + F.out_pos;
+    const long long t0 = prof_now();
+    team_await(&m->res_flag, F.seq[slot]);
+    prof_add(PF_SYNC, t0);
+    const HelpRes *R = &m->res;
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) {
+            const int cost = (int)g_ld32(&R->cost), take = SM.split_cost[depth] >= cost;
+            SM.win_kind = take ? (int)g_ld32(&R->kind) : 0; SM.win_mode = (int)g_ld32(&R->mode);
+            if (F.sc.trace && F.trace_n + 8 <= F.sc.trace_cap) {
+                i32 *t = F.sc.trace + F.trace_n;
+                t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = N; t[3] = SM.win_kind; t[4] = SM.win_mode;
+                t[5] = take ? cost : SM.split_cost[depth]; t[6] = 0; t[7] = 0;
+                F.trace_n += 8;
+            }
+        }
+    }
+    wg_sync();
+    const int kind = SM.win_kind, mode = SM.win_mode;
+    if (kind != 0) {
+        const int cnt0 = SM.entry_a[depth].cnt, nbytes = (int)g_ld32(&R->nbytes);
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            for (int i = tid; i < nbytes; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(R->bytes + i));
+            if (tid < CTX_STRIDE / 4) *(u32a *)&SM.cx[4 * tid] = g_ld32(R->ctx + 4 * tid);
+            if (tid == 64) { FinState f; f.w0 = g_ld32(&R->fin.w0); f.w1 = g_ld32(&R->fin.w1); f.w2 = g_ld32(&R->fin.w2); SM.live = unpack_arith(f); }
+            if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445)
+                const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
+                if (i < n && j < n) {
+                    const int uy = (y0 >> 2) + i, ux = (x0 >> 2) + j;
+                    SM.mapsz[uy + 1][ux + 1] = (u8)N; SM.mapmode[uy + 1][ux + 1] = (u8)mode;
+                }
+            }
+            for (int i = tid; i < N * N / 4; i += WG_THREADS) {      // its reconstruction replaces the children's (:1441, :1477)
+                const int y = i / (N / 4), x4 = (i % (N / 4)) * 4;
+                const u32 v = g_ld32(R->rec + y * N + x4);
+                u8 *d = &SM.rec[y0 + y + 1][x0 + x4 + 1];
+                d[0] = (u8)v; d[1] = (u8)(v >> 8); d[2] = (u8)(v >> 16); d[3] = (u8)(v >> 24);
+            }
+        }
+        wg_sync();
+    }
+}
+
+// main: the decided CU's reconstruction goes to the frame's reconstruction plane right away — the next 16x16 request's
+// helper reads its borders from there (the whole CTU is stored again when it is finished, :1625-1627)
+HD void store_cu_rec(int N, int y0, int x0) {
+    const FrameJob &J = F.job;
+    WAVES(w) LANES(l) {
+        const int tid = w * 64 + l;
+        for (int i = tid; i < N * N; i += WG_THREADS) {
+            const int y = y0 + i / N, x = x0 + i % N;
+            g_st8(J.rcon + (size_t)(F.ctu_y + y) * J.wp + F.ctu_x + x, SM.rec[y + 1][x + 1]);
+        }
+    }
+}
+
+// helper: serve one request — load what the candidate sets read, evaluate the 70 candidates, answer with the last minimum
+HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
+    const HelpReq *Q = &m->req;
+    HelpRes *R = &m->res;
+    const int frame = (int)g_ld32(&Q->frame), cy = (int)g_ld32(&Q->cy), cx = (int)g_ld32(&Q->cx);
+    const int N = (int)g_ld32(&Q->N), y0 = (int)g_ld32(&Q->y0), x0 = (int)g_ld32(&Q->x0), avm = (int)g_ld32(&Q->avm);
+    const int depth = (N == 32) ? 0 : 1;
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) { F.job = jobs[frame]; F.ctu_y = cy; F.ctu_x = cx; F.out_pos = 0; F.trace_n = 0; }
+    }
+    wg_sync();
+    const FrameJob J = F.job;
+    WAVES(w) LANES(l) {
+        const int tid = w * 64 + l;
+        NOUNROLL
+        for (int i = tid; i < 1024; i += WG_THREADS) {      // source pixels of the CTU (:1621)
+            const int y = i >> 5, x = i & 31;
+            SM.org[y][x] = g_ld8(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1));
+        }
+        NOUNROLL
+        for (int i = tid; i < 65 + 32 * 33; i += WG_THREADS) {   // reconstruction around and inside the CTU as the main workgroup has published it
+            const int y = (i < 65) ? -1 : (i - 65) / 33, x = (i < 65) ? i - 1 : (i - 65) % 33 - 1;
+            SM.rec[y + 1][x + 1] = g_ld8(J.rcon + (size_t)clip3(cy + y, 0, J.hp - 1) * J.wp + clip3(cx + x, 0, J.wp - 1));
+        }
+        if (tid < CTX_STRIDE / 4) *(u32a *)&SM.entry_cx[depth][4 * tid] = g_ld32(Q->ctx + 4 * tid);
+        if (tid == 64) {
+            const i32 *r = (const i32 *)&Q->a;
+            Arith a; a.range = (i32)g_ld32(r); a.low = (i32)g_ld32(r + 1); a.nbits = (i32)g_ld32(r + 2); a.nbytes = (i32)g_ld32(r + 3);
+            a.bufbyte = (i32)g_ld32(r + 4); a.zeros = (i32)g_ld32(r + 5); a.cnt = (i32)g_ld32(r + 6);
+            SM.entry_a[depth] = a;
+            const int uy = y0 >> 2, ux = x0 >> 2;                 // the two neighbour cells the CU header reads (:942-946, :957-976)
+            SM.mapsz[uy + 1][ux] = (u8)g_ld32(&Q->szl); SM.mapsz[uy][ux + 1] = (u8)g_ld32(&Q->sza);
+            SM.mapmode[uy + 1][ux] = (u8)g_ld32(&Q->ml); SM.mapmode[uy][ux + 1] = (u8)g_ld32(&Q->ma);
+        }
+    }
+    wg_sync();
+    WAVES(w) eval_2Nx2N(w, depth, N, y0, x0, avm);
+    wg_sync();
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) {
+            int best = I32MAX, kind = 1, mode = 0;
+            for (int c = 0; c < NMODE; c++) if (best >= WM(0).cost[c]) { best = WM(0).cost[c]; kind = 1; mode = c; }
+            for (int c = 0; c < NMODE; c++) if (best >= WM(1).cost[c]) { best = WM(1).cost[c]; kind = 2; mode = c; }
+            SM.win_kind = kind; SM.win_mode = mode; SM.red[0] = best;
+        }
+    }
+    wg_sync();
+    const int kind = SM.win_kind, mode = SM.win_mode;
+    {   // the winner's coder state, contexts and bytes (the rebuild below reuses wave 0's pass buffer, where the contexts live)
+        const int ww = kind - 1;
+        const FinState fin = WM(ww).fin[mode];
+        const int nbytes = (int)(fin.w2 >> 16) - SM.entry_a[depth].cnt;
+        const u8 *src = lane_bytes(F.sc, ww, mode);
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) g_st32(R->bytes + 4 * i, g_ld32(src + 4 * i));
+            if (tid < CTX_STRIDE / 4) g_st32(R->ctx + 4 * tid, *(const u32a *)&WM(ww).u.p2.cx[mode][4 * tid]);
+            if (tid == 64) {
+                g_st32(&R->cost, (u32)SM.red[0]); g_st32(&R->kind, (u32)kind); g_st32(&R->mode, (u32)mode); g_st32(&R->nbytes, (u32)nbytes);
+                g_st32(&R->fin.w0, fin.w0); g_st32(&R->fin.w1, fin.w1); g_st32(&R->fin.w2, fin.w2);
+            }
+        }
+    }
+    wg_sync();
+    rebuild_winner(kind, mode, N, y0, x0, avm);
+    wg_sync();
+    WAVES(w) LANES(l) {
+        const int tid = w * 64 + l;
+        for (int i = tid; i < N * N / 4; i += WG_THREADS) {
+            const int y = i / (N / 4), x4 = (i % (N / 4)) * 4;
+            const u8 *sp = &SM.rec[y0 + y + 1][x0 + x4 + 1];
+            g_st32(R->rec + y * N + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
+        }
+    }
+    team_publish(&m->res_flag, seq);
+}
+
 HD void encode_ctu() {
     const FrameJob J = F.job;
     const int cy = F.ctu_y, cx = F.ctu_x;
@@ -361,22 +559,24 @@ HD void encode_ctu() {
     }
     wg_sync();
 
-    enter_cu(0, 32, 0, 0, 1);
+    const int team = F.mail != nullptr;
+    enter_cu(0, 32, 0, 0, 1, pack_avail(a32));
     for (int i16_ = 0; i16_ < 4; i16_++) {
         const int y16 = (i16_ >> 1) * 16, x16 = (i16_ & 1) * 16;
         const Avail a16 = child_avail(a32, i16_);
-        enter_cu(1, 16, y16, x16, 1);
+        enter_cu(1, 16, y16, x16, 1, pack_avail(a16));
         for (int i8_ = 0; i8_ < 4; i8_++) {
             const int y8 = y16 + (i8_ >> 1) * 8, x8 = x16 + (i8_ & 1) * 8;
             const Avail a8 = child_avail(a16, i8_);
-            enter_cu(2, 8, y8, x8, 0);
+            enter_cu(2, 8, y8, x8, 0, 0);
             decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
-        decide_cu(1, 16, y16, x16, pack_avail(a16));
+        if (team) { decide_remote(1, 16, y16, x16); if (i16_ < 3) store_cu_rec(16, y16, x16); }
+        else decide_cu(1, 16, y16, x16, pack_avail(a16));
     }
     price_split(0, 32, 0, 0);
-    decide_cu(0, 32, 0, 0, pack_avail(a32));
+    if (team) decide_remote(0, 32, 0, 0); else decide_cu(0, 32, 0, 0, pack_avail(a32));
 
     // ---- store the reconstruction, end_of_slice_segment_flag, hand the CTU's bytes over (:1625-1630)
     u8 *live_sink = J.out + F.out_pos;
@@ -442,5 +642,82 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
         }
     }
     wg_sync();
+}
+
+// ---- helper workgroup: serve requests until every slot it listens on has been closed ----------------------------------
+HD void stage_tables(const Tables *gT) {
+    WAVES(w) LANES(l) {
+        const int tid = w * 64 + l;
+        const u32 *src = (const u32 *)gT; u32 *dst = (u32 *)&SM.T;
+        NOUNROLL
+        for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
+    }
+}
+HDN void helper_loop(const Tables *gT, const FrameJob *jobs, const Scratch sc, TeamMail *mail, int slot_mask) {
+    stage_tables(gT);
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = mail; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; } }
+    wg_sync();
+    int open_ = slot_mask;
+    while (open_) {
+        WAVES(w) LANES(l) {
+            if (w == 0 && l == 0) {
+                int pick = -1;
+                for (;;) {                                  // 16x16 requests first: the main workgroup needs those answers sooner
+                    for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++)
+                        if (((open_ >> s_) & 1) && flag_load(&mail->s[s_].req_flag) == F.seq[s_] + 1) pick = s_;
+                    if (pick >= 0) break;
+                    flag_poll_pause();
+                }
+                flag_acquire();
+                F.seq[pick]++; SM.red[1] = pick;
+            }
+        }
+        wg_sync();
+        const int slot = SM.red[1], seq = F.seq[slot];
+        MailSlot *m = &mail->s[slot];
+        if ((int)g_ld32(&m->req.op) == OP_EXIT) open_ &= ~(1 << slot);
+        else serve_request(jobs, m, seq);
+        wg_sync();
+    }
+}
+
+// ---- kernel body (shared by the gfx950 kernel and the host emulation) -------------------------------------------------
+struct KArgs {
+    const Tables *gT; const ColdTables *gK; const FrameJob *jobs; const u8 *hdrs; int njobs;
+    const Scratch *scr; int *counter; i32 *trace; int trace_cap; unsigned long long *prof;
+    TeamMail *mail; int team_size, nteams;      // team_size 1: every workgroup encodes whole frames alone; 2: main + one helper; 3: main + a 16x16 helper + a 32x32 helper
+};
+#ifdef IMCVT_HOSTEMU
+HD int next_job(int *counter) { return (*counter)++; }
+#else
+HD int next_job(int *counter) { return atomicAdd(counter, 1); }
+#endif
+HD void kernel_main(const KArgs &A, int block) {
+    // members of a team are `nteams` blocks apart: with nteams a multiple of 8 they share an XCD (block b runs on XCD b % 8;
+    // a speed bonus only — the hand-off protocol does not depend on placement)
+    const int team_size = A.team_size > 1 ? A.team_size : 1;
+    const int role = team_size > 1 ? block / A.nteams : 0, team = team_size > 1 ? block % A.nteams : block;
+    Scratch sc = A.scr[block];
+    sc.trace_cap = A.trace_cap; sc.prof = A.prof;
+    if (role != 0) {
+        sc.trace = (i32 *)0;
+        helper_loop(A.gT, A.jobs, sc, A.mail + team, team_size == 2 ? 3 : (role == 1 ? 1 << SLOT_16 : 1 << SLOT_32));
+        return;
+    }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = team_size > 1 ? A.mail + team : (TeamMail *)0; F.seq[0] = 0; F.seq[1] = 0; } }
+    // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
+    // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)
+    wg_sync();
+    for (;;) {
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) SM.next_frame = next_job(A.counter); }
+        wg_sync();
+        const int f = SM.next_frame;
+        wg_sync();
+        if (f >= A.njobs) break;
+        sc.trace = (f == 0) ? A.trace : (i32 *)0;
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) F.frame = f; }
+        encode_frame(A.gT, A.gK, A.jobs[f], sc, A.hdrs + (size_t)HDR_MAX * f);
+    }
+    if (team_size > 1) { post_exit(SLOT_16); post_exit(SLOT_32); }
 }
 #undef F

@@ -15,11 +15,12 @@
 #include "hevc_tables.h"
 #include "../../include/imcvt_hevc.h"
 
-#define HDR_MAX 96
-
 __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
-                                                                 const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof) {
+                                                                 const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
+                                                                 TeamMail *mail, int team_size, int nteams) {
+#ifdef DBG_OLDKERNEL
     __shared__ int next_frame;
+    if (threadIdx.x == 0) { SM.F.mail = nullptr; SM.F.seq[0] = 0; SM.F.seq[1] = 0; }
     for (;;) {
         if (threadIdx.x == 0) next_frame = atomicAdd(counter, 1);
         __syncthreads();
@@ -32,6 +33,12 @@ __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables
         sc.prof = prof;
         encode_frame(gT, gK, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
     }
+    return;
+#endif
+    KArgs A;
+    A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
+    A.mail = mail; A.team_size = team_size; A.nteams = nteams;
+    kernel_main(A, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -41,11 +48,14 @@ struct imcvt_hevc_ctx {
     Scratch *d_scratch = nullptr;
     void *d_pool = nullptr;            // backing store of all per-workgroup scratch
     int *d_counter = nullptr;
+    TeamMail *d_mail = nullptr; int mail_cap = 0;          // one mailbox set per team
     FrameJob *d_jobs = nullptr; u8 *d_hdrs = nullptr; int jobs_cap = 0;
     FrameJob *h_jobs = nullptr; u8 *h_hdrs = nullptr;      // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
     int *d_trace = nullptr; int trace_cap = 0;
     unsigned long long *d_prof = nullptr;   // [NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
+    int force_team = 0;                     // 0: choose per launch; 1..3: fixed team size
+    int last_team = 1, last_nteams = 0;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
@@ -59,11 +69,16 @@ static bool have_device() {
     return true;
 }
 
-extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r1 (wg=" "192" ", frame-per-workgroup)"; }
+extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r2 (wg=192; frame per workgroup, or per team of 2-3 workgroups when the batch is small)"; }
 extern "C" int imcvt_hevc_padded(int v) { return ((v < 8192 ? v : 8192) + 31) / 32 * 32; }
 extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 32) * (h + 32) + 65536; }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nteams) {
+    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
+                       (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, team_size, nteams);
+}
 
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     if (!have_device()) return nullptr;
@@ -81,6 +96,8 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
         } else (void)hipGetLastError();
     }
     c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
+    if (const char *e = getenv("IMCVT_HEVC_TEAM")) c->force_team = atoi(e);
+    c->mail_cap = c->max_wg / 2 + 8;
     Tables *T = new Tables(); ColdTables *K = new ColdTables();
     imcvt::build_tables(*T, *K);
     const size_t per_wg = scratch_bytes_per_wg();
@@ -91,6 +108,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
            && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_counter, sizeof(int)) == hipSuccess
+           && hipMalloc(&c->d_mail, sizeof(TeamMail) * c->mail_cap) == hipSuccess
            && hipMalloc(&c->d_prof, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
            && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
            && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -107,8 +125,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
         for (int i = 0; i < 3 && ok; i++) {
             ok = hipMemset(c->d_counter, 0, sizeof(int)) == hipSuccess;
-            if (ok) hipLaunchKernelGGL(hevc_encode_frames, dim3(c->max_wg), dim3(WG_THREADS), 0, 0, c->d_tables, c->d_cold, (const FrameJob *)nullptr, (const u8 *)nullptr, 0,
-                                       c->d_scratch, c->d_counter, (i32 *)nullptr, 0, (unsigned long long *)nullptr);
+            if (ok) launch(c, c->max_wg, 0, 0, 1, 0);
             ok = ok && hipDeviceSynchronize() == hipSuccess;
         }
         if (!ok) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
@@ -118,7 +135,9 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
 
 extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
     if (!c) return;
-    hipFree(c->d_tables); hipFree(c->d_cold); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof);
+    (void)hipSetDevice(c->device);
+    if (c->timed && c->ev1) (void)hipEventSynchronize(c->ev1);
+    hipFree(c->d_tables); hipFree(c->d_cold); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof); hipFree(c->d_mail);
     hipFree(c->d_jobs); hipFree(c->d_hdrs);
     if (c->h_jobs) hipHostFree(c->h_jobs);
     if (c->h_hdrs) hipHostFree(c->h_hdrs);
@@ -128,11 +147,26 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
 }
 
 extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
+extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
+extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) { if (!c) return IMCVT_ERR_ARG; if (nteams) *nteams = c->last_nteams; return c->last_team; }
+
+// How many workgroups share a frame.  A frame alone in a workgroup keeps 3 wavefronts busy; the device holds max_wg
+// workgroups.  When the batch cannot fill the device that way, frames are given to teams of 3 (or 2) workgroups.
+static int pick_team(const imcvt_hevc_ctx *c, int n) {
+    if (c->force_team >= 1) return c->force_team;
+    if (3 * n <= c->max_wg) return 3;
+    if (2 * n <= c->max_wg) return 2;
+    return 1;
+}
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
     if (!c || n < 0 || (n > 0 && !frames)) return IMCVT_ERR_ARG;
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
     hipStream_t stream = (hipStream_t)stream_;
+    // One launch in flight per context: job table, frame counter, mailboxes and per-workgroup scratch belong to the launch
+    // that is running, whatever stream it was put on.
+    if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
     if (n > c->jobs_cap) {
         hipFree(c->d_jobs); hipFree(c->d_hdrs);
         if (c->h_jobs) hipHostFree(c->h_jobs);
@@ -143,8 +177,6 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         HIPCHK(hipHostMalloc(&c->h_jobs, sizeof(FrameJob) * n));
         HIPCHK(hipHostMalloc(&c->h_hdrs, (size_t)HDR_MAX * n));
         c->jobs_cap = n;
-    } else {
-        HIPCHK(hipStreamSynchronize(stream));      // the pinned staging of the previous launch must have been consumed
     }
     for (int i = 0; i < n; i++) {
         const imcvt_hevc_frame &f = frames[i];
@@ -157,10 +189,19 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(int), stream));
-    const int grid = n < c->max_wg ? n : c->max_wg;
+    int team = pick_team(c, n), nteams = 0, grid;
+    if (team > 1) {
+        const int cap = (c->max_wg / team) & ~7;                    // teams that fit the device, a multiple of 8 (team members share an XCD)
+        nteams = ((n + 7) & ~7) < cap ? ((n + 7) & ~7) : cap;
+        if (nteams < 8 || nteams > c->mail_cap) team = 1;
+    }
+    if (team > 1) {
+        grid = team * nteams;
+        HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nteams, stream));     // sequence numbers restart with every launch
+    } else { team = 1; grid = n < c->max_wg ? n : c->max_wg; }
+    c->last_team = team; c->last_nteams = nteams;
     HIPCHK(hipEventRecord(c->ev0, stream));
-    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream,
-                       c->d_tables, c->d_cold, c->d_jobs, c->d_hdrs, n, c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof);
+    launch(c, grid, stream, n, team, nteams);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;
@@ -197,49 +238,116 @@ extern "C" float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *c) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Host-pointer entry points (the reference's own interface)
+// Host-pointer entry points (the reference's own interface).  A batch fans out over every visible device: frame i goes
+// to device i mod D; each device has its own context, stream and a grow-only slab that is reused from call to call.
 // ---------------------------------------------------------------------------------------------------
+struct DevState {
+    int dev = 0;
+    imcvt_hevc_ctx *ctx = nullptr;
+    hipStream_t st = nullptr;
+    u8 *slab = nullptr; size_t slab_cap = 0;
+    std::vector<int> idx;                       // frames of the current call
+    std::vector<size_t> off_img, off_out, off_rc;
+    size_t off_len = 0;
+    std::vector<imcvt_hevc_frame> fr;
+    std::vector<int> lens;
+};
 static std::mutex g_lock;
-static imcvt_hevc_ctx *g_ctx = nullptr;
+static std::vector<DevState> g_devs;
+static int g_last_devices = 0;
+
+static int dev_init(DevState &d) {
+    if (d.ctx) return 0;
+    HIPCHK(hipSetDevice(d.dev));
+    d.ctx = imcvt_hevc_create(0);
+    if (!d.ctx) return IMCVT_ERR_NO_DEVICE;
+    HIPCHK(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    return 0;
+}
+
+extern "C" int imcvt_hevc_batch_devices(void) { return g_last_devices; }
+
+extern "C" void imcvt_hevc_shutdown(void) {
+    std::lock_guard<std::mutex> guard(g_lock);
+    for (DevState &d : g_devs) {
+        if (!d.ctx) continue;
+        (void)hipSetDevice(d.dev);
+        (void)hipStreamSynchronize(d.st);
+        imcvt_hevc_destroy(d.ctx); d.ctx = nullptr;
+        (void)hipStreamDestroy(d.st); d.st = nullptr;
+        (void)hipFree(d.slab); d.slab = nullptr; d.slab_cap = 0;
+    }
+    g_devs.clear();
+}
 
 extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
                                      unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len) {
     if (n < 0 || (n > 0 && (!pbuffers || !imgs || !rcons || !ysz || !xsz || !qpd6 || !out_len))) return IMCVT_ERR_ARG;
-    for (int i = 0; i < n; i++) if (qpd6[i] < 0 || qpd6[i] > 4 || ysz[i] < 1 || xsz[i] < 1) return IMCVT_ERR_ARG;
+    for (int i = 0; i < n; i++) if (qpd6[i] < 0 || qpd6[i] > 4 || ysz[i] < 1 || xsz[i] < 1 || !pbuffers[i] || !imgs[i] || !rcons[i]) return IMCVT_ERR_ARG;
+    if (!have_device()) return IMCVT_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> guard(g_lock);
-    if (!g_ctx) { g_ctx = imcvt_hevc_create(0); if (!g_ctx) return IMCVT_ERR_NO_DEVICE; }
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    if (g_devs.empty()) {
+        int nd = 0;
+        HIPCHK(hipGetDeviceCount(&nd));
+        if (const char *e = getenv("IMCVT_HEVC_DEVICES")) { const int lim = atoi(e); if (lim >= 1 && lim < nd) nd = lim; }
+        g_devs.resize(nd);
+        for (int i = 0; i < nd; i++) g_devs[i].dev = i;
+    }
     if (n == 0) return 0;
-    // one device slab: [img | out | rcon | len] per frame
-    std::vector<size_t> off_img(n), off_out(n), off_rc(n), off_len(n);
-    size_t total = 0;
-    for (int i = 0; i < n; i++) {
-        // the reference indexes img with the ORIGINAL stride but only up to the padded (<=8192) extent (:1621)
-        const int hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
-        off_img[i] = total; total += align256((size_t)ysz[i] * xsz[i]);
-        off_out[i] = total; total += align256((size_t)imcvt_hevc_stream_bound(ysz[i], xsz[i]));
-        off_rc[i] = total;  total += align256((size_t)hp * wp);
-        off_len[i] = total; total += 256;
-    }
-    u8 *slab = nullptr;
-    HIPCHK(hipMalloc(&slab, total));
-    std::vector<imcvt_hevc_frame> fr(n);
+    // a device joins when it gets at least one frame; with one frame the caller's current device does the work
+    const int D = n < (int)g_devs.size() ? n : (int)g_devs.size();
+    const int first = (D == 1 && prev_dev < (int)g_devs.size()) ? prev_dev : 0;
     int rc = 0;
-    for (int i = 0; i < n && rc == 0; i++) {
-        if (hipMemcpyAsync(slab + off_img[i], imgs[i], (size_t)ysz[i] * xsz[i], hipMemcpyHostToDevice, 0) != hipSuccess) rc = IMCVT_ERR_HIP;
-        fr[i].d_img = slab + off_img[i]; fr[i].d_out = slab + off_out[i]; fr[i].d_rcon = slab + off_rc[i];
-        fr[i].d_len = (int *)(slab + off_len[i]); fr[i].h = ysz[i]; fr[i].w = xsz[i]; fr[i].qpd6 = qpd6[i];
+    for (int k = 0; k < D && rc == 0; k++) {
+        DevState &d = g_devs[(first + k) % g_devs.size()];
+        rc = dev_init(d);
+        if (rc) break;
+        d.idx.clear();
+        for (int i = k; i < n; i += D) d.idx.push_back(i);
+        const int m = (int)d.idx.size();
+        d.off_img.resize(m); d.off_out.resize(m); d.off_rc.resize(m); d.fr.resize(m); d.lens.resize(m);
+        size_t total = 0;                           // one device slab: [img | out | rcon] per frame, then the lengths
+        for (int j = 0; j < m; j++) {
+            // the reference indexes img with the ORIGINAL stride but only up to the padded (<=8192) extent (:1621)
+            const int i = d.idx[j], hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
+            d.off_img[j] = total; total += align256((size_t)ysz[i] * xsz[i]);
+            d.off_out[j] = total; total += align256((size_t)imcvt_hevc_stream_bound(ysz[i], xsz[i]));
+            d.off_rc[j] = total;  total += align256((size_t)hp * wp);
+        }
+        d.off_len = total; total += align256(sizeof(int) * (size_t)m);
+        if (hipSetDevice(d.dev) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
+        if (total > d.slab_cap) {
+            (void)hipFree(d.slab); d.slab = nullptr; d.slab_cap = 0;
+            if (hipMalloc(&d.slab, total) != hipSuccess) { fprintf(stderr, "imcvt_hevc: cannot allocate %zu bytes on device %d\n", total, d.dev); rc = IMCVT_ERR_HIP; break; }
+            d.slab_cap = total;
+        }
+        for (int j = 0; j < m && rc == 0; j++) {
+            const int i = d.idx[j];
+            if (hipMemcpyAsync(d.slab + d.off_img[j], imgs[i], (size_t)ysz[i] * xsz[i], hipMemcpyHostToDevice, d.st) != hipSuccess) rc = IMCVT_ERR_HIP;
+            d.fr[j].d_img = d.slab + d.off_img[j]; d.fr[j].d_out = d.slab + d.off_out[j]; d.fr[j].d_rcon = d.slab + d.off_rc[j];
+            d.fr[j].d_len = (int *)(d.slab + d.off_len) + j; d.fr[j].h = ysz[i]; d.fr[j].w = xsz[i]; d.fr[j].qpd6 = qpd6[i];
+        }
+        if (rc == 0) rc = imcvt_hevc_encode_device(d.ctx, m, d.fr.data(), d.st);       // asynchronous: the next device is fed meanwhile
     }
-    if (rc == 0) rc = imcvt_hevc_encode_device(g_ctx, n, fr.data(), nullptr);
-    if (rc == 0 && hipStreamSynchronize(0) != hipSuccess) rc = IMCVT_ERR_HIP;
-    for (int i = 0; i < n && rc == 0; i++) {
-        const int hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
-        int len = 0;
-        if (hipMemcpy(&len, fr[i].d_len, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
-        if (hipMemcpy(pbuffers[i], fr[i].d_out, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
-        if (hipMemcpy(rcons[i], fr[i].d_rcon, (size_t)hp * wp, hipMemcpyDeviceToHost) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
-        out_len[i] = len; ysz[i] = hp; xsz[i] = wp;
+    for (int k = 0; k < D; k++) {                   // collect, device by device (every launched stream is drained even after an error)
+        DevState &d = g_devs[(first + k) % g_devs.size()];
+        if (!d.ctx || d.idx.empty()) continue;
+        const int m = (int)d.idx.size();
+        if (hipSetDevice(d.dev) != hipSuccess || hipStreamSynchronize(d.st) != hipSuccess) { rc = rc ? rc : IMCVT_ERR_HIP; d.idx.clear(); continue; }
+        if (rc == 0 && hipMemcpy(d.lens.data(), d.slab + d.off_len, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) rc = IMCVT_ERR_HIP;
+        for (int j = 0; j < m && rc == 0; j++) {
+            const int i = d.idx[j], hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
+            if (hipMemcpyAsync(pbuffers[i], d.fr[j].d_out, (size_t)d.lens[j], hipMemcpyDeviceToHost, d.st) != hipSuccess
+                || hipMemcpyAsync(rcons[i], d.fr[j].d_rcon, (size_t)hp * wp, hipMemcpyDeviceToHost, d.st) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
+            out_len[i] = d.lens[j]; ysz[i] = hp; xsz[i] = wp;
+        }
+        if (hipStreamSynchronize(d.st) != hipSuccess) rc = rc ? rc : IMCVT_ERR_HIP;
+        d.idx.clear();
     }
-    hipFree(slab);
+    g_last_devices = D;
+    (void)hipSetDevice(prev_dev);
     return rc;
 }
 

@@ -25,7 +25,8 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 # every symbol include/imcvt_hevc.h declares
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
-           "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version")
+           "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -75,6 +76,14 @@ def load_library():
     lib.imcvt_hevc_debug_occupancy.argtypes = [_ip, _ip, _ip, _ip]
     lib.imcvt_hevc_version.restype = C.c_char_p
     lib.imcvt_hevc_version.argtypes = []
+    lib.imcvt_hevc_set_team.restype = None
+    lib.imcvt_hevc_set_team.argtypes = [C.c_void_p, C.c_int]
+    lib.imcvt_hevc_last_team.restype = C.c_int
+    lib.imcvt_hevc_last_team.argtypes = [C.c_void_p, _ip]
+    lib.imcvt_hevc_batch_devices.restype = C.c_int
+    lib.imcvt_hevc_batch_devices.argtypes = []
+    lib.imcvt_hevc_shutdown.restype = None
+    lib.imcvt_hevc_shutdown.argtypes = []
     _lib = lib
     return lib
 
@@ -157,6 +166,15 @@ class DeviceEncoder:
             self.close()
         except Exception:
             pass
+
+    def set_team(self, team_size: int):
+        """Workgroups per frame: 0 = chosen per launch, 1 = a frame per workgroup, 2 / 3 = teams (same results)."""
+        self.lib.imcvt_hevc_set_team(self.ctx, int(team_size))
+
+    def last_team(self):
+        """(team size, number of teams) of the last launch."""
+        nt = C.c_int(0)
+        return int(self.lib.imcvt_hevc_last_team(self.ctx, C.byref(nt))), nt.value
 
     def make_batch(self, imgs_dev, qpd6=0):
         """imgs_dev: list of 2-D uint8 CUDA tensors.  Allocates outputs (torch) and the descriptor array."""

@@ -49,11 +49,20 @@ int writeHEVCImageFile(const char *p_filename, const uint8_t *p_buf, int is_rgb,
  * 2. Batch surface (new; per-frame semantics identical to HEVCImageEncoder)
  * --------------------------------------------------------------------------------------------------- */
 
-/* n independent frames with HOST pointers: frames are copied to the device, encoded concurrently (one
- * workgroup per frame) and copied back.  ysz[i]/xsz[i] are updated to the padded sizes, out_len[i]
- * receives each stream length.  Returns 0, or a negative IMCVT_ERR_*.   */
+/* n independent frames with HOST pointers — the seam is the reference's serial file loop, src/main.c:162-211.
+ * Frames fan out over every visible device (frame i -> device i mod D, D = min(n, devices); a single frame
+ * stays on the caller's current device), are encoded concurrently and copied back; results do not depend on
+ * D.  ysz[i]/xsz[i] are updated to the padded sizes, out_len[i] receives each stream length.  Device memory
+ * and contexts are created on first use and reused by later calls (imcvt_hevc_shutdown releases them).
+ * Environment: IMCVT_HEVC_DEVICES=k limits the fan-out to the first k devices.
+ * Returns 0, or a negative IMCVT_ERR_*.  Thread-safe (internally serialised).   */
 int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
                           unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len);
+
+/* Number of devices the last HEVCImageEncoderBatch / HEVCImageEncoder call used. */
+int imcvt_hevc_batch_devices(void);
+/* Releases the contexts, streams and device memory the host-pointer entry points hold (they are re-created on the next call). */
+void imcvt_hevc_shutdown(void);
 
 /* One frame of a device-resident batch.  All pointers are DEVICE pointers (hipMalloc / torch). */
 typedef struct imcvt_hevc_frame {
@@ -80,8 +89,19 @@ int imcvt_hevc_padded(int v);
 
 /* Encodes n device-resident frames on `stream` (a hipStream_t, may be NULL for the default stream).
  * Asynchronous: returns after the launch; results are valid once the stream has been synchronised.
+ * ONE launch is in flight per context: a call first waits for the context's previous launch (whatever stream
+ * that was on), because the job table, the frame queue and the per-workgroup scratch belong to the running
+ * launch; use one context per stream for concurrent launches.  The call makes the context's device current.
  * Returns 0 or a negative IMCVT_ERR_*. */
 int imcvt_hevc_encode_device(imcvt_hevc_ctx *ctx, int n, const imcvt_hevc_frame *frames, void *stream);
+
+/* How many workgroups share one frame: 0 = chosen per launch (a frame per workgroup when the batch fills the
+ * device, else teams of 2 or 3 workgroups — a main workgroup walks the 8x8 CUs while helpers evaluate the
+ * 16x16 / 32x32 candidate sets), 1..3 = fixed.  Results are identical for every setting.
+ * Environment override at context creation: IMCVT_HEVC_TEAM. */
+void imcvt_hevc_set_team(imcvt_hevc_ctx *ctx, int team_size);
+/* Team size the last launch used (1..3); *nteams receives the number of teams (0 for team size 1). */
+int imcvt_hevc_last_team(imcvt_hevc_ctx *ctx, int *nteams);
 
 /* Kernel-only time of the last imcvt_hevc_encode_device call on this context, in milliseconds, from HIP
  * events recorded on the launch stream (synchronises that stream).  <0 if nothing was launched. */
@@ -98,7 +118,7 @@ int imcvt_hevc_debug_prof(imcvt_hevc_ctx *ctx, unsigned long long *out, int n, i
 /* Debug aid: what the HIP occupancy API reports for the encoder kernel on the current device. */
 int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds_per_block, int *lds_per_cu);
 
-/* Library / build information, e.g. "imcvt_hevc gfx950 r1". */
+/* Library / build information, e.g. "imcvt_hevc gfx950 r2 ...". */
 const char *imcvt_hevc_version(void);
 
 #ifdef __cplusplus

@@ -1,5 +1,5 @@
 // tests/hostemu/hostemu.cpp — TEST-ONLY harness: compiles the device encoder source (imcvt_amd/csrc/hevc_core.h,
-// hevc_frame.h) for the host.  Every lane of the 192-thread workgroup is a cooperative fiber with its own stack, so
+// hevc_frame.h) for the host.  Every lane of every 192-thread workgroup is a cooperative fiber with its own stack, so
 // the kernel runs under real SIMT semantics: registers survive barriers, divergent lanes make independent progress,
 // wave_sync()/wg_sync() are true barriers and ballots/shuffles are collectives.  It exists so the bit-exactness of
 // the kernel LOGIC can be checked against the oracle on a machine without a GPU; it is not part of the product,
@@ -17,7 +17,9 @@ asm(".text\n.globl emu_ctx_switch\n.type emu_ctx_switch,@function\nemu_ctx_switc
     "  movq %rsp,(%rdi)\n  movq %rsi,%rsp\n"
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n");
 
-#define EMU_THREADS 192
+#define EMU_WG_THREADS 192
+#define EMU_MAX_WG 6                                        // up to two teams of three workgroups
+#define EMU_THREADS (EMU_WG_THREADS * EMU_MAX_WG)
 #define EMU_STACK (512 * 1024)
 struct EmuFiber {
     void *sp; char *stack; int done;
@@ -25,26 +27,35 @@ struct EmuFiber {
 };
 static EmuFiber g_fib[EMU_THREADS];
 static void *g_main_sp;
-static int g_cur;                                           // running fiber (= threadIdx.x)
-static unsigned g_wave_gen[3], g_wave_arr[3], g_wg_gen, g_wg_arr;
+static int g_cur;                                           // running fiber (= blockIdx.x * 192 + threadIdx.x)
+static int g_nfib = EMU_WG_THREADS;                         // fibers of this run (192 per workgroup)
+static unsigned g_wave_gen[3 * EMU_MAX_WG], g_wave_arr[3 * EMU_MAX_WG], g_wg_gen[EMU_MAX_WG], g_wg_arr[EMU_MAX_WG];
 static uint64_t g_xchg[EMU_THREADS];                        // collective exchange slots
 static void (*g_entry)(void);
+static unsigned g_yield_gen;                                // a yielding fiber is runnable again at once
 
 static int emu_lane() { return g_cur & 63; }
-static int emu_wave() { return g_cur >> 6; }
-static void emu_block(volatile unsigned *gen, unsigned val) {
+static int emu_wave() { return (g_cur % EMU_WG_THREADS) >> 6; }
+static int emu_block() { return g_cur / EMU_WG_THREADS; }
+static void emu_wait(volatile unsigned *gen, unsigned val) {
     EmuFiber &f = g_fib[g_cur];
     f.wait_gen = gen; f.wait_val = val;
     emu_ctx_switch(&f.sp, g_main_sp);
 }
 static void emu_wave_sync() {
-    const int w = emu_wave();
+    const int w = g_cur >> 6;                               // global wave index
     if (++g_wave_arr[w] == 64) { g_wave_arr[w] = 0; g_wave_gen[w]++; }
-    else emu_block(&g_wave_gen[w], g_wave_gen[w]);
+    else emu_wait(&g_wave_gen[w], g_wave_gen[w]);
 }
 static void emu_wg_sync() {
-    if (++g_wg_arr == EMU_THREADS) { g_wg_arr = 0; g_wg_gen++; }
-    else emu_block(&g_wg_gen, g_wg_gen);
+    const int b = emu_block();
+    if (++g_wg_arr[b] == EMU_WG_THREADS) { g_wg_arr[b] = 0; g_wg_gen[b]++; }
+    else emu_wait(&g_wg_gen[b], g_wg_gen[b]);
+}
+static void emu_yield() {                                   // spin-wait on another workgroup's flag: let everyone else run
+    EmuFiber &f = g_fib[g_cur];
+    f.wait_gen = &g_yield_gen; f.wait_val = g_yield_gen - 1;
+    emu_ctx_switch(&f.sp, g_main_sp);
 }
 static uint64_t emu_ballot(int p) {
     g_xchg[g_cur] = p ? 1 : 0;
@@ -61,6 +72,10 @@ static int emu_shfl(int v, int src_lane) {                  // value of `v` held
     emu_wave_sync();
     return r;
 }
+struct Shm;
+static Shm *g_shm_of[EMU_MAX_WG];                           // each emulated workgroup's LDS image
+static long g_spins;
+static void emu_set_shm(int wg);                            // (defined below, next to the device source's LDS pointer)
 static void emu_trampoline() {
     g_entry();
     g_fib[g_cur].done = 1;
@@ -68,8 +83,8 @@ static void emu_trampoline() {
 }
 static void emu_run(void (*entry)(void)) {
     g_entry = entry;
-    memset(g_wave_gen, 0, sizeof g_wave_gen); memset(g_wave_arr, 0, sizeof g_wave_arr); g_wg_gen = g_wg_arr = 0;
-    for (int i = 0; i < EMU_THREADS; i++) {
+    memset(g_wave_gen, 0, sizeof g_wave_gen); memset(g_wave_arr, 0, sizeof g_wave_arr); memset(g_wg_gen, 0, sizeof g_wg_gen); memset(g_wg_arr, 0, sizeof g_wg_arr);
+    for (int i = 0; i < g_nfib; i++) {
         EmuFiber &f = g_fib[i];
         if (!f.stack) f.stack = (char *)malloc(EMU_STACK);
         f.done = 0; f.wait_gen = nullptr;
@@ -81,48 +96,77 @@ static void emu_run(void (*entry)(void)) {
         f.sp = sp;
     }
     for (;;) {
-        int live = 0, ran = 0;
-        for (int i = 0; i < EMU_THREADS; i++) {
+        int live = 0, ran = 0, worked = 0;
+        for (int i = 0; i < g_nfib; i++) {
             EmuFiber &f = g_fib[i];
             if (f.done) continue;
             live++;
             if (f.wait_gen && *f.wait_gen == f.wait_val) continue;
+            worked += f.wait_gen != &g_yield_gen;           // a fiber that comes back from a yield has done nothing yet
             f.wait_gen = nullptr; g_cur = i; ran++;
+            emu_set_shm(i / EMU_WG_THREADS);
             emu_ctx_switch(&g_main_sp, f.sp);
         }
         if (!live) break;
         if (!ran) { fprintf(stderr, "hostemu: deadlock (divergent barrier)\n"); abort(); }
+        if (!worked && ++g_spins > 1000000) { fprintf(stderr, "hostemu: deadlock (workgroups wait for each other)\n"); abort(); } else if (worked) g_spins = 0;
     }
 }
 
 #include "../../imcvt_amd/csrc/hevc_frame.h"
 #include "../../imcvt_amd/csrc/hevc_tables.h"
 
-static struct { const Tables *T; const ColdTables *K; FrameJob job; Scratch sc; const u8 *hdr; } g_args;
-static void emu_entry() { encode_frame(g_args.T, g_args.K, g_args.job, g_args.sc, g_args.hdr); }
+static void emu_set_shm(int wg) { g_shm_host = g_shm_of[wg]; }
+static KArgs g_args;
+static void emu_entry() { kernel_main(g_args, emu_block()); }
 
-extern "C" int hostemu_HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
-                                        int *ysz, int *xsz, int qpd6, int *trace, int trace_cap) {
+// team_size 1: one workgroup encodes the frames alone (frames pulled one after the other); 2 / 3: teams (hevc_frame.h), `nteams` of them
+static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
+                      int *ysz, int *xsz, int qpd6, int *out_len, int *trace, int trace_cap, int team_size, int nteams) {
     static Tables T; static ColdTables K; static int ready = 0;
     if (!ready) { imcvt::build_tables(T, K); ready = 1; }
-    const int h = *ysz, w = *xsz;
-    const int hp = ((h < 8192 ? h : 8192) + 31) / 32 * 32, wp = ((w < 8192 ? w : 8192) + 31) / 32 * 32;
-    Shm *S = (Shm *)calloc(1, sizeof(Shm));
-    Scratch sc;
-    void *pool = calloc(1, scratch_bytes_per_wg());
-    scratch_carve(sc, (u8 *)pool);
-    sc.trace = trace; sc.trace_cap = trace_cap;
-    u8 hdr[96];
-    FrameJob job;
-    int out_len = 0;
-    job.img = img; job.out = pbuffer; job.rcon = img_rcon; job.h = h; job.w = w; job.hp = hp; job.wp = wp; job.q = qpd6;
-    job.hdr_len = imcvt::build_headers(hdr, qpd6, hp, wp);
-    job.out_len = &out_len;
-    g_shm_host = S; sc.prof = nullptr;
-    g_args.T = &T; g_args.K = &K; g_args.job = job; g_args.sc = sc; g_args.hdr = hdr;
+    if (team_size < 1) team_size = 1;
+    if (team_size == 1) nteams = 1;
+    const int nwg = team_size * nteams;
+    if (nwg > EMU_MAX_WG) return -1;
+    FrameJob *jobs = (FrameJob *)calloc(n, sizeof(FrameJob));
+    u8 *hdrs = (u8 *)calloc(n, HDR_MAX);
+    for (int i = 0; i < n; i++) {
+        const int h = ysz[i], w = xsz[i];
+        FrameJob &job = jobs[i];
+        job.img = imgs[i]; job.out = pbuffers[i]; job.rcon = rcons[i]; job.h = h; job.w = w; job.q = qpd6;
+        job.hp = ((h < 8192 ? h : 8192) + 31) / 32 * 32; job.wp = ((w < 8192 ? w : 8192) + 31) / 32 * 32;
+        job.hdr_len = imcvt::build_headers(hdrs + (size_t)HDR_MAX * i, qpd6, job.hp, job.wp);
+        out_len[i] = 0; job.out_len = &out_len[i];
+        ysz[i] = job.hp; xsz[i] = job.wp;
+    }
+    Scratch sc[EMU_MAX_WG]; void *pool[EMU_MAX_WG];
+    for (int b = 0; b < nwg; b++) {
+        g_shm_of[b] = (Shm *)calloc(1, sizeof(Shm));
+        pool[b] = calloc(1, scratch_bytes_per_wg());
+        scratch_carve(sc[b], (u8 *)pool[b]);
+    }
+    TeamMail *mail = (TeamMail *)aligned_alloc(256, sizeof(TeamMail) * nteams);
+    memset(mail, 0, sizeof(TeamMail) * nteams);
+    int counter = 0;
+    g_args.gT = &T; g_args.gK = &K; g_args.jobs = jobs; g_args.hdrs = hdrs; g_args.njobs = n; g_args.scr = sc; g_args.counter = &counter;
+    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.team_size = team_size; g_args.nteams = nteams;
+    g_nfib = nwg * EMU_WG_THREADS; g_spins = 0;
     emu_run(emu_entry);
-    free(pool); free(S);
-    *ysz = hp; *xsz = wp;
-    return out_len;
+    for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); }
+    free(mail); free(jobs); free(hdrs);
+    return 0;
+}
+extern "C" int hostemu_HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
+                                        int *ysz, int *xsz, int qpd6, int *trace, int trace_cap) {
+    int len = 0;
+    unsigned char *pb[1] = { pbuffer }; const unsigned char *im[1] = { img }; unsigned char *rc[1] = { img_rcon };
+    if (emu_encode(1, pb, im, rc, ysz, xsz, qpd6, &len, trace, trace_cap, 1, 1) < 0) return -1;
+    return len;
+}
+// n frames by `nteams` teams of `team_size` workgroups (the frames are pulled from one queue, as on the device)
+extern "C" int hostemu_HEVCImageEncoderTeam(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
+                                            int *ysz, int *xsz, int qpd6, int *out_len, int team_size, int nteams) {
+    return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, team_size, nteams);
 }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }

@@ -183,3 +183,57 @@ def test_bench_batch_device_resident(amd):
     for i in range(512):
         assert got[i][0] == want[i % 16][0] and (got[i][1] == want[i % 16][1]).all(), i
         assert again[i][0] == got[i][0]
+
+
+@pytest.mark.parametrize("team", [1, 2, 3])
+def test_team_sizes_give_identical_streams(amd, team):
+    """One frame per workgroup, or per team of 2 / 3 cooperating workgroups (requests and results handed over through
+    global memory between compute units): identical bytes.  Frames of many sizes, more frames than teams of 3 fit at once
+    would need only with 350+ frames, so the queue is exercised with a forced small team count by the batch itself."""
+    import torch
+    from oracle import oracle
+    rng = np.random.default_rng(99)
+    imgs = [kat_input(dict(kind="file", file="p5_gray.pgm"))]
+    for i in range(40):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        imgs.append((rng.integers(0, 256, (h, w)) if i % 3 == 0 else np.clip(rng.normal(128, 30, (h, w)), 0, 255) if i % 3 == 1
+                     else np.add.outer(np.arange(h) * 3, np.arange(w) * 7) % 256).astype(np.uint8))
+    qs = [i % 5 for i in range(len(imgs))]
+    enc = amd.DeviceEncoder()
+    enc.set_team(team)
+    batch = enc.make_batch([torch.from_numpy(a).cuda() for a in imgs], qs)
+    for rep in range(2):                                # twice: sequence numbers and mailboxes restart with every launch
+        enc.encode(batch)
+        got = enc.results(batch)
+        assert enc.last_team()[0] == team
+        for a, q, (s, r) in zip(imgs, qs, got):
+            ws, wr, _ = oracle.cpu_encode(a, q)
+            assert s == ws and (r == wr).all(), (a.shape, q, team, rep)
+    enc.close()
+
+
+def test_auto_team_choice_and_full_hd_team(amd):
+    """A single 1080p frame is given to a team automatically; its stream still has the reference's digest."""
+    import torch
+    from oracle import synth
+    e = next(e for e in LARGE if (e["input"]["arg"], e["qpd6"]) == (1, 0))
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, 1)).cuda()], 0)
+    enc.encode(batch)
+    (s, r), = enc.results(batch)
+    assert enc.last_team()[0] == 3
+    assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
+    enc.close()
+
+
+def test_host_batch_uses_the_visible_devices(amd):
+    """HEVCImageEncoderBatch fans frames out over min(n, devices) devices; one device on this box, results unchanged."""
+    import torch
+    from oracle import synth
+    imgs = [synth.syn(64, 64, s) for s in range(5)]
+    a = amd.HEVCImageEncoderBatch(imgs, 1)
+    lib = amd.load_library()
+    assert lib.imcvt_hevc_batch_devices() == min(len(imgs), torch.cuda.device_count()) >= 1
+    lib.imcvt_hevc_shutdown()                           # contexts are re-created on the next call
+    b = amd.HEVCImageEncoderBatch(imgs, 1)
+    assert [x[0] for x in a] == [x[0] for x in b]

@@ -64,6 +64,39 @@ def test_token_row_overflow_path_matches_golden(hostemu_row, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+def emu_encode_team(lib, imgs, q, team_size, nteams):
+    n = len(imgs)
+    imgs = [np.ascontiguousarray(a) for a in imgs]
+    outs = [np.zeros(2 * (a.shape[1] + 32) * (a.shape[0] + 32) + 65536, np.uint8) for a in imgs]
+    rcs = [np.zeros(((a.shape[0] + 31) // 32 * 32) * ((a.shape[1] + 31) // 32 * 32), np.uint8) for a in imgs]
+    P = u8p * n
+    ys = (C.c_int * n)(*[a.shape[0] for a in imgs]); xs = (C.c_int * n)(*[a.shape[1] for a in imgs]); lens = (C.c_int * n)()
+    lib.hostemu_HEVCImageEncoderTeam.restype = C.c_int
+    assert lib.hostemu_HEVCImageEncoderTeam(n, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]),
+                                            P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, q, lens, team_size, nteams) == 0
+    return [(outs[i][:lens[i]].tobytes(), rcs[i]) for i in range(n)]
+
+
+@pytest.mark.parametrize("team_size,nteams", [(3, 1), (2, 1), (3, 2), (2, 3)])
+@pytest.mark.parametrize("q", [0, 4])
+def test_team_modes_match_golden(hostemu, q, team_size, nteams):
+    """A frame encoded by a TEAM of workgroups (hevc_frame.h: the main workgroup walks the 8x8 CUs, helper workgroups evaluate
+    the 16x16 / 32x32 candidate sets from the posted entry states) gives the reference's bytes; several teams pull frames
+    from one queue.  The emulated workgroups run concurrently (fibers), so the request / result hand-offs are real."""
+    es = [e for e in OVF if e["qpd6"] == q]
+    res = emu_encode_team(hostemu, [kat_input(e["input"]) for e in es], q, team_size, nteams)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
+def test_team_mode_natural_image(hostemu):
+    # 10 x 9 CTUs of the reference's own sample picture: helpers read their borders from the reconstruction plane across CTU rows
+    e = next(e for e in kat_entries() if e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] == 4)
+    (stream, rcon), = emu_encode_team(hostemu, [kat_input(e["input"])], 4, 3, 1)
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"] and hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
 def test_sizes_beyond_8192_are_cropped_like_the_reference(hostemu):
     # :1580-1581 pads min(dim, 8192) while the source keeps its own stride (:1621): one CTU row / column of 257 CTUs' worth
     from oracle import oracle, synth

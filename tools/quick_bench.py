@@ -19,5 +19,6 @@ for i in range(min(n, 2)):
     want, wr, _ = oracle.cpu_encode(imgs[i], q)
     bad += not (res[i][0] == want and (res[i][1] == wr).all())
 best = min(ms)
+print(f"team {enc.last_team()}", end="  ")
 print(f"{n} x {w}x{h} q{q}: kernel ms {[round(m, 1) for m in ms]}  best {w * h * n / best / 1e3:.2f} Mpx/s  parity {'OK' if not bad else 'MISMATCH'}")
 sys.exit(1 if bad else 0)
