@@ -231,8 +231,8 @@ def main():
             t = json.load(open(tp))
             if t.get("qpd6") == args.qpd6 and t.get("hbm_bytes_per_launch") and t.get("ctus"):
                 traffic = int(t["hbm_bytes_per_launch"] * ctus / t["ctus"])
-                traffic_src = (f"extrapolated by CTU count from {tp[len(ROOT) + 1:]}: {t.get('frames')} frames of {t.get('width')}x{t.get('height')}, "
-                               f"{t['ctus']} CTUs, {t['hbm_bytes_per_launch']} B per launch")
+                traffic_src = (f"extrapolated by CTU count from {tp[len(ROOT) + 1:]} (calibrated FETCH_SIZE + WRITE_SIZE of a separate counter run: "
+                               f"{t.get('frames')} frames, {t['ctus']} CTUs of the same content class, {t['hbm_bytes_per_launch']} B per launch); not measured in this run")
         macs = 12320 * hp * wp * F                                          # transform MACs per launch
         mode = f"{'strong' if strong else 'weak'}: {total_frames} frames over {world} GPU(s), {F} on rank 0"
         line = {

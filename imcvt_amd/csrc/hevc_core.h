@@ -41,12 +41,11 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD int clz32(u32 v) { return v ? __builtin_clz(v) : 32; }
   HD u64 wave_ballot(int p) { return emu_ballot(p); }
   HD int wave_shfl(int v, int src_lane) { return emu_shfl(v, src_lane); }
-  // cross-workgroup flags (teams): the emulated workgroups are fibers of one thread, so plain accesses are coherent
+  // cross-workgroup mail (teams): the emulated workgroups are fibers of one thread, so plain accesses are coherent
   static void emu_yield();
-  HD i32 flag_load(const i32 *p) { return *(const volatile i32 *)p; }
-  HD void flag_poll_pause() { emu_yield(); }
-  HD void flag_acquire() {}
-  HD void flag_release_store(i32 *p, i32 v) { *(volatile i32 *)p = v; }
+  HD u32 m_ld32(const void *p) { return *(const volatile u32 *)p; }
+  HD void m_st32(void *p, u32 v) { *(volatile u32 *)p = v; }
+  HD void mail_poll_pause() { emu_yield(); }
   HD void drain_stores() {}
 #else
   #define HD __device__ __forceinline__
@@ -65,20 +64,17 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_max(i32 *p, i32 v) { return atomicMax(p, v); }
   HD u32 lds_or(u32 *p, u32 v) { return atomicOr(p, v); }
   HD int clz32(u32 v) { return __clz((int)v); }
-  // Cross-workgroup hand-off (teams, hevc_frame.h).  Per-XCD L2s are not coherent with each other and a CU's L1 is never
-  // refreshed by another CU's stores, so: the producer drains its stores, writes the XCD's dirty L2 lines back (agent-scope
-  // release) and only then stores the flag; the consumer polls the flag with relaxed agent-scope loads (L1 bypassed) and
-  // invalidates its CU's L1 (agent-scope acquire) before any payload load.  The explicit vmcnt(0) keeps the flag from
-  // overtaking the write-back (the compiler may drop the fence's own wait when its scoreboard looks empty).
-  HD i32 flag_load(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  HD void flag_poll_pause() { __builtin_amdgcn_s_sleep(4); }
-  HD void flag_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+  // Cross-workgroup mail (teams, hevc_frame.h).  Per-XCD L2s are not coherent with each other for ordinary accesses and a
+  // CU's L1 is never refreshed by another CU's stores, so everything that crosses workgroups — payload and flags alike — is
+  // written and read with agent-scope accesses (global_store / global_load ... sc1: write-through, L1 bypassed, coherent
+  // across the device).  Order: the producer's payload stores are drained (vmcnt(0) in every wave, then the workgroup
+  // barrier) before one lane stores the flag; the consumer sees the flag, passes a barrier, and only then loads the
+  // payload.  No L2 write-back / L1 invalidate is involved: with hundreds of workgroups per XCD keeping megabytes of
+  // dirty token scratch in L2, an agent-scope release (buffer_wbl2) per hand-off was measured to halve the throughput.
+  HD u32 m_ld32(const void *p) { return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  HD void m_st32(void *p, u32 v) { __hip_atomic_store((u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  HD void mail_poll_pause() { __builtin_amdgcn_s_sleep(4); }
   HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  HD void flag_release_store(i32 *p, i32 v) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 #endif
 
 #if defined(IMCVT_HOSTEMU)
@@ -275,6 +271,8 @@ struct alignas(16) HelpReq {                     // main -> helper: everything t
     i32 szl, sza, ml, ma;                        // CU size / mode of the left and above neighbour cells (split flag context, MPM)
     Arith a; i32 pad_;                           // coder state at the CU's entry
     alignas(4) u8 ctx[CTX_STRIDE];               // contexts at the CU's entry
+    alignas(4) u8 above[68];                     // reconstructed samples the candidates predict from (:196-257): the row above the CU from
+    alignas(4) u8 left[64];                      // x0-1 to x0+2N-1 (corner first), and the column left of it from y0 to y0+2N-1
 };
 struct alignas(16) HelpRes {                     // helper -> main: the best unsplit candidate ("last minimum" of the 70)
     i32 cost, kind, mode, nbytes;                // kind 1: one TU, 2: four TUs; nbytes: bytes the winning trial emitted

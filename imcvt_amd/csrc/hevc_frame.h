@@ -351,23 +351,22 @@ HDN void price_split(int depth, int N, int y0, int x0) {
 // (:1408-1409).  The decision is the reference's: split cost first, then the candidates in order, each accepted with
 // `best >= cost`, i.e. the last minimum of the 70 wins iff it does not exceed the split cost.
 // =====================================================================================================================
-// All threads call these.  publish: everything this workgroup stored so far is visible to whoever then sees flag == v.
+// All threads call these.  publish: every mail word this workgroup stored so far is visible to whoever then sees flag == v
+// (`v` is read from thread 0 only).
 HD void team_publish(i32 *flag, i32 v) {
     drain_stores();
     wg_sync();
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) flag_release_store(flag, v); }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) m_st32(flag, (u32)v); }
 }
-// await: returns once flag == v; loads issued afterwards see what the publisher stored before publishing
+// await: returns once flag == v; mail loads issued afterwards see what the publisher stored before publishing
 HD void team_await(i32 *flag, i32 v) {
     WAVES(w) LANES(l) {
-        if (w == 0 && l == 0) {
-            while (flag_load(flag) != v) flag_poll_pause();
-            flag_acquire();
-        }
+        if (w == 0 && l == 0) { while ((i32)m_ld32(flag) != v) mail_poll_pause(); }
     }
     wg_sync();
 }
 HD int slot_of(int N) { return N == 32 ? SLOT_32 : SLOT_16; }
+HD int ld_i(const i32 *p) { return (i32)m_ld32(p); }
 
 // main: post the entry state of the CU at (y0,x0,N) — call right after enter_cu's snapshot, before the split flag is coded
 HDN void post_request(int depth, int N, int y0, int x0, int avm) {
@@ -376,22 +375,35 @@ HDN void post_request(int depth, int N, int y0, int x0, int avm) {
     const int uy = y0 >> 2, ux = x0 >> 2;
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
-        if (tid < CTX_STRIDE / 4) g_st32(m->req.ctx + 4 * tid, *(const u32a *)&SM.entry_cx[depth][4 * tid]);
-        if (tid == 64) {
+        if (tid < CTX_STRIDE / 4) m_st32(m->req.ctx + 4 * tid, *(const u32a *)&SM.entry_cx[depth][4 * tid]);
+        if (tid >= 32 && tid < 32 + 17) {                 // row above: tile row y0, columns x0 .. x0+2N (the tile row holds 65 samples)
+            const int i = tid - 32;
+            const u8 *r = &SM.rec[y0][imin(x0 + 4 * i, 64)];
+            if (4 * i <= 2 * N) m_st32(m->req.above + 4 * i, (u32)r[0] | (u32)r[1] << 8 | (u32)r[2] << 16 | (u32)r[3] << 24);
+        }
+        if (tid >= 64 && tid < 64 + 16) {                 // column to the left: tile column x0, rows y0+1 .. y0+2N (rows beyond the tile are never available)
+            const int i = tid - 64;
+            if (4 * i < 2 * N) {
+                u32 v = 0;
+                for (int k = 0; k < 4; k++) v |= (u32)SM.rec[imin(y0 + 1 + 4 * i + k, 32)][x0] << (8 * k);
+                m_st32(m->req.left + 4 * i, v);
+            }
+        }
+        if (tid == 128) {
             i32 *r = (i32 *)&m->req;
             const Arith a = SM.entry_a[depth];
             const i32 v[20] = { OP_WORK, F.frame, F.ctu_y, F.ctu_x, N, y0, x0, avm, nb_size(uy, ux - 1), nb_size(uy - 1, ux), nb_mode(uy, ux - 1), nb_mode(uy - 1, ux),
                                 a.range, a.low, a.nbits, a.nbytes, a.bufbyte, a.zeros, a.cnt, 0 };
-            for (int i = 0; i < 20; i++) g_st32(r + i, (u32)v[i]);
+            for (int i = 0; i < 20; i++) m_st32(r + i, (u32)v[i]);
         }
         if (tid == 0) F.seq[slot]++;
     }
-    team_publish(&m->req_flag, F.seq[slot] + 0);       // (F.seq is read after the barrier inside)
+    team_publish(&m->req_flag, F.seq[slot]);
 }
 HDN void post_exit(int slot) {
     MailSlot *m = &F.mail->s[slot];
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { g_st32(&m->req.op, (u32)OP_EXIT); F.seq[slot]++; } }
-    team_publish(&m->req_flag, F.seq[slot] + 0);
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->req.op, (u32)OP_EXIT); F.seq[slot]++; } }
+    team_publish(&m->req_flag, F.seq[slot]);
 }
 
 // main: the CU's children are done and the split is priced — take the helper's answer and decide (:1439, :1475)
@@ -401,12 +413,12 @@ HDN void decide_remote(int depth, int N, int y0, int x0) {
     u8 *live_sink = F.job.out + F.out_pos;
     const long long t0 = prof_now();
     team_await(&m->res_flag, F.seq[slot]);
-    prof_add(PF_SYNC, t0);
+    prof_add(PF_DECIDE, t0);                                // (booked as "wait_help": waiting for the helper's answer)
     const HelpRes *R = &m->res;
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) {
-            const int cost = (int)g_ld32(&R->cost), take = SM.split_cost[depth] >= cost;
-            SM.win_kind = take ? (int)g_ld32(&R->kind) : 0; SM.win_mode = (int)g_ld32(&R->mode);
+            const int cost = ld_i(&R->cost), take = SM.split_cost[depth] >= cost;
+            SM.win_kind = take ? ld_i(&R->kind) : 0; SM.win_mode = ld_i(&R->mode);
             if (F.sc.trace && F.trace_n + 8 <= F.sc.trace_cap) {
                 i32 *t = F.sc.trace + F.trace_n;
                 t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = N; t[3] = SM.win_kind; t[4] = SM.win_mode;
@@ -418,12 +430,16 @@ HDN void decide_remote(int depth, int N, int y0, int x0) {
     wg_sync();
     const int kind = SM.win_kind, mode = SM.win_mode;
     if (kind != 0) {
-        const int cnt0 = SM.entry_a[depth].cnt, nbytes = (int)g_ld32(&R->nbytes);
+        const int cnt0 = SM.entry_a[depth].cnt, nbytes = ld_i(&R->nbytes);
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
-            for (int i = tid; i < nbytes; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(R->bytes + i));
-            if (tid < CTX_STRIDE / 4) *(u32a *)&SM.cx[4 * tid] = g_ld32(R->ctx + 4 * tid);
-            if (tid == 64) { FinState f; f.w0 = g_ld32(&R->fin.w0); f.w1 = g_ld32(&R->fin.w1); f.w2 = g_ld32(&R->fin.w2); SM.live = unpack_arith(f); }
+            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) {      // (the stream buffer has slack beyond the CTU's bytes; whole dwords are copied)
+                const u32 v = m_ld32(R->bytes + 4 * i);
+                u8 *d = live_sink + cnt0 + 4 * i;
+                g_st8(d, (int)(v & 255)); g_st8(d + 1, (int)((v >> 8) & 255)); g_st8(d + 2, (int)((v >> 16) & 255)); g_st8(d + 3, (int)(v >> 24));
+            }
+            if (tid < CTX_STRIDE / 4) *(u32a *)&SM.cx[4 * tid] = m_ld32(R->ctx + 4 * tid);
+            if (tid == 64) { FinState f; f.w0 = m_ld32(&R->fin.w0); f.w1 = m_ld32(&R->fin.w1); f.w2 = m_ld32(&R->fin.w2); SM.live = unpack_arith(f); }
             if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445)
                 const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
                 if (i < n && j < n) {
@@ -433,7 +449,7 @@ HDN void decide_remote(int depth, int N, int y0, int x0) {
             }
             for (int i = tid; i < N * N / 4; i += WG_THREADS) {      // its reconstruction replaces the children's (:1441, :1477)
                 const int y = i / (N / 4), x4 = (i % (N / 4)) * 4;
-                const u32 v = g_ld32(R->rec + y * N + x4);
+                const u32 v = m_ld32(R->rec + y * N + x4);
                 u8 *d = &SM.rec[y0 + y + 1][x0 + x4 + 1];
                 d[0] = (u8)v; d[1] = (u8)(v >> 8); d[2] = (u8)(v >> 16); d[3] = (u8)(v >> 24);
             }
@@ -442,25 +458,12 @@ HDN void decide_remote(int depth, int N, int y0, int x0) {
     }
 }
 
-// main: the decided CU's reconstruction goes to the frame's reconstruction plane right away — the next 16x16 request's
-// helper reads its borders from there (the whole CTU is stored again when it is finished, :1625-1627)
-HD void store_cu_rec(int N, int y0, int x0) {
-    const FrameJob &J = F.job;
-    WAVES(w) LANES(l) {
-        const int tid = w * 64 + l;
-        for (int i = tid; i < N * N; i += WG_THREADS) {
-            const int y = y0 + i / N, x = x0 + i % N;
-            g_st8(J.rcon + (size_t)(F.ctu_y + y) * J.wp + F.ctu_x + x, SM.rec[y + 1][x + 1]);
-        }
-    }
-}
-
-// helper: serve one request — load what the candidate sets read, evaluate the 70 candidates, answer with the last minimum
+// helper: serve one request — stage what the candidate sets read, evaluate the 70 candidates, answer with the last minimum
 HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
     const HelpReq *Q = &m->req;
     HelpRes *R = &m->res;
-    const int frame = (int)g_ld32(&Q->frame), cy = (int)g_ld32(&Q->cy), cx = (int)g_ld32(&Q->cx);
-    const int N = (int)g_ld32(&Q->N), y0 = (int)g_ld32(&Q->y0), x0 = (int)g_ld32(&Q->x0), avm = (int)g_ld32(&Q->avm);
+    const int frame = ld_i(&Q->frame), cy = ld_i(&Q->cy), cx = ld_i(&Q->cx);
+    const int N = ld_i(&Q->N), y0 = ld_i(&Q->y0), x0 = ld_i(&Q->x0), avm = ld_i(&Q->avm);
     const int depth = (N == 32) ? 0 : 1;
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) { F.job = jobs[frame]; F.ctu_y = cy; F.ctu_x = cx; F.out_pos = 0; F.trace_n = 0; }
@@ -470,24 +473,29 @@ HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
         NOUNROLL
-        for (int i = tid; i < 1024; i += WG_THREADS) {      // source pixels of the CTU (:1621)
-            const int y = i >> 5, x = i & 31;
+        for (int i = tid; i < N * N; i += WG_THREADS) {     // source pixels of the CU (:1621)
+            const int y = y0 + i / N, x = x0 + i % N;
             SM.org[y][x] = g_ld8(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1));
         }
-        NOUNROLL
-        for (int i = tid; i < 65 + 32 * 33; i += WG_THREADS) {   // reconstruction around and inside the CTU as the main workgroup has published it
-            const int y = (i < 65) ? -1 : (i - 65) / 33, x = (i < 65) ? i - 1 : (i - 65) % 33 - 1;
-            SM.rec[y + 1][x + 1] = g_ld8(J.rcon + (size_t)clip3(cy + y, 0, J.hp - 1) * J.wp + clip3(cx + x, 0, J.wp - 1));
+        if (tid < 17 && 4 * tid <= 2 * N) {                   // the samples it predicts from, placed where the main workgroup's tile has them
+            const u32 v = m_ld32(Q->above + 4 * tid);
+            u8 *d = &SM.rec[y0][imin(x0 + 4 * tid, 64)];
+            d[0] = (u8)v; d[1] = (u8)(v >> 8); d[2] = (u8)(v >> 16); d[3] = (u8)(v >> 24);
         }
-        if (tid < CTX_STRIDE / 4) *(u32a *)&SM.entry_cx[depth][4 * tid] = g_ld32(Q->ctx + 4 * tid);
-        if (tid == 64) {
+        if (tid >= 64 && tid < 64 + 16 && 4 * (tid - 64) < 2 * N) {
+            const int i = tid - 64;
+            const u32 v = m_ld32(Q->left + 4 * i);
+            for (int k = 0; k < 4; k++) if (y0 + 1 + 4 * i + k <= 32) SM.rec[y0 + 1 + 4 * i + k][x0] = (u8)(v >> (8 * k));
+        }
+        if (tid >= 128 && tid < 128 + CTX_STRIDE / 4) *(u32a *)&SM.entry_cx[depth][4 * (tid - 128)] = m_ld32(Q->ctx + 4 * (tid - 128));
+        if (tid == 32) {
             const i32 *r = (const i32 *)&Q->a;
-            Arith a; a.range = (i32)g_ld32(r); a.low = (i32)g_ld32(r + 1); a.nbits = (i32)g_ld32(r + 2); a.nbytes = (i32)g_ld32(r + 3);
-            a.bufbyte = (i32)g_ld32(r + 4); a.zeros = (i32)g_ld32(r + 5); a.cnt = (i32)g_ld32(r + 6);
+            Arith a; a.range = ld_i(r); a.low = ld_i(r + 1); a.nbits = ld_i(r + 2); a.nbytes = ld_i(r + 3);
+            a.bufbyte = ld_i(r + 4); a.zeros = ld_i(r + 5); a.cnt = ld_i(r + 6);
             SM.entry_a[depth] = a;
             const int uy = y0 >> 2, ux = x0 >> 2;                 // the two neighbour cells the CU header reads (:942-946, :957-976)
-            SM.mapsz[uy + 1][ux] = (u8)g_ld32(&Q->szl); SM.mapsz[uy][ux + 1] = (u8)g_ld32(&Q->sza);
-            SM.mapmode[uy + 1][ux] = (u8)g_ld32(&Q->ml); SM.mapmode[uy][ux + 1] = (u8)g_ld32(&Q->ma);
+            SM.mapsz[uy + 1][ux] = (u8)ld_i(&Q->szl); SM.mapsz[uy][ux + 1] = (u8)ld_i(&Q->sza);
+            SM.mapmode[uy + 1][ux] = (u8)ld_i(&Q->ml); SM.mapmode[uy][ux + 1] = (u8)ld_i(&Q->ma);
         }
     }
     wg_sync();
@@ -510,11 +518,11 @@ HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
         const u8 *src = lane_bytes(F.sc, ww, mode);
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
-            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) g_st32(R->bytes + 4 * i, g_ld32(src + 4 * i));
-            if (tid < CTX_STRIDE / 4) g_st32(R->ctx + 4 * tid, *(const u32a *)&WM(ww).u.p2.cx[mode][4 * tid]);
+            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) m_st32(R->bytes + 4 * i, g_ld32(src + 4 * i));
+            if (tid < CTX_STRIDE / 4) m_st32(R->ctx + 4 * tid, *(const u32a *)&WM(ww).u.p2.cx[mode][4 * tid]);
             if (tid == 64) {
-                g_st32(&R->cost, (u32)SM.red[0]); g_st32(&R->kind, (u32)kind); g_st32(&R->mode, (u32)mode); g_st32(&R->nbytes, (u32)nbytes);
-                g_st32(&R->fin.w0, fin.w0); g_st32(&R->fin.w1, fin.w1); g_st32(&R->fin.w2, fin.w2);
+                m_st32(&R->cost, (u32)SM.red[0]); m_st32(&R->kind, (u32)kind); m_st32(&R->mode, (u32)mode); m_st32(&R->nbytes, (u32)nbytes);
+                m_st32(&R->fin.w0, fin.w0); m_st32(&R->fin.w1, fin.w1); m_st32(&R->fin.w2, fin.w2);
             }
         }
     }
@@ -526,7 +534,7 @@ HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
         for (int i = tid; i < N * N / 4; i += WG_THREADS) {
             const int y = i / (N / 4), x4 = (i % (N / 4)) * 4;
             const u8 *sp = &SM.rec[y0 + y + 1][x0 + x4 + 1];
-            g_st32(R->rec + y * N + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
+            m_st32(R->rec + y * N + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
         }
     }
     team_publish(&m->res_flag, seq);
@@ -572,7 +580,7 @@ HD void encode_ctu() {
             decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
-        if (team) { decide_remote(1, 16, y16, x16); if (i16_ < 3) store_cu_rec(16, y16, x16); }
+        if (team) decide_remote(1, 16, y16, x16);
         else decide_cu(1, 16, y16, x16, pack_avail(a16));
     }
     price_split(0, 32, 0, 0);
@@ -631,7 +639,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
             encode_ctu();
         }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
-    if (sc.prof && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(threadIdx.x >> 6) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);
+    if (sc.prof && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(threadIdx.x >> 6) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);   // role 0's slice
 #endif
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) {
@@ -653,32 +661,40 @@ HD void stage_tables(const Tables *gT) {
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
     }
 }
-HDN void helper_loop(const Tables *gT, const FrameJob *jobs, const Scratch sc, TeamMail *mail, int slot_mask) {
+HDN void helper_loop(const Tables *gT, const FrameJob *jobs, const Scratch sc, TeamMail *mail, int slot_mask, int role) {
     stage_tables(gT);
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+    if ((threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
+#endif
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = mail; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; } }
     wg_sync();
     int open_ = slot_mask;
     while (open_) {
+        const long long tidle = prof_now();
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
                 int pick = -1;
                 for (;;) {                                  // 16x16 requests first: the main workgroup needs those answers sooner
                     for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++)
-                        if (((open_ >> s_) & 1) && flag_load(&mail->s[s_].req_flag) == F.seq[s_] + 1) pick = s_;
+                        if (((open_ >> s_) & 1) && (i32)m_ld32(&mail->s[s_].req_flag) == F.seq[s_] + 1) pick = s_;
                     if (pick >= 0) break;
-                    flag_poll_pause();
+                    mail_poll_pause();
                 }
-                flag_acquire();
                 F.seq[pick]++; SM.red[1] = pick;
             }
         }
         wg_sync();
+        prof_add(PF_CTUIO, tidle);                          // (booked as "idle": waiting for a request)
         const int slot = SM.red[1], seq = F.seq[slot];
         MailSlot *m = &mail->s[slot];
-        if ((int)g_ld32(&m->req.op) == OP_EXIT) open_ &= ~(1 << slot);
+        if (ld_i(&m->req.op) == OP_EXIT) open_ &= ~(1 << slot);
         else serve_request(jobs, m, seq);
         wg_sync();
     }
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+    if (sc.prof && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(role * NWAVES + (threadIdx.x >> 6)) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);
+#endif
+    (void)role;
 }
 
 // ---- kernel body (shared by the gfx950 kernel and the host emulation) -------------------------------------------------
@@ -693,15 +709,31 @@ HD int next_job(int *counter) { return (*counter)++; }
 HD int next_job(int *counter) { return atomicAdd(counter, 1); }
 #endif
 HD void kernel_main(const KArgs &A, int block) {
-    // members of a team are `nteams` blocks apart: with nteams a multiple of 8 they share an XCD (block b runs on XCD b % 8;
-    // a speed bonus only — the hand-off protocol does not depend on placement)
+    // Blocks are grouped by 8 * team_size: inside a group the members of a team are 8 blocks apart, so they share an XCD
+    // (block b runs on XCD b % 8; a speed bonus only — the hand-off protocol does not depend on placement), and every
+    // run of consecutive blocks holds complete teams: if fewer workgroups are resident than were launched, the teams of the
+    // resident prefix still make progress and free their slots when the queue is empty.  nteams is a multiple of 8.
+#ifndef IMCVT_HOSTEMU
+    if (A.team_size < 0) {      // residency census (debug): how many workgroups of this launch are on the device at the same time
+        if (threadIdx.x == 0) {
+            atomicAdd(A.counter, 1);
+            const long long t0 = clock64();
+            while (clock64() - t0 < 2000000) __builtin_amdgcn_s_sleep(32);
+            atomicMax(A.counter + 1, (int)m_ld32(A.counter));
+            atomicAdd(A.counter, -1);
+        }
+        return;
+    }
+#endif
     const int team_size = A.team_size > 1 ? A.team_size : 1;
-    const int role = team_size > 1 ? block / A.nteams : 0, team = team_size > 1 ? block % A.nteams : block;
+    const int gw = A.nteams < 8 ? (A.nteams > 0 ? A.nteams : 1) : 8;      // (fewer than 8 teams: one group)
+    const int grp = block / (gw * team_size), rem = block % (gw * team_size);
+    const int role = team_size > 1 ? rem / gw : 0, team = team_size > 1 ? grp * gw + rem % gw : block;
     Scratch sc = A.scr[block];
     sc.trace_cap = A.trace_cap; sc.prof = A.prof;
     if (role != 0) {
         sc.trace = (i32 *)0;
-        helper_loop(A.gT, A.jobs, sc, A.mail + team, team_size == 2 ? 3 : (role == 1 ? 1 << SLOT_16 : 1 << SLOT_32));
+        helper_loop(A.gT, A.jobs, sc, A.mail + team, team_size == 2 ? 3 : (role == 1 ? 1 << SLOT_16 : 1 << SLOT_32), role);
         return;
     }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = team_size > 1 ? A.mail + team : (TeamMail *)0; F.seq[0] = 0; F.seq[1] = 0; } }

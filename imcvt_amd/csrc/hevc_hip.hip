@@ -53,7 +53,7 @@ struct imcvt_hevc_ctx {
     FrameJob *h_jobs = nullptr; u8 *h_hdrs = nullptr;      // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
     int *d_trace = nullptr; int trace_cap = 0;
-    unsigned long long *d_prof = nullptr;   // [NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
+    unsigned long long *d_prof = nullptr;   // [3 roles][NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
     int force_team = 0;                     // 0: choose per launch; 1..3: fixed team size
     int last_team = 1, last_nteams = 0;
 };
@@ -107,10 +107,10 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
            && hipMemcpy(c->d_cold, K, sizeof(ColdTables), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
-           && hipMalloc(&c->d_counter, sizeof(int)) == hipSuccess
+           && hipMalloc(&c->d_counter, 2 * sizeof(int)) == hipSuccess
            && hipMalloc(&c->d_mail, sizeof(TeamMail) * c->mail_cap) == hipSuccess
-           && hipMalloc(&c->d_prof, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
-           && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * NWAVES * PF_N) == hipSuccess
+           && hipMalloc(&c->d_prof, sizeof(unsigned long long) * 3 * NWAVES * PF_N) == hipSuccess
+           && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 3 * NWAVES * PF_N) == hipSuccess
            && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     delete T; delete K;
     if (ok) {
@@ -150,13 +150,15 @@ extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) {
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) { if (!c) return IMCVT_ERR_ARG; if (nteams) *nteams = c->last_nteams; return c->last_team; }
 
-// How many workgroups share a frame.  A frame alone in a workgroup keeps 3 wavefronts busy; the device holds max_wg
-// workgroups.  When the batch cannot fill the device that way, frames are given to teams of 3 (or 2) workgroups.
+// How many workgroups share a frame.  A frame alone in a workgroup keeps 3 wavefronts busy for ~8.7 s (1080p) whatever else
+// runs; a team of 3 finishes it in ~4.1 s but its helpers idle ~40 % of the time.  Measured on MI355X (1080p frames, qpd6 0,
+// profiles/r02*_scale_probe.log): up to 320 teams (960 of the 1024 resident workgroups) a batch finishes in 4.1-5.8 s with
+// teams against 8.7-9.3 s without; beyond that teams need a second round (336 teams: 9.5 s for 512 frames, 17 s for 1000)
+// while frame-per-workgroup launches keep scaling (10.0 s for 512, 13.1 s for 1000).  Teams of 2 (one helper serving both
+// request kinds) lose to both and are kept for tests.
 static int pick_team(const imcvt_hevc_ctx *c, int n) {
     if (c->force_team >= 1) return c->force_team;
-    if (3 * n <= c->max_wg) return 3;
-    if (2 * n <= c->max_wg) return 2;
-    return 1;
+    return (3 * n <= c->max_wg - c->max_wg / 16) ? 3 : 1;
 }
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
@@ -221,9 +223,21 @@ extern "C" int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds
     return 0;
 }
 
+extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
+    if (!c || grid < 1) return IMCVT_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipMemset(c->d_counter, 0, 2 * sizeof(int)));
+    launch(c, grid, 0, 0, -1, 0);
+    HIPCHK(hipDeviceSynchronize());
+    int v[2] = { 0, 0 };
+    HIPCHK(hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost));
+    return v[1];
+}
+
 extern "C" int imcvt_hevc_debug_prof(imcvt_hevc_ctx *c, unsigned long long *out, int n, int reset) {
     if (!c || !out) return IMCVT_ERR_ARG;
-    const int have = NWAVES * PF_N;
+    const int have = 3 * NWAVES * PF_N;
     if (hipDeviceSynchronize() != hipSuccess) return IMCVT_ERR_HIP;
     if (hipMemcpy(out, c->d_prof, sizeof(unsigned long long) * (n < have ? n : have), hipMemcpyDeviceToHost) != hipSuccess) return IMCVT_ERR_HIP;
     if (reset && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * have) != hipSuccess) return IMCVT_ERR_HIP;

@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown")
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -82,6 +82,8 @@ def load_library():
     lib.imcvt_hevc_last_team.argtypes = [C.c_void_p, _ip]
     lib.imcvt_hevc_batch_devices.restype = C.c_int
     lib.imcvt_hevc_batch_devices.argtypes = []
+    lib.imcvt_hevc_debug_census.restype = C.c_int
+    lib.imcvt_hevc_debug_census.argtypes = [C.c_void_p, C.c_int]
     lib.imcvt_hevc_shutdown.restype = None
     lib.imcvt_hevc_shutdown.argtypes = []
     _lib = lib
@@ -202,10 +204,11 @@ class DeviceEncoder:
         _check(self.lib.imcvt_hevc_encode_device(self.ctx, batch["n"], batch["frames"], C.c_void_p(s.cuda_stream)),
                "imcvt_hevc_encode_device")
 
-    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "decide", "recon", "ctuio", "t_setup", "t_hdr", "passA", "passB", "passC", "n_cg")
+    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "wait_help", "recon", "idle", "t_setup", "t_hdr", "passA", "passB", "passC", "n_cg")
 
     def debug_prof(self, reset=True):
-        """Per-wave cycle totals by phase (only non-zero for -DIMCVT_PROF builds)."""
+        """Per-wave cycle totals by phase (only non-zero for -DIMCVT_PROF builds): rows = 3 waves of the main role (or of
+        frame-per-workgroup launches), then 3 waves of each helper role."""
         buf = (C.c_ulonglong * 256)()
         n = _check(self.lib.imcvt_hevc_debug_prof(self.ctx, buf, 256, int(reset)), "imcvt_hevc_debug_prof")
         k = len(self.PROF_CATS)

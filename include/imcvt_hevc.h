@@ -111,9 +111,13 @@ float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *ctx);
  * into a device buffer of cap ints; pass NULL to disable. */
 void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
 
-/* Debug aid: per-wave cycle totals by phase ([waves][categories], zeros unless the library was built with
+/* Debug aid: per-wave cycle totals by phase ([3 roles][waves][categories], zeros unless the library was built with
  * -DIMCVT_PROF); copies up to n counters to `out`, optionally resets them; returns the number available. */
 int imcvt_hevc_debug_prof(imcvt_hevc_ctx *ctx, unsigned long long *out, int n, int reset);
+
+/* Debug aid: launches `grid` workgroups of the encoder kernel that only count themselves, wait ~1 ms and record how many
+ * had started by then: the number of workgroups of such a launch that are resident at the same time. */
+int imcvt_hevc_debug_census(imcvt_hevc_ctx *ctx, int grid);
 
 /* Debug aid: what the HIP occupancy API reports for the encoder kernel on the current device. */
 int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds_per_block, int *lds_per_cu);

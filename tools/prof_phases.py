@@ -17,9 +17,12 @@ t = time.time(); enc.encode(batch); torch.cuda.synchronize(); dt = time.time() -
 ms = enc.last_kernel_ms()
 prof = enc.debug_prof(True)
 nctu = ((w + 31) // 32) * ((h + 31) // 32) * n
+print(f"team {enc.last_team()}  ", end="")
 print(f"{n} x {w}x{h} q{q}: kernel {ms:.1f} ms  ({ms * 1e3 / nctu * n:.1f} us per CTU per frame, {w*h*n/ms/1e3:.3f} Mpx/s)")
 cats = enc.PROF_CATS
 print("cycles per CTU (per wave):")
 print("wave " + " ".join(f"{c:>8s}" for c in cats) + "    total")
 for wv, row in enumerate(prof):
-    print(f"{wv:4d} " + " ".join(f"{v / nctu:8.0f}" for v in row) + f" {sum(row) / nctu:9.0f}")
+    if not any(row):
+        continue
+    print(f"{'MHh'[wv // 3]}{wv % 3:3d} " + " ".join(f"{v / nctu:8.0f}" for v in row) + f" {sum(row) / nctu:9.0f}")
