@@ -2,7 +2,9 @@
 
     writeJLSImageFile(path, img, near)        -> 0 / 1, the reference's file writer
     JLSencode(img, near)                      -> bytes, the same stream in memory
-    JLSencodeBatch(list of gray planes, near) -> list of bytes, one wavefront per plane, one launch (device-resident)
+    JLSencodeBatch(list of gray planes, near) -> list of bytes, all planes concurrently (device-resident): up to 64 lossless
+                                                 planes are each spread over the device (context chains, csrc/jls_par.h),
+                                                 otherwise one wavefront walks each plane
 
 img: numpy uint8 [h, w] (gray) or [h, w, 3] (RGB).  No CPU fallback: the library needs a gfx950 device."""
 import ctypes as C
@@ -36,6 +38,7 @@ def load_jls_library():
         lib.imcvt_jls_encode_device.argtypes = [C.c_int, C.POINTER(_Plane), C.c_void_p]
         lib.imcvt_jls_last_kernel_ms.restype = C.c_float
         lib.imcvt_jls_version.restype = C.c_char_p
+        lib.imcvt_jls_last_path.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -89,6 +92,10 @@ class DevicePlanes:
 
     def last_kernel_ms(self):
         return float(self.lib.imcvt_jls_last_kernel_ms())
+
+    def last_path(self):
+        """1: planes spread over the device (jls_par.h), 0: one walker per plane."""
+        return int(self.lib.imcvt_jls_last_path())
 
     def results(self):
         import torch

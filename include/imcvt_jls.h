@@ -30,7 +30,7 @@ long long imcvt_jls_encode(const uint8_t *img, int is_rgb, int h, int w, int nea
 /* The reference's own output allocation (src/imageio_jls.c:440): 8*w*h + 65536. */
 long long imcvt_jls_stream_bound(int h, int w);
 
-/* 2b. Device-resident batch of gray planes: one wavefront per plane, all planes concurrently.  All pointers are
+/* 2b. Device-resident batch of gray planes, all planes concurrently (few lossless planes: each spread over the device).  All pointers are
  *     DEVICE pointers.  d_out receives the complete .jls stream of the plane (headers and EOI included). */
 typedef struct imcvt_jls_plane {
     const unsigned char *d_img;   /* h*w gray8 */
@@ -43,6 +43,10 @@ int imcvt_jls_encode_device(int n, const imcvt_jls_plane *planes, void *stream);
 /* Kernel-only time of the last imcvt_jls_encode_device call (HIP events on its stream; synchronises it). */
 float imcvt_jls_last_kernel_ms(void);
 const char *imcvt_jls_version(void);
+/* Which path the last launch took: 1 = one plane spread over the device (lossless planes, at most 64 of them: data-parallel
+ * classification, one lane per context chain, prefix sums of code lengths, chunked bit stuffing — jls_par.h), 0 = one
+ * walker per plane (near-lossless, or many planes).  Environment override: IMCVT_JLS_PAR=0/1 (lossless only). */
+int imcvt_jls_last_path(void);
 
 #ifdef __cplusplus
 }

@@ -22,18 +22,24 @@ u8p = C.POINTER(C.c_ubyte)
 def jls_emu(built):
     d = os.path.join(ROOT, "tests", "hostemu")
     so, src = os.path.join(d, "libjls_hostemu.so"), os.path.join(d, "jls_hostemu.cpp")
-    core = os.path.join(ROOT, "imcvt_amd", "csrc", "jls_core.h")
-    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(core)) > os.path.getmtime(so):
+    deps = [src] + [os.path.join(ROOT, "imcvt_amd", "csrc", f) for f in ("jls_core.h", "jls_par.h")]
+    if not os.path.exists(so) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(so):
         subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", so, src], check=True)
     lib = C.CDLL(so)
     lib.jls_hostemu_encode.restype = C.c_longlong
     lib.jls_hostemu_encode.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+    lib.jls_hostemu_encode_par.restype = C.c_longlong
+    lib.jls_hostemu_encode_par.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
 
-    def enc(img, near):
+    def enc(img, near, par=False):
         img = np.ascontiguousarray(img)
         h, w = img.shape[:2]
         out = np.zeros((8 * w * h + 65536) * (3 if img.ndim == 3 else 1), np.uint8)
-        n = lib.jls_hostemu_encode(img.ctypes.data_as(u8p), int(img.ndim == 3), h, w, near, out.ctypes.data_as(u8p))
+        if par:
+            assert near == 0
+            n = lib.jls_hostemu_encode_par(img.ctypes.data_as(u8p), int(img.ndim == 3), h, w, out.ctypes.data_as(u8p))
+        else:
+            n = lib.jls_hostemu_encode(img.ctypes.data_as(u8p), int(img.ndim == 3), h, w, near, out.ctypes.data_as(u8p))
         return out[:n].tobytes()
     return enc
 
@@ -49,6 +55,27 @@ def test_device_source_matches_reference_vectors(jls_emu, e):
     _check(jls_emu(jls_input(e["input"]), e["near"]), e)
 
 
+@pytest.mark.parametrize("e", [e for e in SMALL if e["near"] == 0] + [e for e in LARGE if e["input"]["w"] == 1920 and e["near"] == 0], ids=jls_id)
+def test_plane_parallel_source_matches_reference_vectors(jls_emu, e):
+    """The plane-parallel lossless path (csrc/jls_par.h: classification, per-context chains, prefix sums of code lengths, chunked
+    bit stuffing) with every grid run as a loop on the host: the reference's bytes."""
+    _check(jls_emu(jls_input(e["input"]), 0, par=True), e)
+
+
+def test_plane_parallel_source_vs_cpu_checker_seeded(jls_emu):
+    # runs, run interruptions at row ends, binary pictures (maximal 0xFF stuffing), single rows / columns, RGB
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    for i in range(48):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        kind = i % 6
+        shape = (h, w, 3) if kind == 4 else (h, w)
+        img = (rng.integers(0, 256, shape) if kind in (0, 4) else np.clip(rng.normal(128, 3, shape), 0, 255) if kind == 1
+               else np.full(shape, int(rng.integers(0, 256))) if kind == 2 else (rng.integers(0, 2, shape) * 255) if kind == 3
+               else np.repeat(rng.integers(0, 256, (h, 1)), w, axis=1)).astype(np.uint8)
+        assert jls_emu(img, 0, par=True) == oracle.jls_cpu_encode(img, 0), (i, shape, kind)
+
+
 def test_reciprocal_quantiser_is_exact():
     # jls_core.h quant_err: n / quant as (n * ceil(2^20 / quant)) >> 20 for every quant = 2*near+1 the ABI admits and every n it can see
     for q in range(1, 512, 2):
@@ -59,7 +86,7 @@ def test_reciprocal_quantiser_is_exact():
 
 def test_library_exports_the_declared_symbols(built):
     lib = C.CDLL(os.path.join(ROOT, "imcvt_amd", "csrc", "libimcvt_jls.so"))
-    for name in ("writeJLSImageFile", "imcvt_jls_encode", "imcvt_jls_stream_bound", "imcvt_jls_encode_device", "imcvt_jls_last_kernel_ms", "imcvt_jls_version"):
+    for name in ("writeJLSImageFile", "imcvt_jls_encode", "imcvt_jls_stream_bound", "imcvt_jls_encode_device", "imcvt_jls_last_kernel_ms", "imcvt_jls_version", "imcvt_jls_last_path"):
         assert hasattr(lib, name), name
     lib.imcvt_jls_stream_bound.restype = C.c_longlong
     assert lib.imcvt_jls_stream_bound(1080, 1920) == 8 * 1920 * 1080 + 65536
@@ -89,6 +116,31 @@ def test_gpu_large_frames_golden_digests_in_one_batch(jls_gpu):
         _check(g, e)
     e2 = [e for e in LARGE if e["near"] == 2][0]
     _check(jls_gpu.JLSencode(jls_input(e2["input"]), 2), e2)
+
+
+@pytest.mark.gpu
+def test_gpu_both_lossless_paths_agree(jls_gpu, monkeypatch):
+    """Lossless planes in small batches are spread over the device (jls_par.h); IMCVT_JLS_PAR=0 forces the walker path:
+    the same bytes, equal to the reference's digests (1080p and 4K) and to the CPU checker on run-heavy inputs."""
+    import torch
+    from oracle import oracle, synth
+    big = [e for e in LARGE if e["near"] == 0]
+    rng = np.random.default_rng(11)
+    extra = [synth.flat(300, 200, 7), (rng.integers(0, 2, (97, 131)) * 255).astype(np.uint8), np.repeat(rng.integers(0, 256, (64, 1)), 500, axis=1).astype(np.uint8),
+             np.clip(rng.normal(128, 1.2, (150, 333)), 0, 255).astype(np.uint8), synth.noise(1, 77, 3), synth.noise(77, 1, 3)]
+    imgs = [jls_input(e["input"]) for e in big] + extra
+    d = jls_gpu.DevicePlanes([torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in imgs], 0)
+    d.encode(); par = d.results()
+    assert d.last_path() == 1
+    monkeypatch.setenv("IMCVT_JLS_PAR", "0")
+    d.encode(); walk = d.results()
+    assert d.last_path() == 0
+    for g, e in zip(par, big):
+        _check(g, e)
+    for a, g, wv in zip(imgs, par, walk):
+        assert g == wv, a.shape
+    for a, g in zip(extra, par[len(big):]):
+        assert g == oracle.jls_cpu_encode(a, 0), a.shape
 
 
 @pytest.mark.gpu
