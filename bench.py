@@ -230,9 +230,11 @@ def main():
         if os.path.exists(tp):
             t = json.load(open(tp))
             if t.get("qpd6") == args.qpd6 and t.get("hbm_bytes_per_launch") and t.get("ctus"):
+                same = (t.get("frames"), t.get("w"), t.get("h")) == (F, W, H)
                 traffic = int(t["hbm_bytes_per_launch"] * ctus / t["ctus"])
-                traffic_src = (f"extrapolated by CTU count from {tp[len(ROOT) + 1:]} (calibrated FETCH_SIZE + WRITE_SIZE of a separate counter run: "
-                               f"{t.get('frames')} frames, {t['ctus']} CTUs of the same content class, {t['hbm_bytes_per_launch']} B per launch); not measured in this run")
+                what = f"{t.get('frames')} x {t.get('w')}x{t.get('h')} frames, {t['ctus']} CTUs, {t['hbm_bytes_per_launch']} B per launch"
+                traffic_src = (f"calibrated FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this same workload ({what}; {tp[len(ROOT) + 1:]}); not collected in this run"
+                               if same else f"extrapolated by CTU count from a counter run over {what} ({tp[len(ROOT) + 1:]}); not measured on this workload")
         macs = 12320 * hp * wp * F                                          # transform MACs per launch
         mode = f"{'strong' if strong else 'weak'}: {total_frames} frames over {world} GPU(s), {F} on rank 0"
         line = {

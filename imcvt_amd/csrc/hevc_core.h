@@ -556,7 +556,13 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
 // Border assembly
 // ---------------------------------------------------------------------------------------------------
 // Shared border of the block at (y0,x0) from the reconstruction tile.  Wave-uniform call.
-HDN void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int ha, int har) {
+#ifndef HDN_BORDER
+#define HDN_BORDER HDN
+#endif
+#ifndef HDN_EVAL
+#define HDN_EVAL HDN
+#endif
+HDN_BORDER void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int ha, int har) {
     WaveMem &W = WM(wave);
     Border &b = W.bsh;
     const int n2 = 2 * N;
@@ -656,7 +662,7 @@ HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int ha
     }
     wave_sync();
 }
-HDN void border_tu_split(int N, int y0, int x0, int k, int hl, int hbl, int ha, int har, int c_lo, int c_hi) {      // modes c_lo .. c_hi-1
+HDN_BORDER void border_tu_split(int N, int y0, int x0, int k, int hl, int hbl, int ha, int har, int c_lo, int c_hi) {      // modes c_lo .. c_hi-1
     if (k == 1) border_tu_split_k<1>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
     else if (k == 2) border_tu_split_k<2>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
     else border_tu_split_k<3>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);

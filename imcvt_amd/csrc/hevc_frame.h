@@ -44,7 +44,7 @@ struct P1Item { int own, shape, lo, hi; };
 #define SPL16_1 32
 #endif
 HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? SPL32_0 : SPL32_1) : (shape == 0 ? SPL16_0 : SPL16_1); }   // passes come out balanced over the three waves
-HDN void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
+HDN_EVAL void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q, h = N / 2, big = N >= 16;
@@ -120,7 +120,7 @@ HDN void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
 // Slot NMODE holds the NxN stream ([0..) header, then the four winners' tokens) and, from NXN_KEEP on, the winners' copies.
 #define NXN_KEEP 1024
 #define NXN_KEEP_STRIDE 160
-HDN void eval_NxN(int wave, int y0, int x0, int avm) {
+HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q;

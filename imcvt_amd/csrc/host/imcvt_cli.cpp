@@ -78,7 +78,12 @@ static uint8_t *load_image(const char *src, int *rgb, uint32_t *h, uint32_t *w, 
 }
 
 struct Job { const char *src = NULL; std::string dst; bool dst_given = false; };
-struct Encoded { bool tried = false, ok = false; std::vector<unsigned char> stream; int len = 0; bool rgb = false; };
+struct Encoded { bool tried = false, ok = false; std::vector<unsigned char> stream; int len = 0; uint32_t h = 0, w = 0; unsigned long long hash = 0; };
+static unsigned long long gray_hash(const uint8_t *px, int rgb, size_t n) {      // FNV-1a over the samples the encoder sees (green of RGB, src/imageio_hevc.c:24-26)
+    unsigned long long hsh = 1469598103934665603ull;
+    for (size_t k = 0; k < n; k++) { hsh ^= rgb ? px[3 * k + 1] : px[k]; hsh *= 1099511628211ull; }
+    return hsh;
+}
 
 int main(int argc, char **argv) {
     bool sw[128] = {false};
@@ -105,36 +110,56 @@ int main(int argc, char **argv) {
     if (jobs.empty()) { usage(); return -1; }
     for (Job &j : jobs) if (!j.dst_given) j.dst = with_extension(j.src, "png");    // :171-175
 
-    // ---- all H.265-bound inputs in one device batch (no output, no messages: the loop below reports in order)
+    // ---- H.265-bound inputs are encoded ahead of the reference's loop, in device batches (one frame keeps only a few compute
+    // units busy; a batch fans out over the GPUs).  The loop below stays the authority: it reloads every input and uses an
+    // early result only if the samples are still the ones that were encoded, so a command line whose earlier job rewrites a
+    // later job's input behaves like the reference's strictly sequential loop (such inputs are not pre-encoded at all).
     const int n = (int)jobs.size();
     std::vector<Encoded> enc(n);
     {
+        const size_t kBudgetPx = (size_t)256 << 20;      // samples per batch: ~256 MB in, ~0.8 GB of stream / reconstruction buffers
         std::vector<int> idx, hs, ws, qs, lens;
         std::vector<std::vector<unsigned char>> gray, rcon;
+        size_t px_in_batch = 0;
+        auto flush = [&]() {
+            const int m = (int)idx.size();
+            if (m > 0) {
+                std::vector<unsigned char *> outs(m), rcs(m); std::vector<const unsigned char *> ins(m);
+                rcon.assign(m, std::vector<unsigned char>()); lens.assign(m, 0);
+                for (int k = 0; k < m; k++) {
+                    enc[idx[k]].stream.resize((size_t)imcvt_hevc_stream_bound(hs[k], ws[k]));
+                    rcon[k].resize((size_t)imcvt_hevc_padded(hs[k]) * imcvt_hevc_padded(ws[k]));
+                    outs[k] = enc[idx[k]].stream.data(); rcs[k] = rcon[k].data(); ins[k] = gray[k].data();
+                }
+                const int rc = HEVCImageEncoderBatch(m, outs.data(), ins.data(), rcs.data(), hs.data(), ws.data(), qs.data(), lens.data());
+                for (int k = 0; k < m; k++) {
+                    Encoded &e = enc[idx[k]];
+                    e.ok = rc == 0 && lens[k] > 0; e.len = lens[k];
+                    if (e.ok) { e.stream.resize((size_t)e.len); e.stream.shrink_to_fit(); }
+                    else { e.tried = false; std::vector<unsigned char>().swap(e.stream); }      // the loop encodes this file on its own
+                }
+            }
+            idx.clear(); hs.clear(); ws.clear(); qs.clear(); gray.clear(); rcon.clear(); px_in_batch = 0;
+        };
         for (int i = 0; i < n; i++) {
             if (!is_hevc_name(jobs[i].dst.c_str())) continue;
+            bool rewritten = false;                      // an earlier job of this command line writes this input
+            for (int k = 0; k < i && !rewritten; k++) rewritten = jobs[k].dst == jobs[i].src;
+            if (rewritten) continue;
             int rgb = 0; uint32_t h = 0, w = 0;
             uint8_t *px = load_image(jobs[i].src, &rgb, &h, &w, true);
             if (!px) continue;
-            std::vector<unsigned char> g((size_t)h * w);
-            for (size_t k = 0; k < g.size(); k++) g[k] = rgb ? px[3 * k + 1] : px[k];     // green channel of RGB, src/imageio_hevc.c:24-26
+            const size_t npx = (size_t)h * w;
+            if (px_in_batch && px_in_batch + npx > kBudgetPx) flush();
+            std::vector<unsigned char> g(npx);
+            for (size_t k = 0; k < npx; k++) g[k] = rgb ? px[3 * k + 1] : px[k];
+            enc[i].tried = true; enc[i].h = h; enc[i].w = w; enc[i].hash = gray_hash(px, rgb, npx);
             free(px);
-            enc[i].tried = true; enc[i].rgb = rgb != 0;
             idx.push_back(i); hs.push_back((int)h); ws.push_back((int)w); qs.push_back(level);
             gray.push_back(std::move(g));
+            px_in_batch += npx;
         }
-        const int m = (int)idx.size();
-        if (m > 0) {
-            std::vector<unsigned char *> outs(m), rcs(m); std::vector<const unsigned char *> ins(m);
-            rcon.resize(m); lens.assign(m, 0);
-            for (int k = 0; k < m; k++) {
-                enc[idx[k]].stream.resize((size_t)imcvt_hevc_stream_bound(hs[k], ws[k]));
-                rcon[k].resize((size_t)imcvt_hevc_padded(hs[k]) * imcvt_hevc_padded(ws[k]));
-                outs[k] = enc[idx[k]].stream.data(); rcs[k] = rcon[k].data(); ins[k] = gray[k].data();
-            }
-            const int rc = HEVCImageEncoderBatch(m, outs.data(), ins.data(), rcs.data(), hs.data(), ws.data(), qs.data(), lens.data());
-            for (int k = 0; k < m; k++) { enc[idx[k]].ok = rc == 0 && lens[k] > 0; enc[idx[k]].len = lens[k]; }
-        }
+        flush();
     }
 
     // ---- the reference's loop (:162-211)
@@ -161,15 +186,13 @@ int main(int argc, char **argv) {
             failed = writeJLSImageFile(dst, px, rgb, h, w, level);
 #endif
         } else if (is_hevc_name(dst)) {
-            if (enc[i].tried) {
+            if (enc[i].tried && enc[i].ok && enc[i].h == h && enc[i].w == w && enc[i].hash == gray_hash(px, rgb, (size_t)h * w)) {
                 if (rgb) printf("   warning: this HEVCencoder currently only support gray 8-bit image instead of RGB image. Only compress the green channel of this image.\n");
                 failed = 1;
-                if (enc[i].ok) {
-                    FILE *fp = fopen(dst, "wb");
-                    if (fp) { failed = fwrite(enc[i].stream.data(), 1, (size_t)enc[i].len, fp) != (size_t)enc[i].len; fclose(fp); }
-                }
+                FILE *fp = fopen(dst, "wb");
+                if (fp) { failed = fwrite(enc[i].stream.data(), 1, (size_t)enc[i].len, fp) != (size_t)enc[i].len; fclose(fp); }
             } else {
-                failed = writeHEVCImageFile(dst, px, rgb, h, w, level);        // the input was not loadable when the batch was formed
+                failed = writeHEVCImageFile(dst, px, rgb, h, w, level);        // not pre-encoded, its batch failed, or the input changed since: encode what the loop just loaded
             }
         } else {
             free(px);

@@ -123,7 +123,7 @@ namespace {
 struct State {
     std::mutex mu;
     bool ready = false;
-    int cus = 0;
+    int cus = 0, device = 0;
     int *d_counter = nullptr;
     PlaneJob *d_jobs = nullptr, *h_jobs = nullptr; int cap = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr; bool timed = false; hipStream_t last_stream = nullptr;
@@ -143,7 +143,7 @@ int init_locked() {
     if (!have_device()) return IMCVT_JLS_ERR_NO_DEVICE;
     hipDeviceProp_t prop; int dev = 0;
     HIPCHK(hipGetDevice(&dev)); HIPCHK(hipGetDeviceProperties(&prop, dev));
-    G.cus = prop.multiProcessorCount;
+    G.cus = prop.multiProcessorCount; G.device = dev;
     HIPCHK(hipMalloc(&G.d_counter, sizeof(int)));
     HIPCHK(hipEventCreate(&G.e0)); HIPCHK(hipEventCreate(&G.e1));
     G.ready = true;
@@ -155,6 +155,9 @@ size_t walker_bytes(int w, int rows3) { return 364 * sizeof(jls::PCtx) + (rows3 
 int launch_par_locked(int n, const PlaneJob *jobs, hipStream_t stream);
 bool use_par(int n, const PlaneJob *jobs);
 int launch_locked(int n, const PlaneJob *jobs, hipStream_t stream) {
+    // one launch in flight: the job table, the plane counter and the work arrays belong to the running launch, whatever stream it is on
+    HIPCHK(hipSetDevice(G.device));
+    if (G.timed) HIPCHK(hipEventSynchronize(G.e1));
     if (use_par(n, jobs)) return launch_par_locked(n, jobs, stream);
     G.last_par = 0;
     if (n > G.cap) {
@@ -164,7 +167,7 @@ int launch_locked(int n, const PlaneJob *jobs, hipStream_t stream) {
         HIPCHK(hipMalloc(&G.d_jobs, sizeof(PlaneJob) * n));
         HIPCHK(hipHostMalloc(&G.h_jobs, sizeof(PlaneJob) * n));
         G.cap = n;
-    } else HIPCHK(hipStreamSynchronize(stream));
+    }
     int wmax = 1, rows3 = 0;
     for (int i = 0; i < n; i++) { G.h_jobs[i] = jobs[i]; if (jobs[i].w > wmax) wmax = jobs[i].w; if (jobs[i].near > 0) rows3 = 1; }
     // walkers per wave: measured on 1024 .. 8192 planes of 1080p, two per wave is the optimum (4.3 Gpx/s; one: 3.0, three: 2.9 —
@@ -209,7 +212,6 @@ int launch_par_locked(int n, const PlaneJob *jobs, hipStream_t stream) {
         HIPCHK(hipHostMalloc(&G.h_par, sizeof(jls::ParPlane) * PAR_GROUP));
         G.par_cap = PAR_GROUP;
     }
-    HIPCHK(hipStreamSynchronize(stream));           // staging of an earlier call has been consumed
     HIPCHK(hipEventRecord(G.e0, stream));
     for (int g0 = 0; g0 < n; g0 += PAR_GROUP) {
         const int m = (n - g0 < PAR_GROUP) ? n - g0 : PAR_GROUP;
