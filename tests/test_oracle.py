@@ -87,3 +87,22 @@ def test_edge_sizes(built):
         a, r, (hp, wp) = oracle.port_encode(img, 1)
         assert (hp, wp) == ((h + 31) // 32 * 32, (w + 31) // 32 * 32)
         assert r.shape == (hp, wp) and len(a) > 80
+
+
+def test_bench_workload_digests_are_complete_and_consistent():
+    """tests/golden/bench512_kat.json pins every frame of BASELINE configs[3] (syn(1920,1080,0..511), qpd6 0) to the REAL
+    reference (make_bench_golden.py).  Complete, and equal to the independently generated 1080p entries of hevc_kat.json."""
+    import json
+    from conftest import ROOT, kat_entries
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "bench512_kat.json")))
+    assert d["qpd6"] == 0 and d["input"] == {"kind": "syn", "w": 1920, "h": 1080}
+    assert sorted(int(k) for k in d["frames"]) == list(range(512))
+    seen = 0
+    for e in kat_entries():
+        i = e["input"]
+        if i.get("kind") == "syn" and (i.get("w"), i.get("h")) == (1920, 1080) and e["qpd6"] == 0:
+            f = d["frames"][str(i["arg"])]
+            assert (f["bytes"], f["sha256"], f["rcon_sha256"]) == (e["bytes"], e["sha256"], e["rcon_sha256"])
+            seen += 1
+    assert seen >= 8
+    assert len({f["sha256"] for f in d["frames"].values()}) == 512
