@@ -71,9 +71,12 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   // barrier) before one lane stores the flag; the consumer sees the flag, passes a barrier, and only then loads the
   // payload.  No L2 write-back / L1 invalidate is involved: with hundreds of workgroups per XCD keeping megabytes of
   // dirty token scratch in L2, an agent-scope release (buffer_wbl2) per hand-off was measured to halve the throughput.
+#ifndef MAIL_POLL_SLEEP
+#define MAIL_POLL_SLEEP 32      // x 64 cycles between polls (~0.9 us): a hop is microseconds, a CTU milliseconds; hundreds of waves polling faster load the fabric
+#endif
   HD u32 m_ld32(const void *p) { return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   HD void m_st32(void *p, u32 v) { __hip_atomic_store((u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  HD void mail_poll_pause() { __builtin_amdgcn_s_sleep(4); }
+  HD void mail_poll_pause() { __builtin_amdgcn_s_sleep(MAIL_POLL_SLEEP); }
   HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
@@ -297,6 +300,7 @@ struct FrameCtx {
     i32 trace_n;
     i32 frame;          // index of the job being encoded
     TeamMail *mail;     // this team's mailboxes (null: the workgroup encodes its frames alone)
+    i32 help16;         // the team has a helper for the 16x16 CUs (teams of 3); teams of 2 only hand out the 32x32 CU
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
 };
 

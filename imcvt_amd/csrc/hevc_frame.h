@@ -300,7 +300,7 @@ HDN void enter_cu(int depth, int N, int y0, int x0, int code_split, int avm) {
         if (tid == 64) SM.entry_a[depth] = SM.live;
     }
     wg_sync();
-    if (F.mail && N >= 16) post_request(depth, N, y0, x0, avm);     // team: a helper starts on this CU's 70 unsplit candidates now
+    if (F.mail && (N == 32 || (N == 16 && F.help16))) post_request(depth, N, y0, x0, avm);     // team: a helper starts on this CU's 70 unsplit candidates now
     if (code_split) {
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
@@ -580,7 +580,7 @@ HD void encode_ctu() {
             decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
-        if (team) decide_remote(1, 16, y16, x16);
+        if (team && F.help16) decide_remote(1, 16, y16, x16);
         else decide_cu(1, 16, y16, x16, pack_avail(a16));
     }
     price_split(0, 32, 0, 0);
@@ -701,7 +701,7 @@ HDN void helper_loop(const Tables *gT, const FrameJob *jobs, const Scratch sc, T
 struct KArgs {
     const Tables *gT; const ColdTables *gK; const FrameJob *jobs; const u8 *hdrs; int njobs;
     const Scratch *scr; int *counter; i32 *trace; int trace_cap; unsigned long long *prof;
-    TeamMail *mail; int team_size, nteams;      // team_size 1: every workgroup encodes whole frames alone; 2: main + one helper; 3: main + a 16x16 helper + a 32x32 helper
+    TeamMail *mail; int team_size, nteams;      // team_size 1: every workgroup encodes whole frames alone; 2: main + a 32x32 helper (the main workgroup keeps the 16x16 CUs); 3: main + a 16x16 helper + a 32x32 helper
 };
 #ifdef IMCVT_HOSTEMU
 HD int next_job(int *counter) { return (*counter)++; }
@@ -733,10 +733,15 @@ HD void kernel_main(const KArgs &A, int block) {
     sc.trace_cap = A.trace_cap; sc.prof = A.prof;
     if (role != 0) {
         sc.trace = (i32 *)0;
-        helper_loop(A.gT, A.jobs, sc, A.mail + team, team_size == 2 ? 3 : (role == 1 ? 1 << SLOT_16 : 1 << SLOT_32), role);
+        helper_loop(A.gT, A.jobs, sc, A.mail + team, (team_size == 2 || role == 2) ? 1 << SLOT_32 : 1 << SLOT_16, role);
         return;
     }
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = team_size > 1 ? A.mail + team : (TeamMail *)0; F.seq[0] = 0; F.seq[1] = 0; } }
+#ifndef IMCVT_HOSTEMU
+    // the main workgroup of a team carries the frame's critical path while its helpers have ~40 % slack: it wins the VALU
+    // arbitration of the SIMDs it shares with them (measured: 320 teams 5.75 s -> 4.95 s, 256 teams 4.78 s -> 4.31 s)
+    if (team_size > 1) __builtin_amdgcn_s_setprio(2);
+#endif
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = team_size > 1 ? A.mail + team : (TeamMail *)0; F.help16 = team_size == 3; F.seq[0] = 0; F.seq[1] = 0; } }
     // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
     // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)
     wg_sync();
@@ -750,6 +755,6 @@ HD void kernel_main(const KArgs &A, int block) {
         WAVES(w) LANES(l) { if (w == 0 && l == 0) F.frame = f; }
         encode_frame(A.gT, A.gK, A.jobs[f], sc, A.hdrs + (size_t)HDR_MAX * f);
     }
-    if (team_size > 1) { post_exit(SLOT_16); post_exit(SLOT_32); }
+    if (team_size > 1) { if (team_size == 3) post_exit(SLOT_16); post_exit(SLOT_32); }
 }
 #undef F

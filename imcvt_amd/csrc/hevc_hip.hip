@@ -150,15 +150,37 @@ extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) {
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) { if (!c) return IMCVT_ERR_ARG; if (nteams) *nteams = c->last_nteams; return c->last_team; }
 
-// How many workgroups share a frame.  A frame alone in a workgroup keeps 3 wavefronts busy for ~8.7 s (1080p) whatever else
-// runs; a team of 3 finishes it in ~4.1 s but its helpers idle ~40 % of the time.  Measured on MI355X (1080p frames, qpd6 0,
-// profiles/r02*_scale_probe.log): up to 320 teams (960 of the 1024 resident workgroups) a batch finishes in 4.1-5.8 s with
-// teams against 8.7-9.3 s without; beyond that teams need a second round (336 teams: 9.5 s for 512 frames, 17 s for 1000)
-// while frame-per-workgroup launches keep scaling (10.0 s for 512, 13.1 s for 1000).  Teams of 2 (one helper serving both
-// request kinds) lose to both and are kept for tests.
-static int pick_team(const imcvt_hevc_ctx *c, int n) {
-    if (c->force_team >= 1) return c->force_team;
-    return (3 * n <= c->max_wg - c->max_wg / 16) ? 3 : 1;
+// How many workgroups share a frame, and how many teams.  A frame alone in a workgroup keeps 3 wavefronts busy for ~8.7 s
+// (1080p) whatever else runs; a team of 3 finishes it in ~4.1 s but its helpers idle ~40 % of the time, so teams win while the
+// device is not full and lose when it is.  Model from measurements on MI355X (1080p frames, qpd6 0, kernel seconds per batch,
+// profiles/r02_scale_probe.log, r02n_prio.log; only ratios matter, both sides scale with the CTU count):
+//   solo   1: 8.66   256: 8.86   512: 9.96   1000: 13.05
+//   teams  T teams, one frame each: 4.06 + 0.9 (T/320)^5   (64: 4.09, 256: 4.31, 320: 4.95; 336 teams — 1008 of the 1024 resident
+//          workgroups — are erratic, 4.9 or 8.3 s, so 320 is the cap); n frames take ceil(n/T) rounds
+// Teams of 2 (main + a 32x32 helper, the main workgroup keeps the 16x16 CUs) lose to both and exist for tests.
+static double solo_seconds(int n) {
+    static const double xs[4] = { 0, 256, 512, 1000 }, ys[4] = { 8.66, 8.86, 9.96, 13.05 };
+    if (n >= 1000) return 13.05 * n / 1000.0;
+    for (int i = 0; i < 3; i++) if (n <= xs[i + 1]) return ys[i] + (ys[i + 1] - ys[i]) * (n - xs[i]) / (xs[i + 1] - xs[i]);
+    return 13.05;
+}
+static int pick_team(const imcvt_hevc_ctx *c, int n, int *nteams) {
+    const int cap = (((c->max_wg - c->max_wg / 16) / 3) & ~7) < c->mail_cap ? (((c->max_wg - c->max_wg / 16) / 3) & ~7) : (c->mail_cap & ~7);   // 320 on MI355X
+    if (c->force_team >= 2) {
+        const int tcap = c->force_team == 3 ? cap : ((c->max_wg / 2) & ~7) < c->mail_cap ? ((c->max_wg / 2) & ~7) : (c->mail_cap & ~7);
+        *nteams = ((n + 7) & ~7) < tcap ? ((n + 7) & ~7) : tcap;
+        return *nteams >= 8 ? c->force_team : 1;
+    }
+    *nteams = 0;
+    if (c->force_team == 1 || cap < 8) return 1;
+    const int rounds = (n + cap - 1) / cap;
+    int T = (((n + rounds - 1) / rounds) + 7) & ~7;              // balanced rounds
+    if (T > cap) T = cap;
+    double r = (double)T / cap, f = r * r * r * r * r;
+    const double team_s = rounds * (4.06 + 0.9 * f);
+    if (team_s >= solo_seconds(n)) return 1;
+    *nteams = T;
+    return 3;
 }
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
@@ -191,16 +213,12 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(int), stream));
-    int team = pick_team(c, n), nteams = 0, grid;
-    if (team > 1) {
-        const int cap = (c->max_wg / team) & ~7;                    // teams that fit the device, a multiple of 8 (team members share an XCD)
-        nteams = ((n + 7) & ~7) < cap ? ((n + 7) & ~7) : cap;
-        if (nteams < 8 || nteams > c->mail_cap) team = 1;
-    }
+    int nteams = 0, grid;
+    int team = pick_team(c, n, &nteams);
     if (team > 1) {
         grid = team * nteams;
         HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nteams, stream));     // sequence numbers restart with every launch
-    } else { team = 1; grid = n < c->max_wg ? n : c->max_wg; }
+    } else { team = 1; nteams = 0; grid = n < c->max_wg ? n : c->max_wg; }
     c->last_team = team; c->last_nteams = nteams;
     HIPCHK(hipEventRecord(c->ev0, stream));
     launch(c, grid, stream, n, team, nteams);
