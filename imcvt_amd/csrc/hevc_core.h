@@ -1571,13 +1571,18 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv) : "v"(pn) : "memory");
 #endif
         if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / lm rows belong to lane 0
+            const long long tp0 = prof_now();
             ring_sync(sink, a.cnt);                         // full 16-byte runs of output leave the ring
             int qn = 0;
             MARK("p2_ring_sync");
+            prof_add(PF_T_NDRAIN, tp0);
+            const long long tp1 = prof_now();
             UNROLL_FULL
             for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
                 code_token_q(a, cx, lm->lq, qn, tok_of(cur, j));
             MARK("p2_eight_tokens");
+            prof_add(PF_T_NTOK, tp1); prof_cnt(PF_BORDER, 1);
+            const long long tp2 = prof_now();
             NOUNROLL
             for (int i = 0; WAVE_ANY(i < qn); i++) {        // the bytes this block pushed out of `low` (:863-878): the common case is
                 const int act = i < qn;                     // straight-line (one byte buffered, no 0xFF run, no emulation prevention)
@@ -1592,11 +1597,14 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
                 const int rare = act & !fast;
                 if (WAVE_ANY(rare)) { if (rare) carry_rare(a, sink, lead); }
             }
+            prof_add(PF_T_DRAIN, tp2);
         }
 #ifdef IMCVT_HOSTEMU
         cur = nxt;
 #else
+        const long long tp3 = prof_now();
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(nv) : : "memory");
+        prof_add(PF_T_SETUP, tp3);
         cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
 #endif
     }
