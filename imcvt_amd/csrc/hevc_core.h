@@ -357,6 +357,20 @@ HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0) SM.prof[threadI
 #else
 HD void prof_cnt(int, int) {}
 #endif
+// Wave collectives for the decisions: the reference's "last minimum wins" scan (`best >= cost` accepts, :1439, :1475, :1520)
+// over a wave's lanes = the minimum over the valid lanes, then the highest valid lane that holds it.
+HD int wave_min_i32(int v, int l) {
+    for (int d = 32; d >= 1; d >>= 1) v = imin(v, wave_shfl(v, l ^ d));
+    return v;
+}
+HD int hibit64(u64 m) { return (m >> 32) ? 32 + hibit((u32)(m >> 32)) : hibit((u32)m); }
+// returns the winning lane (valid lanes only; at least one lane must be valid); *mn receives the minimum
+HD int wave_last_min(int cost, int valid, int l, int *mn) {
+    const int m = wave_min_i32(valid ? cost : I32MAX, l);
+    *mn = m;
+    return hibit64(wave_ballot(valid && cost == m));
+}
+
 // workgroup barrier whose wait time is booked under PF_SYNC
 HD void wg_sync_p() { const long long t = prof_now(); wg_sync(); prof_add(PF_SYNC, t); }
 

@@ -150,9 +150,9 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
         wave_sync_lds();
         prof_add(PF_P2_PU, pt);
         LANES(l) {                                      // pick the PU mode: later mode wins ties (:1520)
+            int mn;
+            const int bm = wave_last_min(l < NMODE ? W.cost[l] : 0, l < NMODE, l, &mn);
             if (l == 0) {
-                int best = I32MAX, bm = 0;
-                for (int m = 0; m < NMODE; m++) if (best >= W.cost[m]) { best = W.cost[m]; bm = m; }
                 W.pu_mode[k] = bm; W.pu_sse[k] = W.sse[bm];
                 W.pu_cnt[k] = W.tnz[bm] ? W.tokn[bm] - 7 : 1;                            // an all-zero PU is cbf_luma = 0 inside the CU
             }
@@ -248,10 +248,17 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
     }
     wg_sync_p();
     WAVES(w) LANES(l) {
+        // split cost first, then modes 0..34 with one TU, 0..34 with four TUs, then NxN, each accepted with `best >= cost`: the last
+        // minimum wins.  Wave 0 scans: the minimum of the 70, a four-TU candidate that holds it beats every one-TU candidate.
+        int m1 = 0, m2 = 0, l1 = 0, l2 = 0;
+        if (w == 0) {
+            l1 = wave_last_min(l < NMODE ? WM(0).cost[l] : 0, l < NMODE, l, &m1);
+            l2 = wave_last_min(l < NMODE ? WM(1).cost[l] : 0, l < NMODE, l, &m2);
+        }
         if (w == 0 && l == 0) {
             int best = (N > 8) ? SM.split_cost[depth] : I32MAX, kind = 0, mode = 0;
-            for (int m = 0; m < NMODE; m++) if (best >= WM(0).cost[m]) { best = WM(0).cost[m]; kind = 1; mode = m; }
-            for (int m = 0; m < NMODE; m++) if (best >= WM(1).cost[m]) { best = WM(1).cost[m]; kind = 2; mode = m; }
+            if (best >= m1) { best = m1; kind = 1; mode = l1; }
+            if (best >= m2) { best = m2; kind = 2; mode = l2; }
             if (N == 8 && best >= WM(2).nxn_cost) { best = WM(2).nxn_cost; kind = 3; }
             SM.win_kind = kind; SM.win_mode = mode;
             if (F.sc.trace && F.trace_n + 8 <= F.sc.trace_cap) {
@@ -502,11 +509,11 @@ HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
     WAVES(w) eval_2Nx2N(w, depth, N, y0, x0, avm);
     wg_sync();
     WAVES(w) LANES(l) {
-        if (w == 0 && l == 0) {
-            int best = I32MAX, kind = 1, mode = 0;
-            for (int c = 0; c < NMODE; c++) if (best >= WM(0).cost[c]) { best = WM(0).cost[c]; kind = 1; mode = c; }
-            for (int c = 0; c < NMODE; c++) if (best >= WM(1).cost[c]) { best = WM(1).cost[c]; kind = 2; mode = c; }
-            SM.win_kind = kind; SM.win_mode = mode; SM.red[0] = best;
+        if (w == 0) {
+            int m1, m2;
+            const int l1 = wave_last_min(l < NMODE ? WM(0).cost[l] : 0, l < NMODE, l, &m1);
+            const int l2 = wave_last_min(l < NMODE ? WM(1).cost[l] : 0, l < NMODE, l, &m2);
+            if (l == 0) { const int four = m1 >= m2; SM.win_kind = four ? 2 : 1; SM.win_mode = four ? l2 : l1; SM.red[0] = four ? m2 : m1; }
         }
     }
     wg_sync();
