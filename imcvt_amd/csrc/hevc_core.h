@@ -174,7 +174,7 @@ HD int mat_off(int s) { return s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336; }
 // ---------------------------------------------------------------------------------------------------
 // Arithmetic coder state (:796-805) — `cnt` counts bytes of the current CTU already pushed.
 // ---------------------------------------------------------------------------------------------------
-enum { PF_BORDER = 0, PF_P1_32, PF_P1_16, PF_P1_8, PF_P1_4, PF_P2_32, PF_P2_16, PF_P2_8, PF_P2_PU, PF_P2_NXN, PF_SYNC, PF_DECIDE, PF_RECON, PF_CTUIO, PF_T_SETUP, PF_T_HDR, PF_T_GEN, PF_T_DRAIN, PF_T_NDRAIN, PF_T_NTOK, PF_N };
+enum { PF_BORDER = 0, PF_P1_32, PF_P1_16, PF_P1_8, PF_P1_4, PF_P2_32, PF_P2_16, PF_P2_8, PF_P2_PU, PF_P2_NXN, PF_SYNC, PF_DECIDE, PF_RECON, PF_CTUIO, PF_T_SETUP, PF_T_HDR, PF_T_GEN, PF_T_DRAIN, PF_T_NDRAIN, PF_T_NTOK, PF_X1, PF_X2, PF_X3, PF_N };
 struct Arith { i32 range, low, nbits, nbytes, bufbyte, zeros, cnt; };
 HD void arith_reset(Arith &a) { a.range = 510; a.low = 0; a.nbits = 23; a.nbytes = 0; a.bufbyte = 0xFF; a.zeros = 0; a.cnt = 0; }
 HD int arith_len(const Arith &a) { return 8 * (a.cnt + a.nbytes) + 23 - a.nbits; }      // :834
@@ -347,9 +347,11 @@ HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] 
 // Optional cycle accounting per wave (build with -DIMCVT_PROF): category -> accumulated shader clocks
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
 HD long long prof_now() { return clock64(); }
+HD int threadIdx_wave() { return (int)(threadIdx.x >> 6); }
 HD void prof_add(int cat, long long t0) { if ((threadIdx.x & 63u) == 0) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)(clock64() - t0); }
 #else
 HD long long prof_now() { return 0; }
+HD int threadIdx_wave() { return 0; }
 HD void prof_add(int, long long) {}
 #endif
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
@@ -1156,6 +1158,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4], x[4][4], t[4][4];
             MARK("b4_setup");
+            long long t4 = prof_now();
             pred_block4(T, br, 4, 2, mode, 0, 0, pr);
             MARK("b4_predict");
             for (int yi = 0; yi < 4; yi++) {
@@ -1178,8 +1181,10 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
             }
             MARK("b4_residual_dst");
+            prof_add(PF_T_HDR, t4); t4 = prof_now();        // (4x4 pipeline, IMCVT_PROF builds: t_hdr = predict + DST, passA = RDOQ, p2_8 on wave 2 = tokens, recon = inverse + SSE)
             const int any = rdoq_group<0>(x, Q);
             MARK("b4_rdoq");
+            prof_add(PF_T_GEN, t4); t4 = prof_now();
             const int st = scan_type_of(4, mode);
             if (P.tok) {                                    // the TU's tokens: cbf_luma, last position, the one group
                 Lv16 L; u32 nzm = 0;
@@ -1205,6 +1210,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 W.tnz[c] = (nzm != 0);
             }
             MARK("b4_tokens");
+            prof_add(threadIdx_wave() == 2 ? PF_P2_8 : PF_T_NTOK, t4); t4 = prof_now();
             int part = 0;
             if (any) {
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * (1 << Q.dqs));
@@ -1242,6 +1248,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
             }
             if (P.only_mode < 0) W.sse[c] += part;         // this lane is the only writer of sse[c] in this pass
             MARK("b4_inverse_recon_sse");
+            prof_add(threadIdx_wave() == 2 ? PF_RECON : PF_T_NDRAIN, t4);
         }
     }
     wave_sync_lds();
@@ -1573,7 +1580,12 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
     // token blocks are loaded unconditionally (index clamped to the stream's last block; p is always a valid address),
     // so the loop carries no conditional load and the only wait for a block is where it is first used, one round later
     const int last_blk = imax((n - 1) >> 3, 0);
+    const long long tx2 = prof_now();
     U4 cur = g_ld128(p);
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w) : : "memory");
+#endif
+    prof_add(PF_X2, tx2);
     NOUNROLL
     for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {           // wave-uniform: one 16-byte block of tokens per lane per round
         const u16 *pn = p + 8 * imin((k0 >> 3) + 1, last_blk);
@@ -1622,7 +1634,9 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
         cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
 #endif
     }
+    const long long tx3 = prof_now();
     ring_finish(sink, a.cnt);
+    prof_add(PF_X3, tx3);
     return sink.ovf;
 }
 // the same on the safe path: bytes go straight to memory, one token load per step
@@ -1641,7 +1655,9 @@ HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, LaneMem *lm, u8 *gbuf, con
 #ifdef IMCVT_TOKSTAT
     if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
 #endif
+    const long long tx1 = prof_now();
     if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i);
+    prof_add(PF_X1, tx1);                                   // (IMCVT_PROF builds: x1 = context copy, x2 = wait for the first token block, x3 = after the last block)
     const int ovf = stream_run(a, cx, lm, gbuf, p, on ? n : 0);
     if (WAVE_ANY(ovf)) {                                    // practically never: redo the overflowed lanes without the ring
         if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i); }

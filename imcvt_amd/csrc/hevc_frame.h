@@ -135,12 +135,14 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
         wave_sync_lds();
         long long pt = prof_now();
         border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
-        P1Args P;
+        prof_add(PF_P1_32, pt); pt = prof_now();            // (NxN chain, IMCVT_PROF builds: p1_32 = borders, p1_16 = store drain before pricing, p1_8 = pick + keep,
+        P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
         P.own = wave; P.c_lo = 0; P.c_hi = NMODE;
         p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         wave_sync();
+        prof_add(PF_P1_16, pt); pt = prof_now();
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             const int on = l < NMODE, ll = on ? l : 0;
             Arith a; arith_reset(a);
@@ -148,7 +150,7 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
             if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
         }
         wave_sync_lds();
-        prof_add(PF_P2_PU, pt);
+        prof_add(PF_P2_PU, pt); pt = prof_now();
         LANES(l) {                                      // pick the PU mode: later mode wins ties (:1520)
             int mn;
             const int bm = wave_last_min(l < NMODE ? W.cost[l] : 0, l < NMODE, l, &mn);
@@ -166,6 +168,7 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
             if (l < 16) SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
         }
         wave_sync_lds();
+        prof_add(PF_P1_8, pt);
     }
     // price the whole NxN CU from the entry state (:1530-1543)
     const int uy = y0 >> 2, ux = x0 >> 2;
@@ -198,6 +201,8 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
         }
         if (l < 8 && ((pos + l) >> 3) == (pos >> 3) && (pos & 7) != 0) g_st16((i16 *)(nxn + pos + l), (int)TOK_IDLE);   // idle tokens up to the block boundary
         wave_sync();
+        prof_add(PF_P2_32, ptn);
+        const long long ptt = prof_now();
         const int on = l == 0;
         Arith a = SM.entry_a[2];
         const int len0 = arith_len(a);
@@ -206,6 +211,7 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
             W.fin[0] = pack_arith(a);
             W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);
         }
+        prof_add(PF_P2_16, ptt);
     }
     wave_sync();
     prof_add(PF_P2_NXN, ptn);

@@ -204,7 +204,7 @@ class DeviceEncoder:
         _check(self.lib.imcvt_hevc_encode_device(self.ctx, batch["n"], batch["frames"], C.c_void_p(s.cuda_stream)),
                "imcvt_hevc_encode_device")
 
-    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "wait_help", "recon", "idle", "t_setup", "t_hdr", "passA", "passB", "passC", "n_cg")
+    PROF_CATS = ("border", "p1_32", "p1_16", "p1_8", "p1_4", "p2_32", "p2_16", "p2_8", "p2_pu", "p2_nxn", "sync", "wait_help", "recon", "idle", "t_setup", "t_hdr", "passA", "passB", "passC", "n_cg", "x1", "x2", "x3")
 
     def debug_prof(self, reset=True):
         """Per-wave cycle totals by phase (only non-zero for -DIMCVT_PROF builds): rows = 3 waves of the main role (or of
