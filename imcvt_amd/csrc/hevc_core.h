@@ -300,6 +300,7 @@ struct FrameCtx {
     i32 trace_n;
     i32 frame;          // index of the job being encoded
     TeamMail *mail;     // this team's mailboxes (null: the workgroup encodes its frames alone)
+    i32 prio_base;      // wave priority of this workgroup outside its critical sections (2: main workgroup of a team, 0 otherwise)
     i32 help16;         // the team has a helper for the 16x16 CUs (teams of 3); teams of 2 only hand out the 32x32 CU
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
 };

@@ -22,6 +22,9 @@ HD Avail child_avail(const Avail &p, int k) {       // Z-order availability of q
     return c;
 }
 #define F (SM.F)
+#ifndef NXN_PRIO_SOLO
+#define NXN_PRIO_SOLO 1
+#endif
 #define HDR_MAX 96       // bytes reserved per frame for the stream headers the host prepares (:664-690)
 
 HD u16 *wave_tok(const Scratch &sc, int wave) { return sc.tok + (size_t)wave * TOK_SLOTS * TOK_CAP; }
@@ -121,6 +124,11 @@ HDN_EVAL void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
 #define NXN_KEEP 1024
 #define NXN_KEEP_STRIDE 160
 HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
+#ifndef IMCVT_HOSTEMU
+    // the NxN chain is the longest of an 8x8 CU's three candidate sets: its wave wins the VALU arbitration of the SIMD it shares
+    // with waves of other workgroups (1024 frames in flight: +3 %)
+    if (F.prio_base) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(NXN_PRIO_SOLO);
+#endif
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q;
@@ -215,6 +223,9 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
     }
     wave_sync();
     prof_add(PF_P2_NXN, ptn);
+#ifndef IMCVT_HOSTEMU
+    if (F.prio_base) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // ---- the winner's reconstruction (only the winner's is ever needed, so candidates do not store theirs): the winning
@@ -754,6 +765,7 @@ HD void kernel_main(const KArgs &A, int block) {
     // arbitration of the SIMDs it shares with them (measured: 320 teams 5.75 s -> 4.95 s, 256 teams 4.78 s -> 4.31 s)
     if (team_size > 1) __builtin_amdgcn_s_setprio(2);
 #endif
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.prio_base = team_size > 1 ? 2 : 0; }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = team_size > 1 ? A.mail + team : (TeamMail *)0; F.help16 = team_size == 3; F.seq[0] = 0; F.seq[1] = 0; } }
     // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
     // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)
