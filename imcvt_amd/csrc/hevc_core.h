@@ -229,7 +229,8 @@ struct alignas(16) WaveMem {
 };
 #define WAVE2_BYTES (sizeof(WaveMem) - 7168 + W2_PAD + NMODE * 16)
 
-#define TRIAL_BYTES 3584
+#define TRIAL_BYTES 3584          // bytes one trial may emit: the reference's own per-CTU coder buffer is TMPBUF_LEN = 3200 (:794), unchecked there too
+static_assert(TRIAL_BYTES >= 3200 + 256, "a trial's byte buffer must cover the reference's per-CTU coder buffer plus the 16-byte flush granularity");
 // Per-frame job and per-workgroup scratch (global memory)
 struct FrameJob {
     const u8 *img;   // h*w gray8

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <new>
+#include <stdexcept>
 
 namespace {
 
@@ -167,7 +169,15 @@ const char *format_name(int color_type, int depth) {
 }
 
 // decodes into `img` (samples as stored: 1, 3 or 4 bytes per pixel for the accepted formats); returns an upng_error value
+int decode_unguarded(const std::vector<uint8_t> &f, uint32_t &w, uint32_t &h, int &color_type, int &depth, std::vector<uint8_t> &img);
+// A header may declare any size: a picture whose buffers cannot be allocated is reported like the reference's failed
+// malloc (uPNG.c:1071-1079 -> "open failed"), not by an exception leaving an extern "C" loader.
 int decode(const std::vector<uint8_t> &f, uint32_t &w, uint32_t &h, int &color_type, int &depth, std::vector<uint8_t> &img) {
+    try { return decode_unguarded(f, w, h, color_type, depth, img); }
+    catch (const std::bad_alloc &) { return kMalformed; }
+    catch (const std::length_error &) { return kMalformed; }
+}
+int decode_unguarded(const std::vector<uint8_t> &f, uint32_t &w, uint32_t &h, int &color_type, int &depth, std::vector<uint8_t> &img) {
     static const uint8_t sig[8] = { 137, 80, 78, 71, 13, 10, 26, 10 };
     if (f.size() < 29 || memcmp(f.data(), sig, 8) != 0) return kNotPng;
     if (memcmp(f.data() + 12, "IHDR", 4) != 0) return kMalformed;
@@ -188,6 +198,7 @@ int decode(const std::vector<uint8_t> &f, uint32_t &w, uint32_t &h, int &color_t
     const int channels = color_type == 0 ? 1 : color_type == 2 ? 3 : color_type == 4 ? 2 : 4;
     const size_t bpp = (size_t)channels * depth, line = ((size_t)w * bpp + 7) / 8, bytes_pp = (bpp + 7) / 8;
     std::vector<uint8_t> raw;
+    if (w == 0 || h == 0 || line > ((size_t)1 << 40) / h) return kMalformed;   // (sizes whose products would wrap)
     const size_t cap = ((size_t)w * ((size_t)h * bpp + 7)) / 8 + h;           // uPNG.c:1071
     if (!zlib_inflate(z.data(), z.size(), raw, cap)) return kMalformed;
     raw.resize((line + 1) * (size_t)h > raw.size() ? (line + 1) * (size_t)h : raw.size(), 0);
