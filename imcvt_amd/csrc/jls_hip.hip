@@ -94,7 +94,14 @@ __global__ __launch_bounds__(K2_ROWS) void jls_par_k2(const jls::ParPlane *pl) {
 __global__ void jls_par_k3(const jls::ParPlane *pl) { const jls::ParPlane P = pl[blockIdx.y]; const long t = PAR_T; if (t < 365) jls::k3_cells(P, t); }
 __global__ void jls_par_k3b(const jls::ParPlane *pl) { if (threadIdx.x == 0) jls::k3_bases(pl[blockIdx.y]); }
 __global__ void jls_par_k4(const jls::ParPlane *pl) { const jls::ParPlane P = pl[blockIdx.y]; const long t = PAR_T; if (t < (long)P.h * P.w) jls::k4_scatter(P, t); }
-__global__ __launch_bounds__(64) void jls_par_k5(const jls::ParPlane *pl) { if (threadIdx.x == 0) jls::k5_chain(pl[blockIdx.y], (long)blockIdx.x); }   // one chain per wavefront: a chain is a dependent scalar program
+// one chain per wavefront: a chain is a dependent scalar program.  The 364 regular chains are run by ALL lanes on wave-uniform
+// values (scalar-unit code, every lane stores the same code word to the same address); the run chain by lane 0.
+#ifdef JLS_CHAIN_VECTOR
+#define K5_ALL_LANES 0
+#else
+#define K5_ALL_LANES (blockIdx.x < 364)
+#endif
+__global__ __launch_bounds__(64) void jls_par_k5(const jls::ParPlane *pl) { if (K5_ALL_LANES || threadIdx.x == 0) jls::k5_chain(pl[blockIdx.y], (long)blockIdx.x); }
 __global__ void jls_par_k6(const jls::ParPlane *pl) { const jls::ParPlane P = pl[blockIdx.y]; const long t = PAR_T; if (t < (long)P.h * P.w) jls::k6_len(P, t); }
 __global__ void jls_par_k6b(const jls::ParPlane *pl) { const jls::ParPlane P = pl[blockIdx.y]; const long t = PAR_T; if (t < P.h) jls::k6_rowscan(P, t); }
 __global__ void jls_par_k6c(const jls::ParPlane *pl) { if (threadIdx.x == 0) jls::k6_rows(pl[blockIdx.y]); }

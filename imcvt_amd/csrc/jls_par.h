@@ -68,6 +68,14 @@ enum { CHUNK_BITS = 16384 };                                        // unstuffed
 // Pointers that come out of a struct are generic to the compiler: FLAT loads / stores, which wait on both memory counters
 // (a load issued ahead of its use would be waited for at the next store).  G() says "global memory" at the point of use.
 #define G(type, ptr) ((JLS_GLB type *)(ptr))
+// A context chain is ONE dependent program.  Run by a whole wavefront on wave-uniform values it is executed by the scalar
+// unit (s_* instructions, one issue per cycle or two) instead of as 64-lane vector instructions of which one lane matters:
+// UNI() tells the compiler a loaded value is the same in every lane.
+#if defined(IMCVT_JLS_HOST) || defined(JLS_CHAIN_VECTOR)
+#define UNI(x) (x)
+#else
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
 JD int px_at(const ParPlane &P, int y, int x) { return G(const uint8_t, P.src)[((size_t)y * P.w + x) * P.stride]; }
 
 // ---- k1: one thread per pixel
@@ -201,7 +209,7 @@ JD uint32_t regular_step(const Par &p, Ctx &r, uint32_t el) {
 JD void k5_chain(const ParPlane &P, long t) {
     const Par p = make_par(0);
     if (t < 364) {
-        const uint32_t base = P.binbase[t], n = P.binbase[t + 1] - base;
+        const uint32_t base = UNI(G(const uint32_t, P.binbase)[t]), n = UNI(G(const uint32_t, P.binbase)[t + 1]) - base;
         Ctx r; r.a = p.a_init; r.b = 0; r.c = 0; r.n = 1;
         // Whole blocks of eight samples: the list is read TWO blocks ahead of its use (stores and loads share one in-order
         // completion counter on this target, so a wait for a block's loads also waits for the code words stored before them:
@@ -210,15 +218,15 @@ JD void k5_chain(const ParPlane &P, long t) {
         JLS_GLB const uint32_t *list = G(const uint32_t, P.list) + base;
         JLS_GLB uint32_t *code = G(uint32_t, P.code) + base;
         uint32_t b0[8], b1[8];
-        JLS_UNROLL for (int j = 0; j < 8; j++) { b0[j] = list[j]; b1[j] = list[8 + j]; }
+        JLS_UNROLL for (int j = 0; j < 8; j++) { b0[j] = UNI(list[j]); b1[j] = UNI(list[8 + j]); }
         uint32_t i0 = 0;
         for (; i0 + 8 <= n; i0 += 8) {
             uint32_t cur[8];
-            JLS_UNROLL for (int j = 0; j < 8; j++) { cur[j] = b0[j]; b0[j] = b1[j]; b1[j] = list[i0 + 16 + j]; }
+            JLS_UNROLL for (int j = 0; j < 8; j++) { cur[j] = b0[j]; b0[j] = b1[j]; b1[j] = UNI(list[i0 + 16 + j]); }
             JLS_UNROLL for (int j = 0; j < 8; j++) cur[j] = regular_step(p, r, cur[j]);
             JLS_UNROLL for (int j = 0; j < 8; j++) code[i0 + j] = cur[j];
         }
-        for (; i0 < n; i0++) code[i0] = regular_step(p, r, list[i0]);
+        for (; i0 < n; i0++) code[i0] = regular_step(p, r, UNI(list[i0]));
     } else {
         const uint32_t nev = P.binbase[365];
         Ctx ri[2];
