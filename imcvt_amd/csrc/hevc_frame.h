@@ -571,10 +571,18 @@ HD void encode_ctu() {
     // ---- load the CTU: source pixels replicate the original edges, neighbours come from the padded reconstruction (:1613-1621)
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
-        NOUNROLL
-        for (int i = tid; i < 1024; i += WG_THREADS) {
-            const int y = i >> 5, x = i & 31;
-            SM.org[y][x] = g_ld8(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1));
+        if (cx + 32 <= J.w && (((size_t)J.img | (size_t)J.w) & 3) == 0) {      // CTU columns inside the picture, rows 4-byte aligned: coalesced dword loads
+            NOUNROLL
+            for (int i = tid; i < 256; i += WG_THREADS) {
+                const int y = i >> 3, x4 = (i & 7) * 4;
+                *(u32a *)&SM.org[y][x4] = g_ld32(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + cx + x4);
+            }
+        } else {
+            NOUNROLL
+            for (int i = tid; i < 1024; i += WG_THREADS) {
+                const int y = i >> 5, x = i & 31;
+                SM.org[y][x] = g_ld8(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1));
+            }
         }
         if (tid < 32) SM.rec[tid + 1][0] = g_ld8(J.rcon + (size_t)clip3(cy + tid, 0, J.hp - 1) * J.wp + clip3(cx - 1, 0, J.wp - 1));
         if (tid >= 32 && tid < 32 + 65) {
@@ -614,10 +622,19 @@ HD void encode_ctu() {
     u8 *live_sink = J.out + F.out_pos;
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
-        NOUNROLL
-        for (int i = tid; i < 1024; i += WG_THREADS) {
-            const int y = i >> 5, x = i & 31;
-            g_st8(J.rcon + (size_t)(cy + y) * J.wp + cx + x, SM.rec[y + 1][x + 1]);
+        if (((size_t)J.rcon & 3) == 0) {                    // the padded plane's rows are multiples of 32: dword stores
+            NOUNROLL
+            for (int i = tid; i < 256; i += WG_THREADS) {
+                const int y = i >> 3, x4 = (i & 7) * 4;
+                const u8 *r = &SM.rec[y + 1][x4 + 1];
+                g_st32(J.rcon + (size_t)(cy + y) * J.wp + cx + x4, (u32)r[0] | (u32)r[1] << 8 | (u32)r[2] << 16 | (u32)r[3] << 24);
+            }
+        } else {
+            NOUNROLL
+            for (int i = tid; i < 1024; i += WG_THREADS) {
+                const int y = i >> 5, x = i & 31;
+                g_st8(J.rcon + (size_t)(cy + y) * J.wp + cx + x, SM.rec[y + 1][x + 1]);
+            }
         }
         if (tid < 8) {
             g_st8(F.sc.above_sz + (cx >> 2) + tid, SM.mapsz[8][tid + 1]);
