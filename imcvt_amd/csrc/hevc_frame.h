@@ -104,6 +104,9 @@ HDN_EVAL void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
     u16 *tok = wave_tok(F.sc, wave);
     const RdW rw = rd_weights(q);
     pt = prof_now();
+#ifndef IMCVT_HOSTEMU
+    if (big) { if (F.prio_base) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
+#endif
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a = SM.entry_a[depth];
@@ -115,6 +118,10 @@ HDN_EVAL void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
         }
     }
     wave_sync();
+#ifndef IMCVT_HOSTEMU
+    if (big) { if (F.prio_base) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+#endif
+
     prof_add(N == 32 ? PF_P2_32 : N == 16 ? PF_P2_16 : PF_P2_8, pt);
 }
 
