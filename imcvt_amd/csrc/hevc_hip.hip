@@ -154,15 +154,15 @@ extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) { if (!c) re
 // (1080p) whatever else runs; a team of 3 finishes it in ~4.1 s but its helpers idle ~40 % of the time, so teams win while the
 // device is not full and lose when it is.  Model from measurements on MI355X (1080p frames, qpd6 0, kernel seconds per batch,
 // profiles/r02_scale_probe.log, r02n_prio.log; only ratios matter, both sides scale with the CTU count):
-//   solo   1: 8.66   256: 8.86   512: 9.96   1000: 13.05
-//   teams  T teams, one frame each: 4.06 + 0.9 (T/320)^5   (64: 4.09, 256: 4.31, 320: 4.95; 336 teams — 1008 of the 1024 resident
+//   solo   1: 8.66   256: 8.84   512: 9.91   768: 11.34   1000: 12.19
+//   teams  T teams, one frame each: 4.06 + 0.65 (T/320)^5   (64: 4.03, 256: 4.28, 320: 4.69; 336 teams — 1008 of the 1024 resident
 //          workgroups — are erratic, 4.9 or 8.3 s, so 320 is the cap); n frames take ceil(n/T) rounds
 // Teams of 2 (main + a 32x32 helper, the main workgroup keeps the 16x16 CUs) lose to both and exist for tests.
 static double solo_seconds(int n) {
-    static const double xs[4] = { 0, 256, 512, 1000 }, ys[4] = { 8.66, 8.86, 9.96, 13.05 };
-    if (n >= 1000) return 13.05 * n / 1000.0;
-    for (int i = 0; i < 3; i++) if (n <= xs[i + 1]) return ys[i] + (ys[i + 1] - ys[i]) * (n - xs[i]) / (xs[i + 1] - xs[i]);
-    return 13.05;
+    static const double xs[5] = { 0, 256, 512, 768, 1000 }, ys[5] = { 8.66, 8.84, 9.91, 11.34, 12.19 };
+    if (n >= 1000) return 12.19 * n / 1000.0;
+    for (int i = 0; i < 4; i++) if (n <= xs[i + 1]) return ys[i] + (ys[i + 1] - ys[i]) * (n - xs[i]) / (xs[i + 1] - xs[i]);
+    return 12.19;
 }
 static int pick_team(const imcvt_hevc_ctx *c, int n, int *nteams) {
     const int cap = (((c->max_wg - c->max_wg / 16) / 3) & ~7) < c->mail_cap ? (((c->max_wg - c->max_wg / 16) / 3) & ~7) : (c->mail_cap & ~7);   // 320 on MI355X
@@ -177,7 +177,7 @@ static int pick_team(const imcvt_hevc_ctx *c, int n, int *nteams) {
     int T = (((n + rounds - 1) / rounds) + 7) & ~7;              // balanced rounds
     if (T > cap) T = cap;
     double r = (double)T / cap, f = r * r * r * r * r;
-    const double team_s = rounds * (4.06 + 0.9 * f);
+    const double team_s = rounds * (4.06 + 0.65 * f);
     if (team_s >= solo_seconds(n)) return 1;
     *nteams = T;
     return 3;
