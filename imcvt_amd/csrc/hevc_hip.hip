@@ -164,24 +164,32 @@ static double solo_seconds(int n) {
     for (int i = 0; i < 4; i++) if (n <= xs[i + 1]) return ys[i] + (ys[i + 1] - ys[i]) * (n - xs[i]) / (xs[i + 1] - xs[i]);
     return 12.19;
 }
-static int pick_team(const imcvt_hevc_ctx *c, int n, int *nteams) {
-    const int cap = (((c->max_wg - c->max_wg / 16) / 3) & ~7) < c->mail_cap ? (((c->max_wg - c->max_wg / 16) / 3) & ~7) : (c->mail_cap & ~7);   // 320 on MI355X
-    if (c->force_team >= 2) {
-        const int tcap = c->force_team == 3 ? cap : ((c->max_wg / 2) & ~7) < c->mail_cap ? ((c->max_wg / 2) & ~7) : (c->mail_cap & ~7);
-        *nteams = ((n + 7) & ~7) < tcap ? ((n + 7) & ~7) : tcap;
-        return *nteams >= 8 ? c->force_team : 1;
-    }
+// pure: the launch shape for n frames on a device that holds max_wg workgroups (force_team 0: choose; 1..3: fixed team size)
+extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nteams_out) {
+    int dummy = 0; int *nteams = nteams_out ? nteams_out : &dummy;
     *nteams = 0;
-    if (c->force_team == 1 || cap < 8) return 1;
+    if (n < 1 || max_wg < 1) return 1;
+    const int mail_cap = max_wg / 2 + 8;
+    const int cap3 = ((max_wg - max_wg / 16) / 3) & ~7;                       // 320 on MI355X (1024 resident workgroups)
+    const int cap = cap3 < mail_cap ? cap3 : (mail_cap & ~7);
+    if (force_team >= 2) {
+        const int tcap = force_team == 3 ? cap : ((max_wg / 2) & ~7) < mail_cap ? ((max_wg / 2) & ~7) : (mail_cap & ~7);
+        *nteams = ((n + 7) & ~7) < tcap ? ((n + 7) & ~7) : tcap;
+        if (*nteams >= 8) return force_team > 3 ? 3 : force_team;
+        *nteams = 0;
+        return 1;
+    }
+    if (force_team == 1 || cap < 8) return 1;
     const int rounds = (n + cap - 1) / cap;
     int T = (((n + rounds - 1) / rounds) + 7) & ~7;              // balanced rounds
     if (T > cap) T = cap;
-    double r = (double)T / cap, f = r * r * r * r * r;
+    const double r = (double)T / cap, f = r * r * r * r * r;
     const double team_s = rounds * (4.06 + 0.65 * f);
-    if (team_s >= solo_seconds(n)) return 1;
+    if (team_s >= solo_seconds((int)((long long)n * 1024 / max_wg))) return 1;       // (the solo row was measured with 1024 resident workgroups)
     *nteams = T;
     return 3;
 }
+static int pick_team(const imcvt_hevc_ctx *c, int n, int *nteams) { return imcvt_hevc_plan(n, c->max_wg, c->force_team, nteams); }
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
     if (!c || n < 0 || (n > 0 && !frames)) return IMCVT_ERR_ARG;

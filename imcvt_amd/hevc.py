@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census")
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_plan")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -84,6 +84,8 @@ def load_library():
     lib.imcvt_hevc_batch_devices.argtypes = []
     lib.imcvt_hevc_debug_census.restype = C.c_int
     lib.imcvt_hevc_debug_census.argtypes = [C.c_void_p, C.c_int]
+    lib.imcvt_hevc_plan.restype = C.c_int
+    lib.imcvt_hevc_plan.argtypes = [C.c_int, C.c_int, C.c_int, _ip]
     lib.imcvt_hevc_shutdown.restype = None
     lib.imcvt_hevc_shutdown.argtypes = []
     _lib = lib

@@ -100,6 +100,9 @@ int imcvt_hevc_encode_device(imcvt_hevc_ctx *ctx, int n, const imcvt_hevc_frame 
  * 16x16 / 32x32 candidate sets), 1..3 = fixed.  Results are identical for every setting.
  * Environment override at context creation: IMCVT_HEVC_TEAM. */
 void imcvt_hevc_set_team(imcvt_hevc_ctx *ctx, int team_size);
+/* The choice itself, as a pure function (no device needed): launch shape for n_frames on a device that holds
+ * max_workgroups resident workgroups of the encoder kernel (1024 on MI355X); returns the team size, *nteams the teams. */
+int imcvt_hevc_plan(int n_frames, int max_workgroups, int force_team, int *nteams);
 /* Team size the last launch used (1..3); *nteams receives the number of teams (0 for team size 1). */
 int imcvt_hevc_last_team(imcvt_hevc_ctx *ctx, int *nteams);
 

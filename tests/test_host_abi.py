@@ -87,3 +87,25 @@ def test_reference_main_links_against_the_library_unchanged(built, tmp_path):
         r = subprocess.run([exe, str(src), "-o", str(tmp_path / "out.h265")], capture_output=True, text=True)
         assert r.returncode == 1 and "***ERROR" in r.stdout and "no CPU fallback" in r.stderr
         assert not (tmp_path / "out.h265").exists()
+
+
+def test_launch_shape_policy(built):
+    """imcvt_hevc_plan is pure (no device): teams of three while the batch leaves the device room, frames per workgroup when it
+    is full; team counts are multiples of 8 (members of a team share an XCD), never beyond the resident capacity, and
+    multi-round plans are balanced."""
+    import imcvt_amd
+    lib = imcvt_amd.load_library()
+
+    def plan(n, wg=1024, force=0):
+        nt = C.c_int(-1)
+        return lib.imcvt_hevc_plan(n, wg, force, C.byref(nt)), nt.value
+
+    assert plan(1) == (3, 8) and plan(64) == (3, 64) and plan(65) == (3, 72) and plan(320) == (3, 320)
+    assert plan(512) == (3, 256) and plan(640) == (3, 320)            # two balanced rounds
+    assert plan(768) == (1, 0) and plan(1000) == (1, 0) and plan(5000) == (1, 0)
+    for n in range(1, 1400, 7):
+        team, nt = plan(n)
+        assert team in (1, 3) and (nt == 0 if team == 1 else (nt % 8 == 0 and 8 <= nt <= 320 and 3 * nt <= 1024))
+    assert plan(100, force=1) == (1, 0) and plan(100, force=2) == (2, 104) and plan(2000, force=3) == (3, 320) and plan(2000, force=2) == (2, 512)
+    assert plan(10, wg=16) == (1, 0)                                   # too small a device for eight teams
+    assert plan(0) == (1, 0)
