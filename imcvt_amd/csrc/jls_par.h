@@ -19,7 +19,7 @@
 //                   then every chunk writes its bytes
 //
 // Every step is one thread per item with no intra-workgroup communication, so the same source compiles for the host
-// (-DIMCVT_JLS_HOST, tests/hostemu/jls_par_host.cpp: the grid is a loop) and the bits are checked on the CPU against the
+// (-DIMCVT_JLS_HOST, tests/hostemu/jls_hostemu.cpp: every grid is a loop) and the bits are checked on the CPU against the
 // golden vectors.  Compiled for gfx950 by jls_hip.hip.  NEAR > 0 keeps the walker path (jls_core.h): there the
 // reconstruction depends on the coded errors and the neighbourhood is no longer known in advance.
 #pragma once
