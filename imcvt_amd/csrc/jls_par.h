@@ -181,26 +181,39 @@ JD int golomb_k_nb(int a, int n) {                        // golomb_k without it
     const int k = imax(bitlen((unsigned)imax(a - 1, 0)) - bitlen((unsigned)n), 0);
     return k + ((n << k) < a);
 }
+// clamp on wave-uniform values: the instruction selector turns the max/min pattern into the vector unit's v_med3 even when
+// everything around it is scalar, which costs a round trip through v_readfirstlane
+#if defined(IMCVT_JLS_HOST) || defined(JLS_CHAIN_VECTOR)
+JD int uclamp(int v, int lo, int hi) { return clampi(v, lo, hi); }
+#else
+JD int uclamp(int v, int lo, int hi) {
+    int t;
+    asm("s_max_i32 %0, %1, %2" : "=s"(t) : "s"(v), "s"(lo) : "scc");
+    asm("s_min_i32 %0, %1, %2" : "=s"(t) : "s"(t), "s"(hi) : "scc");
+    return t;
+}
+#endif
 JD uint32_t regular_step(const Par &p, Ctx &r, uint32_t el) {
     const int v = (int)(el & 255), med = (int)((el >> 8) & 255), m = -(int)((el >> 16) & 1);      // m = -1 for the negative sign
-    const int pred = clampi(med + ((r.c ^ m) - m), 0, 255);                                        // med + sign * C (:349-350)
+    const int pred = uclamp(med + ((r.c ^ m) - m), 0, 255);                                        // med + sign * C (:349-350)
     int e = v - pred;
     e = (e ^ m) - m;                                                                               // sign * (x - px)
     e = ((e + 128) & 255) - 128;                                                                   // modRange, qbeta = 256
-    const int ae = iabs(e), neg = e < 0;
+    const int ae = iabs(e), neg = (int)((uint32_t)e >> 31);
     const int k = golomb_k_nb(r.a, r.n);
     const int map = (k == 0) & (2 * r.b <= -r.n);                                                  // :366
-    const int me = 2 * ae + (neg ? -(map + 1) : map);                                              // :367-372
+    const int me = 2 * ae + map - neg * (2 * map + 1);                                             // :367-372: e < 0 ? 2|e| - map - 1 : 2|e| + map
     const int zeros = me >> k, esc = zeros >= p.limit;
-    const uint32_t val = esc ? (256u | ((uint32_t)(me - 1) & 255u)) : ((1u << k) | ((uint32_t)me & ((1u << k) - 1u)));
-    const uint32_t word = val | (uint32_t)(esc ? p.limit + 1 + 8 : zeros + 1 + k) << 24;          // :187-197 (qbpp = 8)
-    const int rs = r.n >= 64;                                                                      // :376-381
+    const uint32_t val_n = (1u << k) | ((uint32_t)me & ((1u << k) - 1u)), val_e = 256u | ((uint32_t)(me - 1) & 255u);
+    const uint32_t word_n = val_n | (uint32_t)(zeros + 1 + k) << 24, word_e = val_e | (uint32_t)(p.limit + 1 + 8) << 24;   // :187-197 (qbpp = 8)
+    const uint32_t word = word_n ^ ((word_n ^ word_e) & (uint32_t)-esc);                           // (a select without a branch)
+    const int rs = r.n >> 6;                                                                       // N >= 64 (N never exceeds 64): :376-381
     int B = (r.b + e) >> rs, N = (r.n >> rs) + 1;
     r.a = (r.a + ae) >> rs;
     const int lo = B <= -N, hi = B > 0;                                                            // :383-392
     const int b_lo = imax(B + N, 1 - N), b_hi = imin(B - N, 0);
     B = lo ? b_lo : hi ? b_hi : B;
-    r.c = clampi(r.c + hi - lo, -128, 127);
+    r.c = uclamp(r.c + hi - lo, -128, 127);
     r.b = B; r.n = N;
     return word;
 }
