@@ -237,3 +237,29 @@ def test_host_batch_uses_the_visible_devices(amd):
     lib.imcvt_hevc_shutdown()                           # contexts are re-created on the next call
     b = amd.HEVCImageEncoderBatch(imgs, 1)
     assert [x[0] for x in a] == [x[0] for x in b]
+
+
+def test_team_handoffs_under_uneven_load(amd):
+    """Mailbox hand-offs between workgroups under uneven load (frames of very different sizes and content, more frames than
+    teams so that every team serves several, repeated launches): teams of 3 and of 2 give what frame-per-workgroup launches give."""
+    import torch
+    rng = np.random.default_rng(77)
+    imgs = []
+    for i in range(140):
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 400))
+        k = i % 4
+        a = (rng.integers(0, 256, (h, w)) if k == 0 else np.clip(rng.normal(128, 40, (h, w)), 0, 255) if k == 1
+             else (np.add.outer(np.arange(h) * 2, np.arange(w) * 3) % 256) if k == 2 else np.full((h, w), int(rng.integers(0, 256))))
+        imgs.append(torch.from_numpy(a.astype(np.uint8)).cuda())
+    qs = [i % 5 for i in range(len(imgs))]
+    enc = amd.DeviceEncoder(max_workgroups=96)          # a small device share: 24 teams of 3 (32 of 2) serve the 140 frames
+    batch = enc.make_batch(imgs, qs)
+    enc.set_team(1); enc.encode(batch); ref = enc.results(batch)
+    for team in (3, 2):
+        enc.set_team(team)
+        for rep in range(2):
+            enc.encode(batch); got = enc.results(batch)
+            assert enc.last_team()[0] == team
+            for i, ((s, r), (s2, r2)) in enumerate(zip(got, ref)):
+                assert s == s2 and (r == r2).all(), (team, rep, i)
+    enc.close()
