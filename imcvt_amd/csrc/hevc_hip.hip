@@ -18,23 +18,6 @@
 __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
                                                                  TeamMail *mail, int team_size, int nteams) {
-#ifdef DBG_OLDKERNEL
-    __shared__ int next_frame;
-    if (threadIdx.x == 0) { SM.F.mail = nullptr; SM.F.seq[0] = 0; SM.F.seq[1] = 0; }
-    for (;;) {
-        if (threadIdx.x == 0) next_frame = atomicAdd(counter, 1);
-        __syncthreads();
-        const int f = next_frame;
-        __syncthreads();
-        if (f >= njobs) break;
-        Scratch sc = scr[blockIdx.x];
-        sc.trace = (f == 0) ? trace : (i32 *)0;
-        sc.trace_cap = trace_cap;
-        sc.prof = prof;
-        encode_frame(gT, gK, jobs[f], sc, hdrs + (size_t)HDR_MAX * f);
-    }
-    return;
-#endif
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
     A.mail = mail; A.team_size = team_size; A.nteams = nteams;
@@ -96,7 +79,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
         } else (void)hipGetLastError();
     }
     c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
-    if (const char *e = getenv("IMCVT_HEVC_TEAM")) c->force_team = atoi(e);
+    if (const char *e = getenv("IMCVT_HEVC_TEAM")) imcvt_hevc_set_team(c, atoi(e));      // clamped to 0..3 like the API call
     c->mail_cap = c->max_wg / 2 + 8;
     Tables *T = new Tables(); ColdTables *K = new ColdTables();
     imcvt::build_tables(*T, *K);
@@ -169,13 +152,17 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nteams_ou
     int dummy = 0; int *nteams = nteams_out ? nteams_out : &dummy;
     *nteams = 0;
     if (n < 1 || max_wg < 1) return 1;
+    force_team = force_team < 0 ? 0 : force_team > 3 ? 3 : force_team;
     const int mail_cap = max_wg / 2 + 8;
     const int cap3 = ((max_wg - max_wg / 16) / 3) & ~7;                       // 320 on MI355X (1024 resident workgroups)
     const int cap = cap3 < mail_cap ? cap3 : (mail_cap & ~7);
     if (force_team >= 2) {
-        const int tcap = force_team == 3 ? cap : ((max_wg / 2) & ~7) < mail_cap ? ((max_wg / 2) & ~7) : (mail_cap & ~7);
+        // a forced team size may fill the device to the last workgroup (grid = team size x teams <= max_wg: every member of every
+        // team is resident, which is all the hand-offs need); the automatic choice below keeps a 1/16 margin for speed
+        const int full = ((max_wg / force_team) & ~7) < mail_cap ? ((max_wg / force_team) & ~7) : (mail_cap & ~7);
+        const int tcap = full;
         *nteams = ((n + 7) & ~7) < tcap ? ((n + 7) & ~7) : tcap;
-        if (*nteams >= 8) return force_team > 3 ? 3 : force_team;
+        if (*nteams >= 8) return force_team;
         *nteams = 0;
         return 1;
     }
@@ -227,6 +214,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         grid = team * nteams;
         HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nteams, stream));     // sequence numbers restart with every launch
     } else { team = 1; nteams = 0; grid = n < c->max_wg ? n : c->max_wg; }
+    if (grid > c->max_wg || (team > 1 && nteams > c->mail_cap)) { fprintf(stderr, "imcvt_hevc: launch shape %d x %d exceeds the context (%d workgroups, %d mailboxes)\n", team, nteams, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
     c->last_team = team; c->last_nteams = nteams;
     HIPCHK(hipEventRecord(c->ev0, stream));
     launch(c, grid, stream, n, team, nteams);
@@ -264,6 +252,7 @@ extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
 extern "C" int imcvt_hevc_debug_prof(imcvt_hevc_ctx *c, unsigned long long *out, int n, int reset) {
     if (!c || !out) return IMCVT_ERR_ARG;
     const int have = 3 * NWAVES * PF_N;
+    HIPCHK(hipSetDevice(c->device));
     if (hipDeviceSynchronize() != hipSuccess) return IMCVT_ERR_HIP;
     if (hipMemcpy(out, c->d_prof, sizeof(unsigned long long) * (n < have ? n : have), hipMemcpyDeviceToHost) != hipSuccess) return IMCVT_ERR_HIP;
     if (reset && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * have) != hipSuccess) return IMCVT_ERR_HIP;

@@ -63,7 +63,10 @@ struct ParPlane {
     int hdr;
 };
 enum { CL_REG = 0, CL_RUN = 1, CL_RUNEND = 2, CL_EOL = 3 };      // CL_EOL: last pixel of a row, inside a run
-enum { CHUNK_BITS = 16384 };                                        // unstuffed bits per stuffing chunk
+#ifndef JLS_CHUNK_BITS
+#define JLS_CHUNK_BITS 16384                                        // unstuffed bits per stuffing chunk (tests also build the host form with 64: a chunk edge every few pixels)
+#endif
+enum { CHUNK_BITS = JLS_CHUNK_BITS };
 
 // Pointers that come out of a struct are generic to the compiler: FLAT loads / stores, which wait on both memory counters
 // (a load issued ahead of its use would be waited for at the next store).  G() says "global memory" at the point of use.
@@ -350,7 +353,9 @@ JD uint32_t stuff_chunk(const ParPlane &P, long c, int st, uint8_t *dst) {
         at += cap;
         cap = (v == 0xFFu) ? 7 : 8;
     }
-    const int out_off = (at >= T) ? 0 : (int)(at - (unsigned long long)(c + 1) * CHUNK_BITS);
+    // Only the LAST chunk has no successor to hand an offset to.  A byte of an earlier chunk may end past T (when T lies 1..7 bits
+    // beyond the chunk edge): its successor then starts at or past T, writes nothing and passes the pending cap on.
+    const int out_off = (end >= T) ? 0 : (int)(at - (unsigned long long)(c + 1) * CHUNK_BITS);
     return (uint32_t)(out_off | (cap == 7) << 3) | n << 8;
 }
 // one thread per (chunk, entry state)

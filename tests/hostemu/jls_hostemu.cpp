@@ -34,6 +34,7 @@ extern "C" long long jls_hostemu_encode(const uint8_t *img, int is_rgb, int h, i
 
 // ---- the parallel (one plane over the whole GPU) path of jls_par.h, with every grid as a loop -------------------------
 #include "../../imcvt_amd/csrc/jls_par.h"
+static long long g_last_bits;
 static long long encode_plane_par(const uint8_t *src0, int stride, int h, int w, uint8_t *out) {
     jls::ParPlane P;
     P.src = src0; P.stride = stride; P.h = h; P.w = w; P.out = out; P.hdr = 0;
@@ -54,8 +55,11 @@ static long long encode_plane_par(const uint8_t *src0, int stride, int h, int w,
     for (long t = 0; t < cmax * 16; t++) jls::k8_simulate(P, t);
     jls::k8_chain(P, cmax);
     for (long c = 0; c < cmax; c++) jls::k8_write(P, c, cmax);
+    g_last_bits = (long long)P.total[0];
     return (long long)P.total[1];
 }
+extern "C" long long jls_hostemu_last_bits(void) { return g_last_bits; }     // unstuffed bits of the plane coded last (tests aim at chunk edges with it)
+extern "C" int jls_hostemu_chunk_bits(void) { return (int)jls::CHUNK_BITS; }
 extern "C" long long jls_hostemu_encode_par(const uint8_t *img, int is_rgb, int h, int w, uint8_t *out) {
     const int planes = is_rgb ? 3 : 1;
     int at = jls::frame_header(out, planes, h, w);

@@ -263,3 +263,42 @@ def test_team_handoffs_under_uneven_load(amd):
             for i, ((s, r), (s2, r2)) in enumerate(zip(got, ref)):
                 assert s == s2 and (r == r2).all(), (team, rep, i)
     enc.close()
+
+
+@pytest.mark.slow
+def test_bench_frames_sample_against_reference_digests(amd):
+    """BASELINE configs[3] at FULL size: 16 of the 512 bench frames (seeds spread over the range) in one device batch against
+    the digests the REAL reference produced for them (tests/golden/bench512_kat.json, make_bench_golden.py)."""
+    import json
+    import torch
+    from conftest import ROOT
+    from oracle import synth
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "bench512_kat.json")))
+    assert kat["input"] == {"kind": "syn", "w": 1920, "h": 1080} and kat["qpd6"] == 0
+    seeds = [8 + 33 * i for i in range(15)] + [511]
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, s)).cuda() for s in seeds], 0)
+    enc.encode(batch)
+    for s, (stream, _) in zip(seeds, enc.results(batch)):
+        e = kat["frames"][str(s)]
+        assert len(stream) == e["bytes"] and hashlib.sha256(stream).hexdigest() == e["sha256"], s
+    enc.close()
+
+
+def test_teams_fill_exactly_the_workgroups_they_are_given(amd):
+    """Forward progress of teams: members of a team are launched in one grid and wait for each other, so every member must be
+    resident.  The library sizes team launches from max_workgroups (never more than 3 T workgroups for T teams); here the context
+    is told the device holds exactly 24 workgroups and 40 frames are queued: 8 teams of 3 serve them in five rounds."""
+    import torch
+    from oracle import oracle, synth
+    imgs = [synth.syn(40 + i, 33 + (i % 5), i) for i in range(40)]
+    enc = amd.DeviceEncoder(max_workgroups=24)
+    enc.set_team(3)
+    batch = enc.make_batch([torch.from_numpy(a).cuda() for a in imgs], 1)
+    enc.encode(batch)
+    team, nteams = enc.last_team()
+    assert team == 3 and 3 * nteams <= 24
+    for a, (s, r) in zip(imgs, enc.results(batch)):
+        ws, wr, _ = oracle.cpu_encode(a, 1)
+        assert s == ws and (r == wr).all()
+    enc.close()
