@@ -106,6 +106,6 @@ def test_launch_shape_policy(built):
     for n in range(1, 1400, 7):
         team, nt = plan(n)
         assert team in (1, 3) and (nt == 0 if team == 1 else (nt % 8 == 0 and 8 <= nt <= 320 and 3 * nt <= 1024))
-    assert plan(100, force=1) == (1, 0) and plan(100, force=2) == (2, 104) and plan(2000, force=3) == (3, 320) and plan(2000, force=2) == (2, 512)
+    assert plan(100, force=1) == (1, 0) and plan(100, force=2) == (2, 104) and plan(2000, force=3) == (3, 336) and plan(2000, force=2) == (2, 512)
     assert plan(10, wg=16) == (1, 0)                                   # too small a device for eight teams
     assert plan(0) == (1, 0)
