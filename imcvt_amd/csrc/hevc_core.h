@@ -45,7 +45,10 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   static void emu_yield();
   HD u32 m_ld32(const void *p) { return *(const volatile u32 *)p; }
   HD void m_st32(void *p, u32 v) { *(volatile u32 *)p = v; }
+  HD u32 m_add32(void *p, u32 v) { const u32 o = *(volatile u32 *)p; *(volatile u32 *)p = o + v; return o; }
+  HD int m_cas32(void *p, u32 expect, u32 desired) { if (*(volatile u32 *)p != expect) return 0; *(volatile u32 *)p = desired; return 1; }
   HD void mail_poll_pause() { emu_yield(); }
+  HD void mail_idle_pause(int) { emu_yield(); }
   HD void drain_stores() {}
 #else
   #define HD __device__ __forceinline__
@@ -76,7 +79,11 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
 #endif
   HD u32 m_ld32(const void *p) { return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   HD void m_st32(void *p, u32 v) { __hip_atomic_store((u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  HD u32 m_add32(void *p, u32 v) { return __hip_atomic_fetch_add((u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  HD int m_cas32(void *p, u32 expect, u32 desired) { return __hip_atomic_compare_exchange_strong((u32 *)p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   HD void mail_poll_pause() { __builtin_amdgcn_s_sleep(MAIL_POLL_SLEEP); }
+  // an idle helper backs off (round r of an unsuccessful poll): ~0.9 us doubling to ~7 us, so that hundreds of idle helpers do not hammer the queue words
+  HD void mail_idle_pause(int r) { const int n = r < 3 ? 1 << r : 8; for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(MAIL_POLL_SLEEP); }
   HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
@@ -168,7 +175,11 @@ struct Tables {
     u16 iang[36];          // |invAngle|                                                                  (:283)
 };
 // tables that stay in global memory (read once per frame)
-struct ColdTables { u8 ctx_init[5][CTX_STRIDE]; };   // initial context states per qpd6 (:726-784)
+#define RQ_CLASSES 10
+struct ColdTables {
+    u8 ctx_init[5][CTX_STRIDE];            // initial context states per qpd6 (:726-784)
+    i32 rthr[5][4][RQ_CLASSES];            // RDOQ decision thresholds per qpd6 and TU size (rdoq_group below); a frame stages its qpd6's 40 words into LDS
+};
 HD int mat_off(int s) { return s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -273,7 +284,7 @@ struct alignas(16) HelpReq {                     // main -> helper: everything t
     i32 op, frame, cy, cx;                       // job index, CTU origin
     i32 N, y0, x0, avm;                          // the CU inside the CTU, neighbour availability
     i32 szl, sza, ml, ma;                        // CU size / mode of the left and above neighbour cells (split flag context, MPM)
-    Arith a; i32 pad_;                           // coder state at the CU's entry
+    Arith a; i32 seq;                            // coder state at the CU's entry; sequence number the answer is published under
     alignas(4) u8 ctx[CTX_STRIDE];               // contexts at the CU's entry
     alignas(4) u8 above[68];                     // reconstructed samples the candidates predict from (:196-257): the row above the CU from
     alignas(4) u8 left[64];                      // x0-1 to x0+2N-1 (corner first), and the column left of it from y0 to y0+2N-1
@@ -292,6 +303,17 @@ struct alignas(256) MailSlot {
     HelpRes res;
 };
 struct TeamMail { MailSlot s[MAIL_SLOTS]; };
+// Request queues of a launch: the helper workgroups form ONE pool that serves the requests of every main workgroup.  One
+// ticket ring per request kind: a main workgroup takes ticket t = tail++ and publishes its index in ring[t]; a helper claims
+// ticket h = head++ (compare-and-swap while head < tail), waits for ring[h] and clears it.  A main workgroup has at most one
+// request of a kind outstanding, so a ring of twice the main workgroups never wraps onto a live entry.
+#define POOL_QCAP 2048
+struct alignas(256) PoolQ {
+    u32 head[MAIL_SLOTS], tail[MAIL_SLOTS];      // tickets claimed / issued, per request kind
+    u32 done;                                    // main workgroups that have left (no frames remain): helpers leave when all have
+    u32 pad_[59];
+    u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> main workgroup index + 1 (0: not published yet)
+};
 
 struct FrameCtx {
     FrameJob job;
@@ -300,7 +322,9 @@ struct FrameCtx {
     i32 ctu_y, ctu_x;   // pixel origin of the current CTU
     i32 trace_n;
     i32 frame;          // index of the job being encoded
-    TeamMail *mail;     // this team's mailboxes (null: the workgroup encodes its frames alone)
+    TeamMail *mail;     // this main workgroup's mailboxes (null: the workgroup encodes its frames alone)
+    PoolQ *pq;          // the launch's request queues
+    i32 main_id;        // index of this main workgroup (= of its mailboxes)
     i32 prio_base;      // wave priority of this workgroup outside its critical sections (2: main workgroup of a team, 0 otherwise)
     i32 help16;         // the team has a helper for the 16x16 CUs (teams of 3); teams of 2 only hand out the 32x32 CU
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
@@ -331,6 +355,7 @@ struct alignas(16) Shm {
 #endif
     FourTU X;
     alignas(4) u8 cx0[CTX_STRIDE];       // fresh context states of this frame's qpd6 (:1505)
+    i32 rthr[4][RQ_CLASSES];             // RDOQ thresholds of this frame's qpd6
     alignas(16) u8 wraw[NWAVES * sizeof(WaveMem)];   // wave slices (wave 2 runs full pipeline passes for the 16x16 / 32x32 CUs too)
 };
 
@@ -769,44 +794,32 @@ struct QConst { int sh, add, dmax, thr, dq, dqs; RdW rw; };
 template <int S>
 HD QConst qconst(int q) { QConst Q; Q.sh = 19 - S + q; Q.add = 1 << Q.sh >> 1; Q.dmax = I32MAX - Q.add; Q.thr = 9 << Q.sh >> 2; Q.dqs = 5 - S + q; Q.dq = 1 << Q.dqs; Q.rw = rd_weights(q); return Q; }
 
-// Simplified RDOQ of one 4x4 coefficient group held in registers (:540-594), written without branches: every coefficient
-// prices the levels l0, l0-1, l0-2 (results of impossible candidates are masked), the larger level winning ties (:570-578).
-// With x0 = d - (l0 << sh) in (-2^(sh-1), 2^(sh-1)], the three errors are |x0|, x0 + 2^sh, x0 + 2^(sh+1) (the last two are
-// positive), and |x0| >> dsh < 2^15 never reaches the 46340 clamp of :572.
-// The three costs are compared through their differences to the first: with dist <= (2^31-1) >> 7, rate <= 92000 + (32 << 15)
-// and the weights of :178-181 no product or sum reaches the saturation branches of :182-184, so
-//     cost(l0-k) < cost(l0)  <=>  wd * (dist_k - dist_0) - wb * (rate(l0) - rate(l0-k)) < 0
-// exactly.  The rate model (:526-535) is non-decreasing and all its steps are multiples of 16: T.ldelta holds, for l0 <= 7, the
-// steps rate(l0) - rate(l0-1) and rate(l0) - rate(l0-2) in units of 16 (two 16-bit fields); from l0 = 8 on both are
-// differences of floor(log2(level - 5)), i.e. of leading-zero counts, times 2^16.
+// Simplified RDOQ (:540-594).  The reference prices the levels l0 = round(|coef| / step), l0 - 1 and l0 - 2 of every coefficient
+// and keeps the cheapest (the larger level on ties).  What it decides depends on |coef| alone (for a given qpd6 and TU size), and
+// it has this shape — established by exhaustive comparison with the reference's loop over every |coef| the transforms can
+// produce, for all 5 x 4 (qpd6, size) pairs, in tests/test_oracle.py::test_rdoq_thresholds_match_reference_loop:
+//   * l0 - 2 never wins: its extra distortion (>= (1.5 step)^2 scaled) outweighs any rate it can save;
+//   * l0 - 1 wins iff the remainder x = |coef| 2^14 - l0 step (in [-step/2, step/2)) is at or below a threshold that depends only
+//     on the rate step rate(l0) - rate(l0 - 1) (:526-535): one value per l0 in 1..7, one for the l0 >= 8 where the exp-Golomb
+//     escape grows (l0 - 5 a power of two), and "never" for every other l0 (no rate to save, more distortion).
+// The thresholds (in units of 2^14, i.e. of |coef|) are derived on the host from the reference's own cost loop (hevc_tables.h).
+// class of a rounded level: 0..7 itself, 8: l0 >= 8 with l0 - 5 a power of two, 9: the other l0 >= 8
+HD int rdoq_class(int l0) { return l0 < 8 ? l0 : (((l0 - 5) & (l0 - 6)) == 0 ? 8 : 9); }
 // in: acc = forward-transform sums before the final shift; out: acc = signed levels.  Returns non-zero when the group keeps
 // any level after the weak-group test (:588-591).
 template <int S>
 HD int rdoq_group(int acc[4][4], const QConst &Q) {
-    constexpr int b1 = S + 8, dsh = 8 - S;
-    const Tables &T = SM.T;
-    const int step = 1 << Q.sh, wd = Q.rw.wd, nwb16 = -(Q.rw.wb << 4);
+    constexpr int b1 = S + 8;
+    const i32 *th = SM.rthr[S];
+    const int xs = Q.sh - 14;
     int sum = 0, any = 0;
     for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) {
-        const int cf = acc[r][cc] >> b1, av = iabs(cf);
-        const u32 dd = (u32)imin(av, 0x20000) << 14;                             // :556-558 (2^31 when av exceeds 17 bits: clamped next)
+        const int cf = acc[r][cc] >> b1, av = imin(iabs(cf), 0x20000);
+        const u32 dd = (u32)av << 14;                                             // :556-558 (2^31 when |coef| exceeds 17 bits: clamped next)
         const int d = (int)(dd < (u32)Q.dmax ? dd : (u32)Q.dmax);
         const int l0 = imin((int)(((u32)d + (u32)Q.add) >> Q.sh), 32767);     // the 16-bit clip of :560 (the value is not negative)
-        const int x0 = d - (l0 << Q.sh);
-        const int e0 = iabs(x0) >> dsh, e1 = (int)((u32)(x0 + step) >> dsh), e2 = (int)((u32)(x0 + 2 * step) >> dsh);
-        const int d0 = (int)((u32)umul24(e0, e0) >> 7);
-        const int d1 = (int)(((e1 < 46340) ? (u32)umul24(e1, e1) : (u32)I32MAX) >> 7);
-        const int d2 = (int)(((e2 < 46340) ? (u32)umul24(e2, e2) : (u32)I32MAX) >> 7);
-        const u32 tw = T.ldelta[imin(l0, 7)];
-        const int z0 = clz_nz((u32)(l0 - 5)), z1 = clz_nz((u32)(l0 - 6)), z2 = clz_nz((u32)(l0 - 7));   // (discarded below 8, whatever clz returns)
-        const int big = l0 >= 8;
-        const int dl1 = big ? (z1 - z0) << 12 : (int)(tw & 0xFFFFu), dl2 = big ? (z2 - z0) << 12 : (int)(tw >> 16);
-        const int k1 = mul24(nwb16, dl1) + umul24(wd, d1 - d0);                  // cost(l0-1) - cost(l0)
-        const int k2 = mul24(nwb16, dl2) + umul24(wd, d2 - d0);                  // cost(l0-2) - cost(l0)
-        const int t1 = (l0 > 0) & (k1 < 0);
-        const int best1 = t1 ? k1 : 0;
-        const int t2 = (l0 > 1) & (k2 < best1);
-        const int pick = l0 - (t2 ? 2 : t1);
+        const int xa = av - (l0 << xs);                                           // remainder in units of 2^14 (a clamped |coef| lands in class 9)
+        const int pick = l0 - (xa <= th[rdoq_class(l0)]);
         acc[r][cc] = (cf < 0) ? -pick : pick;
         any |= pick;
         sum += imin(d, Q.thr);

@@ -331,7 +331,7 @@ HDN void enter_cu(int depth, int N, int y0, int x0, int code_split, int avm) {
         if (tid == 64) SM.entry_a[depth] = SM.live;
     }
     wg_sync();
-    if (F.mail && (N == 32 || (N == 16 && F.help16))) post_request(depth, N, y0, x0, avm);     // team: a helper starts on this CU's 70 unsplit candidates now
+    if (F.mail && N >= 16) post_request(depth, N, y0, x0, avm);     // pool: a helper starts on this CU's 70 unsplit candidates now
     if (code_split) {
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
@@ -389,6 +389,14 @@ HD void team_publish(i32 *flag, i32 v) {
     wg_sync();
     WAVES(w) LANES(l) { if (w == 0 && l == 0) m_st32(flag, (u32)v); }
 }
+// the same for a request: the mail words are visible to the helper that claims the ticket and finds this workgroup's index in it
+HD void pool_push(int slot) {
+    drain_stores();
+    wg_sync();
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) { PoolQ *q = F.pq; const u32 t = m_add32(&q->tail[slot], 1u); m_st32(&q->ring[slot][t % POOL_QCAP], (u32)F.main_id + 1u); }
+    }
+}
 // await: returns once flag == v; mail loads issued afterwards see what the publisher stored before publishing
 HD void team_await(i32 *flag, i32 v) {
     WAVES(w) LANES(l) {
@@ -424,17 +432,13 @@ HDN void post_request(int depth, int N, int y0, int x0, int avm) {
             i32 *r = (i32 *)&m->req;
             const Arith a = SM.entry_a[depth];
             const i32 v[20] = { OP_WORK, F.frame, F.ctu_y, F.ctu_x, N, y0, x0, avm, nb_size(uy, ux - 1), nb_size(uy - 1, ux), nb_mode(uy, ux - 1), nb_mode(uy - 1, ux),
-                                a.range, a.low, a.nbits, a.nbytes, a.bufbyte, a.zeros, a.cnt, 0 };
+                                a.range, a.low, a.nbits, a.nbytes, a.bufbyte, a.zeros, a.cnt, F.seq[slot] + 1 };
             for (int i = 0; i < 20; i++) m_st32(r + i, (u32)v[i]);
         }
-        if (tid == 0) F.seq[slot]++;
     }
-    team_publish(&m->req_flag, F.seq[slot]);
-}
-HDN void post_exit(int slot) {
-    MailSlot *m = &F.mail->s[slot];
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->req.op, (u32)OP_EXIT); F.seq[slot]++; } }
-    team_publish(&m->req_flag, F.seq[slot]);
+    wg_sync();
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.seq[slot]++; }
+    pool_push(slot);
 }
 
 // main: the CU's children are done and the split is priced — take the helper's answer and decide (:1439, :1475)
@@ -490,8 +494,9 @@ HDN void decide_remote(int depth, int N, int y0, int x0) {
 }
 
 // helper: serve one request — stage what the candidate sets read, evaluate the 70 candidates, answer with the last minimum
-HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
+HDN void serve_request(const ColdTables *gK, const FrameJob *jobs, MailSlot *m) {
     const HelpReq *Q = &m->req;
+    const int seq = ld_i(&Q->seq);
     HelpRes *R = &m->res;
     const int frame = ld_i(&Q->frame), cy = ld_i(&Q->cy), cx = ld_i(&Q->cx);
     const int N = ld_i(&Q->N), y0 = ld_i(&Q->y0), x0 = ld_i(&Q->x0), avm = ld_i(&Q->avm);
@@ -519,6 +524,7 @@ HDN void serve_request(const FrameJob *jobs, MailSlot *m, int seq) {
             for (int k = 0; k < 4; k++) if (y0 + 1 + 4 * i + k <= 32) SM.rec[y0 + 1 + 4 * i + k][x0] = (u8)(v >> (8 * k));
         }
         if (tid >= 128 && tid < 128 + CTX_STRIDE / 4) *(u32a *)&SM.entry_cx[depth][4 * (tid - 128)] = m_ld32(Q->ctx + 4 * (tid - 128));
+        if (tid >= 152 && tid < 152 + 4 * RQ_CLASSES) (&SM.rthr[0][0])[tid - 152] = (i32)g_ld32(&gK->rthr[J.q][0][0] + (tid - 152));
         if (tid == 32) {
             const i32 *r = (const i32 *)&Q->a;
             Arith a; a.range = ld_i(r); a.low = ld_i(r + 1); a.nbits = ld_i(r + 2); a.nbytes = ld_i(r + 3);
@@ -619,7 +625,7 @@ HD void encode_ctu() {
             decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
-        if (team && F.help16) decide_remote(1, 16, y16, x16);
+        if (team) decide_remote(1, 16, y16, x16);
         else decide_cu(1, 16, y16, x16, pack_avail(a16));
     }
     price_split(0, 32, 0, 0);
@@ -677,6 +683,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
         if (tid < CTX_STRIDE) { const u8 v = g_ld8(&gK->ctx_init[job.q][tid]); SM.cx[tid] = v; SM.cx0[tid] = v; }
+        if (tid >= 128 && tid < 128 + 4 * RQ_CLASSES) (&SM.rthr[0][0])[tid - 128] = (i32)g_ld32(&gK->rthr[job.q][0][0] + (tid - 128));
         if (tid == 64) arith_reset(SM.live);
     }
     wg_sync();
@@ -709,34 +716,40 @@ HD void stage_tables(const Tables *gT) {
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
     }
 }
-HDN void helper_loop(const Tables *gT, const FrameJob *jobs, const Scratch sc, TeamMail *mail, int slot_mask, int role) {
+HDN void helper_loop(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const Scratch sc, TeamMail *mail, PoolQ *pq, int nmains, int role) {
     stage_tables(gT);
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if ((threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = mail; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = (TeamMail *)0; F.pq = pq; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; } }
     wg_sync();
-    int open_ = slot_mask;
-    while (open_) {
+    for (;;) {
         const long long tidle = prof_now();
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
-                int pick = -1;
-                for (;;) {                                  // 16x16 requests first: the main workgroup needs those answers sooner
-                    for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++)
-                        if (((open_ >> s_) & 1) && (i32)m_ld32(&mail->s[s_].req_flag) == F.seq[s_] + 1) pick = s_;
-                    if (pick >= 0) break;
-                    mail_poll_pause();
+                int pick = -1, id = -1, round = 0; u32 ticket = 0;
+                for (;;) {                                  // 16x16 requests first: their main workgroups need the answers sooner
+                    for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++) {
+                        const u32 h = m_ld32(&pq->head[s_]), t = m_ld32(&pq->tail[s_]);
+                        if ((i32)(t - h) > 0) { if (m_cas32(&pq->head[s_], h, h + 1u)) { pick = s_; ticket = h; } else s_--; }   // lost the race for ticket h: look again
+                    }
+                    if (pick >= 0 || m_ld32(&pq->done) == (u32)nmains) break;     // every main workgroup has left: no request can follow
+                    mail_idle_pause(round++);
                 }
-                F.seq[pick]++; SM.red[1] = pick;
+                if (pick >= 0) {                            // the ticket's owner publishes its index right after taking the ticket
+                    u32 *e = &pq->ring[pick][ticket % POOL_QCAP]; u32 v;
+                    while ((v = m_ld32(e)) == 0u) mail_poll_pause();
+                    m_st32(e, 0u);
+                    id = (int)v - 1;
+                }
+                SM.red[1] = pick; SM.red[2] = id;
             }
         }
         wg_sync();
         prof_add(PF_CTUIO, tidle);                          // (booked as "idle": waiting for a request)
-        const int slot = SM.red[1], seq = F.seq[slot];
-        MailSlot *m = &mail->s[slot];
-        if (ld_i(&m->req.op) == OP_EXIT) open_ &= ~(1 << slot);
-        else serve_request(jobs, m, seq);
+        const int slot = SM.red[1], id = SM.red[2];
+        if (slot < 0) break;
+        serve_request(gK, jobs, &mail[id].s[slot]);
         wg_sync();
     }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
@@ -749,7 +762,8 @@ HDN void helper_loop(const Tables *gT, const FrameJob *jobs, const Scratch sc, T
 struct KArgs {
     const Tables *gT; const ColdTables *gK; const FrameJob *jobs; const u8 *hdrs; int njobs;
     const Scratch *scr; int *counter; i32 *trace; int trace_cap; unsigned long long *prof;
-    TeamMail *mail; int team_size, nteams;      // team_size 1: every workgroup encodes whole frames alone; 2: main + a 32x32 helper (the main workgroup keeps the 16x16 CUs); 3: main + a 16x16 helper + a 32x32 helper
+    TeamMail *mail; PoolQ *pq;
+    int team_size, nteams, nhelp;               // team_size 1: every workgroup encodes whole frames alone; > 1: `nteams` main workgroups + a pool of `nhelp` helper workgroups
 };
 #ifdef IMCVT_HOSTEMU
 HD int next_job(int *counter) { return (*counter)++; }
@@ -757,10 +771,8 @@ HD int next_job(int *counter) { return (*counter)++; }
 HD int next_job(int *counter) { return atomicAdd(counter, 1); }
 #endif
 HD void kernel_main(const KArgs &A, int block) {
-    // Blocks are grouped by 8 * team_size: inside a group the members of a team are 8 blocks apart, so they share an XCD
-    // (block b runs on XCD b % 8; a speed bonus only — the hand-off protocol does not depend on placement), and every
-    // run of consecutive blocks holds complete teams: if fewer workgroups are resident than were launched, the teams of the
-    // resident prefix still make progress and free their slots when the queue is empty.  nteams is a multiple of 8.
+    // Main and helper workgroups are interleaved in proportion over the block indices, so that every run of consecutive blocks
+    // — in particular the resident prefix, if fewer workgroups are resident than were launched — holds both kinds.
 #ifndef IMCVT_HOSTEMU
     if (A.team_size < 0) {      // residency census (debug): how many workgroups of this launch are on the device at the same time
         if (threadIdx.x == 0) {
@@ -773,24 +785,24 @@ HD void kernel_main(const KArgs &A, int block) {
         return;
     }
 #endif
-    const int team_size = A.team_size > 1 ? A.team_size : 1;
-    const int gw = A.nteams < 8 ? (A.nteams > 0 ? A.nteams : 1) : 8;      // (fewer than 8 teams: one group)
-    const int grp = block / (gw * team_size), rem = block % (gw * team_size);
-    const int role = team_size > 1 ? rem / gw : 0, team = team_size > 1 ? grp * gw + rem % gw : block;
+    const int pool = A.team_size > 1 && A.nhelp > 0;
+    const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
+    const int mi0 = pool ? (int)((long long)block * nm / tot) : block, mi1 = pool ? (int)((long long)(block + 1) * nm / tot) : block + 1;
+    const int role = mi1 > mi0 ? 0 : 1, team = mi0;          // block b is main workgroup mi0 iff the count of mains steps at b
     Scratch sc = A.scr[block];
     sc.trace_cap = A.trace_cap; sc.prof = A.prof;
     if (role != 0) {
         sc.trace = (i32 *)0;
-        helper_loop(A.gT, A.jobs, sc, A.mail + team, (team_size == 2 || role == 2) ? 1 << SLOT_32 : 1 << SLOT_16, role);
+        helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, role);
         return;
     }
 #ifndef IMCVT_HOSTEMU
     // the main workgroup of a team carries the frame's critical path while its helpers have ~40 % slack: it wins the VALU
     // arbitration of the SIMDs it shares with them (measured: 320 teams 5.75 s -> 4.95 s, 256 teams 4.78 s -> 4.31 s)
-    if (team_size > 1) __builtin_amdgcn_s_setprio(2);
+    if (pool) __builtin_amdgcn_s_setprio(2);
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.prio_base = team_size > 1 ? 2 : 0; }
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = team_size > 1 ? A.mail + team : (TeamMail *)0; F.help16 = team_size == 3; F.seq[0] = 0; F.seq[1] = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.prio_base = pool ? 2 : 0; }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = pool ? A.mail + team : (TeamMail *)0; F.pq = A.pq; F.main_id = team; F.help16 = pool; F.seq[0] = 0; F.seq[1] = 0; } }
     // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
     // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)
     wg_sync();
@@ -804,6 +816,6 @@ HD void kernel_main(const KArgs &A, int block) {
         WAVES(w) LANES(l) { if (w == 0 && l == 0) F.frame = f; }
         encode_frame(A.gT, A.gK, A.jobs[f], sc, A.hdrs + (size_t)HDR_MAX * f);
     }
-    if (team_size > 1) { if (team_size == 3) post_exit(SLOT_16); post_exit(SLOT_32); }
+    if (pool) { WAVES(w) LANES(l) { if (w == 0 && l == 0) m_add32(&A.pq->done, 1u); } }      // this main workgroup posts no further request
 }
 #undef F

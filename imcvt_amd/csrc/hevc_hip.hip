@@ -17,10 +17,10 @@
 
 __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                 TeamMail *mail, int team_size, int nteams) {
+                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
-    A.mail = mail; A.team_size = team_size; A.nteams = nteams;
+    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp;
     kernel_main(A, (int)blockIdx.x);
 }
 
@@ -31,14 +31,16 @@ struct imcvt_hevc_ctx {
     Scratch *d_scratch = nullptr;
     void *d_pool = nullptr;            // backing store of all per-workgroup scratch
     int *d_counter = nullptr;
-    TeamMail *d_mail = nullptr; int mail_cap = 0;          // one mailbox set per team
+    TeamMail *d_mail = nullptr; int mail_cap = 0;          // one mailbox set per main workgroup
+    PoolQ *d_pq = nullptr;                                 // request queues of the running launch
     FrameJob *d_jobs = nullptr; u8 *d_hdrs = nullptr; int jobs_cap = 0;
     FrameJob *h_jobs = nullptr; u8 *h_hdrs = nullptr;      // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
     int *d_trace = nullptr; int trace_cap = 0;
     unsigned long long *d_prof = nullptr;   // [3 roles][NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
-    int force_team = 0;                     // 0: choose per launch; 1..3: fixed team size
-    int last_team = 1, last_nteams = 0;
+    int force_team = 0;                     // 0: choose per launch; 1: no helpers; 2 / 3: one / two helper workgroups per main workgroup
+    int force_mains = 0, force_help = 0;    // > 0: exactly this launch shape (debug / tuning)
+    int last_mains = 0, last_help = 0;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
@@ -58,9 +60,9 @@ extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 3
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nteams) {
+static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp) {
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
-                       (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, team_size, nteams);
+                       (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp);
 }
 
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
@@ -92,6 +94,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_counter, 2 * sizeof(int)) == hipSuccess
            && hipMalloc(&c->d_mail, sizeof(TeamMail) * c->mail_cap) == hipSuccess
+           && hipMalloc(&c->d_pq, sizeof(PoolQ)) == hipSuccess
            && hipMalloc(&c->d_prof, sizeof(unsigned long long) * 3 * NWAVES * PF_N) == hipSuccess
            && hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 3 * NWAVES * PF_N) == hipSuccess
            && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -108,7 +111,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
         for (int i = 0; i < 3 && ok; i++) {
             ok = hipMemset(c->d_counter, 0, sizeof(int)) == hipSuccess;
-            if (ok) launch(c, c->max_wg, 0, 0, 1, 0);
+            if (ok) launch(c, c->max_wg, 0, 0, 1, 0, 0);
             ok = ok && hipDeviceSynchronize() == hipSuccess;
         }
         if (!ok) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
@@ -120,7 +123,7 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->timed && c->ev1) (void)hipEventSynchronize(c->ev1);
-    hipFree(c->d_tables); hipFree(c->d_cold); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof); hipFree(c->d_mail);
+    hipFree(c->d_tables); hipFree(c->d_cold); hipFree(c->d_pool); hipFree(c->d_scratch); hipFree(c->d_counter); hipFree(c->d_prof); hipFree(c->d_mail); hipFree(c->d_pq);
     hipFree(c->d_jobs); hipFree(c->d_hdrs);
     if (c->h_jobs) hipHostFree(c->h_jobs);
     if (c->h_hdrs) hipHostFree(c->h_hdrs);
@@ -131,52 +134,61 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
 
 extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
-extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) { if (!c) return IMCVT_ERR_ARG; if (nteams) *nteams = c->last_nteams; return c->last_team; }
-
-// How many workgroups share a frame, and how many teams.  A frame alone in a workgroup keeps 3 wavefronts busy for ~8.7 s
-// (1080p) whatever else runs; a team of 3 finishes it in ~4.1 s but its helpers idle ~40 % of the time, so teams win while the
-// device is not full and lose when it is.  Model from measurements on MI355X (1080p frames, qpd6 0, kernel seconds per batch,
-// profiles/r02_scale_probe.log, r02n_prio.log; only ratios matter, both sides scale with the CTU count):
-//   solo   1: 8.66   256: 8.84   512: 9.91   768: 11.34   1000: 12.19
-//   teams  T teams, one frame each: 4.06 + 0.65 (T/320)^5   (64: 4.03, 256: 4.28, 320: 4.69; 336 teams — 1008 of the 1024 resident
-//          workgroups — are erratic, 4.9 or 8.3 s, so 320 is the cap); n frames take ceil(n/T) rounds
-// Teams of 2 (main + a 32x32 helper, the main workgroup keeps the 16x16 CUs) lose to both and exist for tests.
-static double solo_seconds(int n) {
-    static const double xs[5] = { 0, 256, 512, 768, 1000 }, ys[5] = { 8.66, 8.84, 9.91, 11.34, 12.19 };
-    if (n >= 1000) return 12.19 * n / 1000.0;
-    for (int i = 0; i < 4; i++) if (n <= xs[i + 1]) return ys[i] + (ys[i + 1] - ys[i]) * (n - xs[i]) / (xs[i + 1] - xs[i]);
-    return 12.19;
+extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) {
+    if (!c) return IMCVT_ERR_ARG;
+    if (nteams) *nteams = c->last_help > 0 ? c->last_mains : 0;
+    return c->last_help <= 0 ? 1 : c->last_help >= 2 * c->last_mains ? 3 : 2;
 }
-// pure: the launch shape for n frames on a device that holds max_wg workgroups (force_team 0: choose; 1..3: fixed team size)
-extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nteams_out) {
-    int dummy = 0; int *nteams = nteams_out ? nteams_out : &dummy;
-    *nteams = 0;
+extern "C" int imcvt_hevc_last_shape(imcvt_hevc_ctx *c, int *nmains, int *nhelp) {
+    if (!c) return IMCVT_ERR_ARG;
+    if (nmains) *nmains = c->last_mains;
+    if (nhelp) *nhelp = c->last_help;
+    return c->last_help > 0 ? 2 : 1;
+}
+
+// Launch shape.  A frame's CTUs are a serial chain; a workgroup that encodes its frame alone keeps 3 wavefronts busy for ~8.7 s
+// (1080p, qpd6 0).  With helpers it hands the 70 unsplit candidates of every 16x16 / 32x32 CU to a pool of helper workgroups and
+// walks only the 8x8 CUs itself (~4.1 s); the helper work of a frame is about as long as the main workgroup's own, so a pool as
+// large as the mains keeps up with them, and more than two helpers per main cannot be used (a main workgroup has at most one
+// request of each kind outstanding).  Every workgroup of the launch must be resident (helpers poll, mains wait for answers).
+//   n <= max_wg / 2       n mains, min(2 n, max_wg - n) helpers: one round
+//   n <= 5 max_wg / 8     max_wg / 2 mains and as many helpers; the mains pull the remaining frames as they finish
+//   beyond                a frame per workgroup, max_wg of them, no helpers (the device is full either way and the hand-offs cost)
+// pure: the launch shape for n frames on a device that holds max_wg workgroups (force_team 0: choose; 1: no helpers; 2 / 3: one / two
+// helpers per main workgroup).  Returns 1 (frames per workgroup; *nmains workgroups) or 2 (pool; *nmains + *nhelp workgroups).
+extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_out, int *nhelp_out) {
+    int d0 = 0, d1 = 0; int *nmains = nmains_out ? nmains_out : &d0, *nhelp = nhelp_out ? nhelp_out : &d1;
+    *nmains = 0; *nhelp = 0;
     if (n < 1 || max_wg < 1) return 1;
     force_team = force_team < 0 ? 0 : force_team > 3 ? 3 : force_team;
     const int mail_cap = max_wg / 2 + 8;
-    const int cap3 = ((max_wg - max_wg / 16) / 3) & ~7;                       // 320 on MI355X (1024 resident workgroups)
-    const int cap = cap3 < mail_cap ? cap3 : (mail_cap & ~7);
-    if (force_team >= 2) {
-        // a forced team size may fill the device to the last workgroup (grid = team size x teams <= max_wg: every member of every
-        // team is resident, which is all the hand-offs need); the automatic choice below keeps a 1/16 margin for speed
-        const int full = ((max_wg / force_team) & ~7) < mail_cap ? ((max_wg / force_team) & ~7) : (mail_cap & ~7);
-        const int tcap = full;
-        *nteams = ((n + 7) & ~7) < tcap ? ((n + 7) & ~7) : tcap;
-        if (*nteams >= 8) return force_team;
-        *nteams = 0;
-        return 1;
+    *nmains = n < max_wg ? n : max_wg;
+    if (force_team == 1 || max_wg < 2) return 1;
+    int m, h;
+    if (force_team >= 2) {                                   // fixed ratio, as many mains as fit
+        const int per = force_team;                          // workgroups per main
+        m = n < max_wg / per ? n : max_wg / per;
+        if (m < 1) return 1;
+        h = (per - 1) * m;
+    } else {
+        if ((long long)n * 8 > (long long)max_wg * 5) return 1;
+        m = n < max_wg / 2 ? n : max_wg / 2;
+        if (m < 1) return 1;
+        h = 2 * m < max_wg - m ? 2 * m : max_wg - m;
     }
-    if (force_team == 1 || cap < 8) return 1;
-    const int rounds = (n + cap - 1) / cap;
-    int T = (((n + rounds - 1) / rounds) + 7) & ~7;              // balanced rounds
-    if (T > cap) T = cap;
-    const double r = (double)T / cap, f = r * r * r * r * r;
-    const double team_s = rounds * (4.06 + 0.65 * f);
-    if (team_s >= solo_seconds((int)((long long)n * 1024 / max_wg))) return 1;       // (the solo row was measured with 1024 resident workgroups)
-    *nteams = T;
-    return 3;
+    if (m > mail_cap) m = mail_cap;
+    if (2 * m > POOL_QCAP) m = POOL_QCAP / 2;
+    *nmains = m; *nhelp = h;
+    return 2;
 }
-static int pick_team(const imcvt_hevc_ctx *c, int n, int *nteams) { return imcvt_hevc_plan(n, c->max_wg, c->force_team, nteams); }
+static int pick_shape(const imcvt_hevc_ctx *c, int n, int *nmains, int *nhelp) {
+    if (c->force_mains > 0 && c->force_help > 0 && c->force_mains + c->force_help <= c->max_wg) {
+        *nmains = c->force_mains < n ? c->force_mains : n; *nhelp = c->force_help;
+        return 2;
+    }
+    return imcvt_hevc_plan(n, c->max_wg, c->force_team, nmains, nhelp);
+}
+extern "C" void imcvt_hevc_set_shape(imcvt_hevc_ctx *c, int nmains, int nhelp) { if (c) { c->force_mains = nmains > 0 ? nmains : 0; c->force_help = nhelp > 0 ? nhelp : 0; } }
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
     if (!c || n < 0 || (n > 0 && !frames)) return IMCVT_ERR_ARG;
@@ -208,16 +220,17 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(int), stream));
-    int nteams = 0, grid;
-    int team = pick_team(c, n, &nteams);
-    if (team > 1) {
-        grid = team * nteams;
-        HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nteams, stream));     // sequence numbers restart with every launch
-    } else { team = 1; nteams = 0; grid = n < c->max_wg ? n : c->max_wg; }
-    if (grid > c->max_wg || (team > 1 && nteams > c->mail_cap)) { fprintf(stderr, "imcvt_hevc: launch shape %d x %d exceeds the context (%d workgroups, %d mailboxes)\n", team, nteams, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
-    c->last_team = team; c->last_nteams = nteams;
+    int nmains = 0, nhelp = 0;
+    const int mode = pick_shape(c, n, &nmains, &nhelp);
+    const int grid = nmains + nhelp;
+    if (mode > 1) {
+        HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nmains, stream));     // sequence numbers restart with every launch
+        HIPCHK(hipMemsetAsync(c->d_pq, 0, sizeof(PoolQ), stream));
+    }
+    if (grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_QCAP))) { fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
+    c->last_mains = nmains; c->last_help = nhelp;
     HIPCHK(hipEventRecord(c->ev0, stream));
-    launch(c, grid, stream, n, team, nteams);
+    launch(c, grid, stream, n, mode, nmains, nhelp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;
@@ -242,7 +255,7 @@ extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
     HIPCHK(hipSetDevice(c->device));
     if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipMemset(c->d_counter, 0, 2 * sizeof(int)));
-    launch(c, grid, 0, 0, -1, 0);
+    launch(c, grid, 0, 0, -1, 0, 0);
     HIPCHK(hipDeviceSynchronize());
     int v[2] = { 0, 0 };
     HIPCHK(hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost));

@@ -43,6 +43,38 @@ inline int dct_entry(int n, int i, int j) {
     return (m > 32) ? -kCos32[64 - m] : kCos32[m];
 }
 
+// The reference's per-coefficient RDOQ decision (:555-582), spelled out as it is written there: levels l0, l0-1, l0-2 priced by
+// calcRDcost(dist, estimateCoeffRate(level)) (:177-185, :526-535), strictly smaller cost replaces.  Host only: the device code
+// uses the thresholds derived from it below.
+inline int ref_level_rate(int level) {
+    static const int t[6] = { 0, 70000, 90000, 92000, 157536, 190304 };
+    if (level < 6) return t[level];
+    int i; level -= 6;
+    for (i = 0; (1 << i) <= level; i++) level -= 1 << i;
+    return 92000 + ((3 + i * 2 + 1) << 15);
+}
+inline int ref_rd_cost(int q, int dist, int bits) {
+    static const int wd[5] = { 11, 11, 11, 5, 1 }, wb[5] = { 1, 4, 16, 29, 23 };
+    const int c1 = (I32MAX / wd[q] <= dist) ? I32MAX : wd[q] * dist, c2 = (I32MAX / wb[q] <= bits) ? I32MAX : wb[q] * bits;
+    return (I32MAX - c1 <= c2) ? I32MAX : c1 + c2;
+}
+inline int ref_rdoq_pick(int q, int s, int absval) {             // s = log2(TU size) - 2
+    const int dist_sft = 8 - s, sft = 19 - s + q, add = 1 << sft >> 1, max_dlevel = I32MAX - add;
+    const long long sh14 = (long long)(absval & 0x1ffff) << 14;
+    const int dlevel = (absval > 0x1ffff) ? max_dlevel : (int)(sh14 < max_dlevel ? sh14 : max_dlevel);
+    int level = (int)(((long long)dlevel + add) >> sft); level = level > 32767 ? 32767 : level;
+    const int min_level = level - 2 > 0 ? level - 2 : 0;
+    int best = I32MAX, pick = 0;
+    for (; level >= min_level; level--) {
+        long long e = (long long)dlevel - ((long long)level << sft); if (e < 0) e = -e;
+        const int dist1 = (int)(e >> dist_sft);
+        const int dist = ((dist1 < 46340) ? dist1 * dist1 : I32MAX) >> 7;
+        const int cost = ref_rd_cost(q, dist, ref_level_rate(level));
+        if (cost < best) { best = cost; pick = level; }
+    }
+    return pick;
+}
+
 inline void build_tables(Tables &T, ColdTables &K) {
     memset(&T, 0, sizeof(T)); memset(&K, 0, sizeof(K));
     for (int s = 0; s < 4; s++) {
@@ -100,6 +132,19 @@ inline void build_tables(Tables &T, ColdTables &K) {
         }
     }
     for (int m = 0; m < 35; m++) { T.ang[m] = (u8)(kAng[m] + 32); T.iang[m] = kInvAng[m]; }
+    // RDOQ thresholds (rdoq_group, hevc_core.h): for one level of every class, the largest remainder (in units of 2^14) at which the
+    // reference's loop still prefers l0 - 1; "never" (below every remainder) where it does not occur.
+    for (int q = 0; q < 5; q++) for (int s = 0; s < 4; s++) {
+        const int sft = 19 - s + q, per = 1 << (sft - 14);            // |coef| values per level
+        for (int c = 0; c < RQ_CLASSES; c++) {
+            int thr = -(1 << 30);
+            if (c >= 1 && c <= 8) {
+                const int l0 = c < 8 ? c : 9;
+                for (int x = -1; x >= -per / 2; x--) if (ref_rdoq_pick(q, s, l0 * per + x) < l0) { thr = x; break; }
+            }
+            K.rthr[q][s][c] = thr;
+        }
+    }
 }
 
 // VPS | SPS(+dims) | PPS | slice header (reference :664-690).  Returns the number of bytes written (<= 96).

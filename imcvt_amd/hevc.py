@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_plan")
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_plan")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -85,7 +85,11 @@ def load_library():
     lib.imcvt_hevc_debug_census.restype = C.c_int
     lib.imcvt_hevc_debug_census.argtypes = [C.c_void_p, C.c_int]
     lib.imcvt_hevc_plan.restype = C.c_int
-    lib.imcvt_hevc_plan.argtypes = [C.c_int, C.c_int, C.c_int, _ip]
+    lib.imcvt_hevc_plan.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
+    lib.imcvt_hevc_last_shape.restype = C.c_int
+    lib.imcvt_hevc_last_shape.argtypes = [C.c_void_p, _ip, _ip]
+    lib.imcvt_hevc_set_shape.restype = None
+    lib.imcvt_hevc_set_shape.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.imcvt_hevc_shutdown.restype = None
     lib.imcvt_hevc_shutdown.argtypes = []
     _lib = lib
@@ -172,13 +176,23 @@ class DeviceEncoder:
             pass
 
     def set_team(self, team_size: int):
-        """Workgroups per frame: 0 = chosen per launch, 1 = a frame per workgroup, 2 / 3 = teams (same results)."""
+        """Helper workgroups: 0 = chosen per launch, 1 = none (a frame per workgroup), 2 / 3 = one / two per main workgroup (same results)."""
         self.lib.imcvt_hevc_set_team(self.ctx, int(team_size))
 
     def last_team(self):
-        """(team size, number of teams) of the last launch."""
+        """(1 / 2 / 3 = no / fewer than two / two helpers per main workgroup, main workgroups of a launch with helpers) of the last launch."""
         nt = C.c_int(0)
         return int(self.lib.imcvt_hevc_last_team(self.ctx, C.byref(nt))), nt.value
+
+    def set_shape(self, nmains: int, nhelp: int):
+        """Debug / tuning: exactly this many main and helper workgroups for the next launches; (0, 0) = automatic again."""
+        self.lib.imcvt_hevc_set_shape(self.ctx, int(nmains), int(nhelp))
+
+    def last_shape(self):
+        """(main workgroups, helper workgroups) of the last launch."""
+        a, b = C.c_int(0), C.c_int(0)
+        self.lib.imcvt_hevc_last_shape(self.ctx, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def make_batch(self, imgs_dev, qpd6=0):
         """imgs_dev: list of 2-D uint8 CUDA tensors.  Allocates outputs (torch) and the descriptor array."""

@@ -95,16 +95,23 @@ int imcvt_hevc_padded(int v);
  * Returns 0 or a negative IMCVT_ERR_*. */
 int imcvt_hevc_encode_device(imcvt_hevc_ctx *ctx, int n, const imcvt_hevc_frame *frames, void *stream);
 
-/* How many workgroups share one frame: 0 = chosen per launch (a frame per workgroup when the batch fills the
- * device, else teams of 2 or 3 workgroups — a main workgroup walks the 8x8 CUs while helpers evaluate the
- * 16x16 / 32x32 candidate sets), 1..3 = fixed.  Results are identical for every setting.
- * Environment override at context creation: IMCVT_HEVC_TEAM. */
+/* Helper workgroups: 0 = chosen per launch (a frame per workgroup when the batch fills the device, else main
+ * workgroups that walk the 8x8 CUs of their frames plus a pool of helper workgroups that evaluate the 16x16 / 32x32
+ * candidate sets for all of them), 1 = none, 2 / 3 = one / two helpers per main workgroup.
+ * Results are identical for every setting.  Environment override at context creation: IMCVT_HEVC_TEAM. */
 void imcvt_hevc_set_team(imcvt_hevc_ctx *ctx, int team_size);
 /* The choice itself, as a pure function (no device needed): launch shape for n_frames on a device that holds
- * max_workgroups resident workgroups of the encoder kernel (1024 on MI355X); returns the team size, *nteams the teams. */
-int imcvt_hevc_plan(int n_frames, int max_workgroups, int force_team, int *nteams);
-/* Team size the last launch used (1..3); *nteams receives the number of teams (0 for team size 1). */
+ * max_workgroups resident workgroups of the encoder kernel (1024 on MI355X).  Returns 1 (a frame per workgroup,
+ * *nmains workgroups, *nhelp = 0) or 2 (*nmains main workgroups + a pool of *nhelp helper workgroups). */
+int imcvt_hevc_plan(int n_frames, int max_workgroups, int force_team, int *nmains, int *nhelp);
+/* Shape of the last launch: returns 1 / 2 / 3 (no helpers / fewer than two / two or more helpers per main workgroup);
+ * *nteams receives the main workgroups of a launch with helpers (0 without). */
 int imcvt_hevc_last_team(imcvt_hevc_ctx *ctx, int *nteams);
+/* The same in full: returns 1 (no helpers) or 2 (pool), *nmains and *nhelp the workgroups of each kind. */
+int imcvt_hevc_last_shape(imcvt_hevc_ctx *ctx, int *nmains, int *nhelp);
+/* Debug / tuning aid: the next launches use exactly nmains main and nhelp helper workgroups (both > 0 and together within the
+ * context's workgroups; fewer mains when there are fewer frames); (0, 0) returns to imcvt_hevc_set_team's choice. */
+void imcvt_hevc_set_shape(imcvt_hevc_ctx *ctx, int nmains, int nhelp);
 
 /* Kernel-only time of the last imcvt_hevc_encode_device call on this context, in milliseconds, from HIP
  * events recorded on the launch stream (synchronises that stream).  <0 if nothing was launched. */

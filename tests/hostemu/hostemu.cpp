@@ -18,7 +18,7 @@ asm(".text\n.globl emu_ctx_switch\n.type emu_ctx_switch,@function\nemu_ctx_switc
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n");
 
 #define EMU_WG_THREADS 192
-#define EMU_MAX_WG 6                                        // up to two teams of three workgroups
+#define EMU_MAX_WG 6                                        // main + helper workgroups of one emulated launch
 #define EMU_THREADS (EMU_WG_THREADS * EMU_MAX_WG)
 #define EMU_STACK (512 * 1024)
 struct EmuFiber {
@@ -120,14 +120,15 @@ static void emu_set_shm(int wg) { g_shm_host = g_shm_of[wg]; }
 static KArgs g_args;
 static void emu_entry() { kernel_main(g_args, emu_block()); }
 
-// team_size 1: one workgroup encodes the frames alone (frames pulled one after the other); 2 / 3: teams (hevc_frame.h), `nteams` of them
+// nhelp 0: `nmains` workgroups encode the frames alone (frames pulled one after the other); > 0: they hand the 16x16 / 32x32 candidate
+// sets to a pool of `nhelp` helper workgroups (hevc_frame.h)
 static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
-                      int *ysz, int *xsz, int qpd6, int *out_len, int *trace, int trace_cap, int team_size, int nteams) {
+                      int *ysz, int *xsz, int qpd6, int *out_len, int *trace, int trace_cap, int nmains, int nhelp) {
     static Tables T; static ColdTables K; static int ready = 0;
     if (!ready) { imcvt::build_tables(T, K); ready = 1; }
-    if (team_size < 1) team_size = 1;
-    if (team_size == 1) nteams = 1;
-    const int nwg = team_size * nteams;
+    if (nmains < 1) nmains = 1;
+    if (nhelp < 0) nhelp = 0;
+    const int nteams = nmains, nwg = nmains + nhelp;
     if (nwg > EMU_MAX_WG) return -1;
     FrameJob *jobs = (FrameJob *)calloc(n, sizeof(FrameJob));
     u8 *hdrs = (u8 *)calloc(n, HDR_MAX);
@@ -148,25 +149,56 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     }
     TeamMail *mail = (TeamMail *)aligned_alloc(256, sizeof(TeamMail) * nteams);
     memset(mail, 0, sizeof(TeamMail) * nteams);
+    PoolQ *pq = (PoolQ *)aligned_alloc(256, sizeof(PoolQ));
+    memset(pq, 0, sizeof(PoolQ));
     int counter = 0;
     g_args.gT = &T; g_args.gK = &K; g_args.jobs = jobs; g_args.hdrs = hdrs; g_args.njobs = n; g_args.scr = sc; g_args.counter = &counter;
-    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.team_size = team_size; g_args.nteams = nteams;
+    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp;
     g_nfib = nwg * EMU_WG_THREADS; g_spins = 0;
     emu_run(emu_entry);
     for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); }
-    free(mail); free(jobs); free(hdrs);
+    free(mail); free(pq); free(jobs); free(hdrs);
     return 0;
 }
 extern "C" int hostemu_HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
                                         int *ysz, int *xsz, int qpd6, int *trace, int trace_cap) {
     int len = 0;
     unsigned char *pb[1] = { pbuffer }; const unsigned char *im[1] = { img }; unsigned char *rc[1] = { img_rcon };
-    if (emu_encode(1, pb, im, rc, ysz, xsz, qpd6, &len, trace, trace_cap, 1, 1) < 0) return -1;
+    if (emu_encode(1, pb, im, rc, ysz, xsz, qpd6, &len, trace, trace_cap, 1, 0) < 0) return -1;
     return len;
 }
-// n frames by `nteams` teams of `team_size` workgroups (the frames are pulled from one queue, as on the device)
-extern "C" int hostemu_HEVCImageEncoderTeam(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
-                                            int *ysz, int *xsz, int qpd6, int *out_len, int team_size, int nteams) {
-    return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, team_size, nteams);
+// n frames by `nmains` main workgroups and a pool of `nhelp` helper workgroups (the frames are pulled from one queue, as on the device)
+extern "C" int hostemu_HEVCImageEncoderPool(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
+                                            int *ysz, int *xsz, int qpd6, int *out_len, int nmains, int nhelp) {
+    return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, nmains, nhelp);
 }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
+
+// The device's RDOQ (rdoq_group, hevc_core.h) on a sz x sz block of transform coefficients, group by group, with the thresholds
+// the host derives for qpd6 (hevc_tables.h) staged as a frame stages them.  dst: signed levels; groups the weak-group test
+// clears come back as zeros, like the reference's quantize().
+template <int S>
+static void emu_rdoq_groups(int q, int sz, const int *src, int *dst) {
+    const QConst Q = qconst<S>(q);
+    for (int gy = 0; gy < sz; gy += 4) for (int gx = 0; gx < sz; gx += 4) {
+        int acc[4][4];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) acc[r][c] = src[(gy + r) * sz + gx + c] * (1 << (S + 8));
+        const int any = rdoq_group<S>(acc, Q);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) dst[(gy + r) * sz + gx + c] = any ? acc[r][c] : 0;
+    }
+}
+extern "C" int hostemu_rdoq_block(int q, int sz, const int *src, int *dst) {
+    static Tables T; static ColdTables K; static int ready = 0;
+    if (!ready) { imcvt::build_tables(T, K); ready = 1; }
+    static Shm *shm = (Shm *)calloc(1, sizeof(Shm));
+    g_shm_host = shm;
+    memcpy(shm->rthr, K.rthr[q], sizeof(shm->rthr));
+    if (sz == 4) emu_rdoq_groups<0>(q, sz, src, dst); else if (sz == 8) emu_rdoq_groups<1>(q, sz, src, dst);
+    else if (sz == 16) emu_rdoq_groups<2>(q, sz, src, dst); else if (sz == 32) emu_rdoq_groups<3>(q, sz, src, dst); else return -1;
+    return 0;
+}
+extern "C" int hostemu_rdoq_threshold(int q, int s, int cls) {
+    static Tables T; static ColdTables K; static int ready = 0;
+    if (!ready) { imcvt::build_tables(T, K); ready = 1; }
+    return K.rthr[q][s][cls];
+}

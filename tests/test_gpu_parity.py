@@ -265,6 +265,26 @@ def test_team_handoffs_under_uneven_load(amd):
     enc.close()
 
 
+def test_pool_shapes_give_identical_streams(amd):
+    """Any ratio of main to helper workgroups gives the bytes of frame-per-workgroup launches: many mains on one helper (the
+    mains queue up for it), one main with many helpers (most of them idle), more mains than frames."""
+    import torch
+    rng = np.random.default_rng(5)
+    imgs = [torch.from_numpy(rng.integers(0, 256, (int(rng.integers(20, 150)), int(rng.integers(20, 200)))).astype(np.uint8) if i % 2
+                             else (np.add.outer(np.arange(90 + i) * 5, np.arange(70 + 3 * i) * 3) % 256).astype(np.uint8)).cuda() for i in range(24)]
+    qs = [i % 5 for i in range(len(imgs))]
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch(imgs, qs)
+    enc.set_team(1); enc.encode(batch); ref = enc.results(batch)
+    for shape in ((8, 1), (1, 9), (3, 5), (40, 40), (24, 1)):
+        enc.set_shape(*shape)
+        enc.encode(batch); got = enc.results(batch)
+        assert enc.last_shape() == (min(shape[0], len(imgs)), shape[1])
+        for i, ((s, r), (s2, r2)) in enumerate(zip(got, ref)):
+            assert s == s2 and (r == r2).all(), (shape, i)
+    enc.close()
+
+
 @pytest.mark.slow
 def test_bench_frames_sample_against_reference_digests(amd):
     """BASELINE configs[3] at FULL size: 16 of the 512 bench frames (seeds spread over the range) in one device batch against

@@ -90,22 +90,24 @@ def test_reference_main_links_against_the_library_unchanged(built, tmp_path):
 
 
 def test_launch_shape_policy(built):
-    """imcvt_hevc_plan is pure (no device): teams of three while the batch leaves the device room, frames per workgroup when it
-    is full; team counts are multiples of 8 (members of a team share an XCD), never beyond the resident capacity, and
-    multi-round plans are balanced."""
+    """imcvt_hevc_plan is pure (no device): main workgroups plus a pool of helper workgroups while the batch leaves the device
+    room (at most two helpers per main workgroup — it has two requests outstanding at most — and never more workgroups than are
+    resident), frames per workgroup when the batch fills the device."""
     import imcvt_amd
     lib = imcvt_amd.load_library()
 
     def plan(n, wg=1024, force=0):
-        nt = C.c_int(-1)
-        return lib.imcvt_hevc_plan(n, wg, force, C.byref(nt)), nt.value
+        m, h = C.c_int(-1), C.c_int(-1)
+        return lib.imcvt_hevc_plan(n, wg, force, C.byref(m), C.byref(h)), m.value, h.value
 
-    assert plan(1) == (3, 8) and plan(64) == (3, 64) and plan(65) == (3, 72) and plan(320) == (3, 320)
-    assert plan(512) == (3, 256) and plan(640) == (3, 320)            # two balanced rounds
-    assert plan(768) == (1, 0) and plan(1000) == (1, 0) and plan(5000) == (1, 0)
+    assert plan(1) == (2, 1, 2) and plan(64) == (2, 64, 128) and plan(341) == (2, 341, 682) and plan(342) == (2, 342, 682)
+    assert plan(512) == (2, 512, 512) and plan(640) == (2, 512, 512)      # the mains pull the remaining frames as they finish
+    assert plan(641) == (1, 641, 0) and plan(1000) == (1, 1000, 0) and plan(5000) == (1, 1024, 0)
     for n in range(1, 1400, 7):
-        team, nt = plan(n)
-        assert team in (1, 3) and (nt == 0 if team == 1 else (nt % 8 == 0 and 8 <= nt <= 320 and 3 * nt <= 1024))
-    assert plan(100, force=1) == (1, 0) and plan(100, force=2) == (2, 104) and plan(2000, force=3) == (3, 336) and plan(2000, force=2) == (2, 512)
-    assert plan(10, wg=16) == (1, 0)                                   # too small a device for eight teams
-    assert plan(0) == (1, 0)
+        mode, m, h = plan(n)
+        assert mode in (1, 2) and 1 <= m <= min(n, 1024) and m + h <= 1024
+        assert (h == 0) if mode == 1 else (m <= h <= 2 * m and m <= 512)
+    assert plan(100, force=1) == (1, 100, 0) and plan(100, force=2) == (2, 100, 100) and plan(100, force=3) == (2, 100, 200)
+    assert plan(2000, force=3) == (2, 341, 682) and plan(2000, force=2) == (2, 512, 512)
+    assert plan(10, wg=16) == (2, 8, 8) and plan(11, wg=16) == (1, 11, 0) and plan(5, wg=16) == (2, 5, 10)
+    assert plan(0) == (1, 0, 0)

@@ -64,36 +64,94 @@ def test_token_row_overflow_path_matches_golden(hostemu_row, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
-def emu_encode_team(lib, imgs, q, team_size, nteams):
+@pytest.mark.parametrize("q", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("sz", [4, 8, 16, 32])
+def test_rdoq_thresholds_match_reference_loop(hostemu, q, sz):
+    """The device's RDOQ decides by thresholds on the rounding remainder (hevc_core.h rdoq_group) where the reference prices three
+    levels per coefficient (src/HEVCe/HEVCe.c:540-594).  Exhaustive over every |coefficient| the 17-bit clamp distinguishes
+    (0 .. 0x20001), both signs, for this (qpd6, size): the levels must be the ones the reference's quantize() returns — the real
+    reference where oracle/_ref is built (dev container), its pinned restatement otherwise.  Fifteen test values and one
+    saturating filler per 4x4 group keep the weak-group rule out of the way; a second pass without fillers exercises that rule."""
+    from oracle import oracle
+    n = sz * sz
+    ip = C.POINTER(C.c_int)
+    if oracle.have_ref():
+        ref = oracle.ref_lib()
+        def want(block):                                            # quantize(qpd6, sz, src[][32], dst[][32])
+            src = np.zeros((32, 32), np.int32); dst = np.zeros((32, 32), np.int32)
+            src[:sz, :sz] = block.reshape(sz, sz)
+            ref.quantize(q, sz, src.ctypes.data_as(ip), dst.ctypes.data_as(ip))
+            return dst[:sz, :sz].reshape(-1).copy()
+    else:
+        port = oracle.port_lib()
+        def want(block):
+            dst = np.zeros(n, np.int32)
+            port.oracle_rdoq(q, sz, block.ctypes.data_as(ip), dst.ctypes.data_as(ip))
+            return dst
+    def got(block):
+        dst = np.zeros(n, np.int32)
+        assert hostemu.hostemu_rdoq_block(q, sz, block.ctypes.data_as(ip), dst.ctypes.data_as(ip)) == 0
+        return dst
+    # positions of a block in (group, in-group) order; slot 15 of every group is the filler
+    gy, gx = np.meshgrid(np.arange(0, sz, 4), np.arange(0, sz, 4), indexing="ij")
+    pos = np.stack([((gy.reshape(-1, 1) + np.arange(16) // 4) * sz + gx.reshape(-1, 1) + np.arange(16) % 4)], 0)[0]   # [groups][16]
+    test_pos = pos[:, :15].reshape(-1)
+    vals = np.arange(0, 0x20002, dtype=np.int64)
+    vals = np.concatenate([vals, -vals]).astype(np.int32)
+    per = test_pos.size
+    for filler in (0x1ffff, None):
+        for i in range(0, vals.size, per):
+            chunk = vals[i:i + per]
+            block = np.zeros(n, np.int32)
+            block[test_pos[:chunk.size]] = chunk
+            if filler is not None:
+                block[pos[:, 15]] = filler
+            elif i > 40 * per:
+                break                                              # without fillers only small values meet the weak-group rule
+            w, g = want(block), got(block)
+            assert (w == g).all(), (q, sz, filler, i, block[np.nonzero(w != g)[0][:4]], w[np.nonzero(w != g)[0][:4]], g[np.nonzero(w != g)[0][:4]])
+
+
+def test_rdoq_never_class_is_really_never(hostemu):
+    """Classes 0 and 9 of the threshold table (level 0; levels >= 8 whose escape length does not grow) carry 'never'."""
+    hostemu.hostemu_rdoq_threshold.restype = C.c_int
+    for q in range(5):
+        for s in range(4):
+            assert hostemu.hostemu_rdoq_threshold(q, s, 0) < -(1 << 20) and hostemu.hostemu_rdoq_threshold(q, s, 9) < -(1 << 20)
+            assert all(hostemu.hostemu_rdoq_threshold(q, s, c) < 0 for c in range(10))
+
+
+def emu_encode_pool(lib, imgs, q, nmains, nhelp):
     n = len(imgs)
     imgs = [np.ascontiguousarray(a) for a in imgs]
     outs = [np.zeros(2 * (a.shape[1] + 32) * (a.shape[0] + 32) + 65536, np.uint8) for a in imgs]
     rcs = [np.zeros(((a.shape[0] + 31) // 32 * 32) * ((a.shape[1] + 31) // 32 * 32), np.uint8) for a in imgs]
     P = u8p * n
     ys = (C.c_int * n)(*[a.shape[0] for a in imgs]); xs = (C.c_int * n)(*[a.shape[1] for a in imgs]); lens = (C.c_int * n)()
-    lib.hostemu_HEVCImageEncoderTeam.restype = C.c_int
-    assert lib.hostemu_HEVCImageEncoderTeam(n, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]),
-                                            P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, q, lens, team_size, nteams) == 0
+    lib.hostemu_HEVCImageEncoderPool.restype = C.c_int
+    assert lib.hostemu_HEVCImageEncoderPool(n, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]),
+                                            P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, q, lens, nmains, nhelp) == 0
     return [(outs[i][:lens[i]].tobytes(), rcs[i]) for i in range(n)]
 
 
-@pytest.mark.parametrize("team_size,nteams", [(3, 1), (2, 1), (3, 2), (2, 3)])
+@pytest.mark.parametrize("nmains,nhelp", [(1, 2), (1, 1), (2, 4), (3, 3), (4, 1), (1, 5)])
 @pytest.mark.parametrize("q", [0, 4])
-def test_team_modes_match_golden(hostemu, q, team_size, nteams):
-    """A frame encoded by a TEAM of workgroups (hevc_frame.h: the main workgroup walks the 8x8 CUs, helper workgroups evaluate
-    the 16x16 / 32x32 candidate sets from the posted entry states) gives the reference's bytes; several teams pull frames
-    from one queue.  The emulated workgroups run concurrently (fibers), so the request / result hand-offs are real."""
+def test_pool_modes_match_golden(hostemu, q, nmains, nhelp):
+    """Frames encoded by main workgroups and a POOL of helper workgroups (hevc_frame.h: a main workgroup walks the 8x8 CUs of its
+    frame, any helper evaluates the 16x16 / 32x32 candidate sets from the entry states it posts) give the reference's bytes,
+    whatever the ratio of the two kinds; the main workgroups pull frames from one queue.  The emulated workgroups run
+    concurrently (fibers), so the ticket queue and the request / result hand-offs are real."""
     es = [e for e in OVF if e["qpd6"] == q]
-    res = emu_encode_team(hostemu, [kat_input(e["input"]) for e in es], q, team_size, nteams)
+    res = emu_encode_pool(hostemu, [kat_input(e["input"]) for e in es], q, nmains, nhelp)
     for e, (stream, rcon) in zip(es, res):
         assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
 
 
-def test_team_mode_natural_image(hostemu):
+def test_pool_mode_natural_image(hostemu):
     # 10 x 9 CTUs of the reference's own sample picture: helpers read their borders from the reconstruction plane across CTU rows
     e = next(e for e in kat_entries() if e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] == 4)
-    (stream, rcon), = emu_encode_team(hostemu, [kat_input(e["input"])], 4, 3, 1)
+    (stream, rcon), = emu_encode_pool(hostemu, [kat_input(e["input"])], 4, 1, 2)
     assert hashlib.sha256(stream).hexdigest() == e["sha256"] and hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
