@@ -52,7 +52,9 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD void drain_stores() {}
 #else
   #define HD __device__ __forceinline__
+  #ifndef HDN
   #define HDN __device__ __noinline__
+  #endif
   #define LANES(l) for (int l = (int)(threadIdx.x & 63u), l##_once = 1; l##_once; l##_once = 0)
   #define WAVES(w) for (int w = (int)(threadIdx.x >> 6), w##_once = 1; w##_once; w##_once = 0)
   // LDS traffic of one wavefront is in program order; the fence only stops the compiler (and drains
@@ -108,6 +110,8 @@ HD i16 g_ld16(const i16 *p) { return *p; }
 HD U4 g_ld128(const void *p) { return *(const U4 *)p; }
 HD void g_st128(void *p, const U4 &v) { *(U4 *)p = v; }
 HD u8 *uniform_ptr(u8 *p) { return p; }
+HD int uni_i(int v) { return v; }
+template <class T_> HD T_ *uni_p(T_ *p) { return p; }
 HD int hibit(u32 v) { return 31 - __builtin_clz(v); }
 HD int clz_nz(u32 v) { return v ? __builtin_clz(v) : 32; }
 HD int popc32(u32 v) { return __builtin_popcount(v); }
@@ -130,6 +134,14 @@ HD u8 *uniform_ptr(u8 *p) {
     const u64 v = (u64)p;
     const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
     return (u8 *)(((u64)hi << 32) | lo);
+}
+// arguments of out-of-line functions arrive in vector registers; these are wave-uniform by construction: moved to scalar registers,
+// so that what is computed from them stays scalar and branches on them are scalar branches
+HD int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T_> HD T_ *uni_p(T_ *p) {
+    const u64 v = (u64)p;
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return (T_ *)(((u64)hi << 32) | lo);
 }
 HD int hibit(u32 v) { return 31 - __clz((int)v); }
 HD int clz_nz(u32 v) { return __builtin_clz(v); }          // v != 0 where the result is used
@@ -303,18 +315,23 @@ struct alignas(256) MailSlot {
     HelpRes res;
 };
 struct TeamMail { MailSlot s[MAIL_SLOTS]; };
-// Request queues of a launch: the helper workgroups form ONE pool that serves the requests of every main workgroup.  One
-// ticket ring per request kind: a main workgroup takes ticket t = tail++ and publishes its index in ring[t]; a helper claims
-// ticket h = head++ (compare-and-swap while head < tail), waits for ring[h] and clears it.  A main workgroup has at most one
-// request of a kind outstanding, so a ring of twice the main workgroups never wraps onto a live entry.
-#define POOL_QCAP 2048
-struct alignas(256) PoolQ {
+// Request queues of a launch: the helper workgroups form ONE pool that serves the requests of every main workgroup.  A queue
+// is a ticket ring per request kind: a main workgroup takes ticket t = tail++ and publishes its index in ring[t]; a helper
+// claims ticket h = head++ (compare-and-swap while head < tail), waits for ring[h] and clears it.  A main workgroup has at most
+// one request of a kind outstanding, so a ring of POOL_QCAP entries never wraps onto a live entry.  The queue is cut into
+// POOL_SHARDS shards on their own cache lines (main workgroup i posts to shard i mod POOL_SHARDS; a helper looks at its home
+// shard first and then at one other shard per poll), so that hundreds of polling workgroups do not meet on one line.
+#define POOL_SHARDS 16
+#define POOL_QCAP 256        // per shard and kind: >= 2 x the main workgroups that share a shard (POOL_SHARDS x POOL_QCAP / 2 = 2048 mains)
+struct alignas(256) PoolShard {
     u32 head[MAIL_SLOTS], tail[MAIL_SLOTS];      // tickets claimed / issued, per request kind
-    u32 done;                                    // main workgroups that have left (no frames remain): helpers leave when all have
-    u32 pad_[59];
+    u32 pad_[60];
     u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> main workgroup index + 1 (0: not published yet)
 };
-
+struct alignas(256) PoolQ {
+    u32 done; u32 pad_[63];                      // main workgroups that have left (no frames remain): helpers leave when all have
+    PoolShard sh[POOL_SHARDS];
+};
 struct FrameCtx {
     FrameJob job;
     Scratch sc;
@@ -326,7 +343,8 @@ struct FrameCtx {
     PoolQ *pq;          // the launch's request queues
     i32 main_id;        // index of this main workgroup (= of its mailboxes)
     i32 prio_base;      // wave priority of this workgroup outside its critical sections (2: main workgroup of a team, 0 otherwise)
-    i32 help16;         // the team has a helper for the 16x16 CUs (teams of 3); teams of 2 only hand out the 32x32 CU
+    i32 lim[MAIL_SLOTS];   // a request of this kind is only posted while fewer than this many wait unclaimed in the workgroup's shard (else the CU is evaluated here)
+    i32 posted[3];      // the CU of depth 0 / 1 being walked has a request out
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
 };
 
@@ -609,7 +627,8 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
 #ifndef HDN_EVAL
 #define HDN_EVAL HDN
 #endif
-HDN_BORDER void border_from_tile(int wave, int N, int y0, int x0, int hl, int hbl, int ha, int har) {
+HDN_BORDER void border_from_tile(int wave_, int N_, int y0_, int x0_, int hl_, int hbl_, int ha_, int har_) {
+    const int wave = uni_i(wave_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int hl = uni_i(hl_); const int hbl = uni_i(hbl_); const int ha = uni_i(ha_); const int har = uni_i(har_);
     WaveMem &W = WM(wave);
     Border &b = W.bsh;
     const int n2 = 2 * N;
@@ -709,7 +728,8 @@ HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int ha
     }
     wave_sync();
 }
-HDN_BORDER void border_tu_split(int N, int y0, int x0, int k, int hl, int hbl, int ha, int har, int c_lo, int c_hi) {      // modes c_lo .. c_hi-1
+HDN_BORDER void border_tu_split(int N_, int y0_, int x0_, int k_, int hl_, int hbl_, int ha_, int har_, int c_lo_, int c_hi_) {
+    const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int k = uni_i(k_); const int hl = uni_i(hl_); const int hbl = uni_i(hbl_); const int ha = uni_i(ha_); const int har = uni_i(har_); const int c_lo = uni_i(c_lo_); const int c_hi = uni_i(c_hi_);      // modes c_lo .. c_hi-1
     if (k == 1) border_tu_split_k<1>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
     else if (k == 2) border_tu_split_k<2>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
     else border_tu_split_k<3>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
@@ -1047,6 +1067,82 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
     B.esc = esc;
     return cnt | ((g2 >= 0) ? 1 << 16 : 0);
 }
+// magnitude codes of a group: min(|level|, 3) of scan position n in bits 2n, 2n+1 (built by scan_levels)
+#define MC_LO 0x55555555u
+HD u32 mc_nz(u32 P) { return (P | (P >> 1)) & MC_LO; }        // bit 2n: level n is non-zero
+HD u32 mc_big(u32 P) { return (P >> 1) & MC_LO; }             //          exceeds 1
+HD u32 mc_g2(u32 P) { return P & (P >> 1) & MC_LO; }          //          exceeds 2
+HD u32 mc_of(const Lv16 &L) { u32 P = 0; for (int n = 0; n < 16; n++) P |= (u32)imin(iabs(L.v[n]), 3) << (2 * n); return P; }
+// Part A for a lane-private row (the hot path: pass rows of p1_run_t, lane rows of 4x4 TUs), same tokens as tokg_a<true, true>.
+// The row has room for all of part A (at most 1 + 16 + 8 + 1 + 2 tokens after at most 7 staged ones), so nothing is clamped;
+// a token that does not exist is written where the next existing one will land.  Positions follow from counts instead of a
+// running predicate: the significance flags of scan positions top..0 are consecutive, the greater-1 flags belong to the first
+// min(nnz, 8) set bits of the non-zero mask, walked with clz; contexts of the latter are min(1 + j, 3) until a level above 1
+// was seen and 0 afterwards (:1218-1227).  P = the group's magnitude codes (scan_levels).
+template <int S>
+HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB &B) {
+    const Tables &T = SM.T;
+    const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3;
+    B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
+    tb[cnt] = (u16)(((CX_CSBF + (pat != 0)) << 1) | (nzm != 0));
+    cnt += (!dcg && !has_last);
+    if (nzm == 0 && !dcg) return cnt;
+    {   // significance flags of scan positions top..0 (the last significant position itself is not coded; position 0 is inferred
+        // when nothing else of a group known to be coded is set)
+        const int top = has_last ? hibit(nzm) - 1 : 15;
+        u32 tlo, thi = 0; int base;
+        if (S == 0) { const u64 t = T.c4tab[st]; tlo = (u32)t; thi = (u32)(t >> 32); base = 0; }
+        else { tlo = T.posadd[pat][st]; base = 9 + (S >= 2 ? 12 : 0) + ((S == 1 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); }
+        u16 *const lo = tb + cnt, *const hi = lo + top;
+        UNROLL_FULL
+        for (int n = 15; n >= 0; n--) {
+            const int f = S == 0 ? (int)(((n < 8 ? tlo : thi) >> (4 * (n & 7))) & 15) : (int)((tlo >> (2 * n)) & 3);
+            const int ci = (n == 0 && dcg) ? 0 : base + f;
+            u16 *p = hi - n;
+            p = p < lo ? lo : p;
+            *p = (u16)(((CX_SIG + ci) << 1) | (int)((nzm >> n) & 1));
+        }
+        cnt += top + 1 - ((top >= 0) & !(dcg | ((nzm >> 1) != 0)));
+    }
+    if (nzm == 0) return cnt;
+    const u32 nzs = mc_nz(P), bigs = mc_big(P), g2s = mc_g2(P);
+    const int nnz = popc32(nzm), m8 = imin(nnz, 8);
+    const int set = (dcg ? 0 : 2) + ((cfg & TG_C1Z) != 0);
+    u32 rem = nzs;
+    {   // greater-1 flags of the first 8 non-zero levels
+        const int K = (CX_GT1 + 4 * set) << 1;
+        u16 *const g0 = tb + cnt, *const gend = g0 + m8;
+        int seenbig = 0;
+        UNROLL_FULL
+        for (int j = 0; j < 8; j++) {
+            const int p2 = 31 - clz_nz(rem | 1u);
+            const int bigj = (int)((bigs >> p2) & 1u);
+            u16 *p = g0 + j;
+            p = p > gend ? gend : p;
+            *p = (u16)(K + (seenbig ? 0 : 2 * (j < 2 ? j + 1 : 3)) + bigj);
+            seenbig |= bigj;
+            rem &= (1u << p2) - 1u;
+        }
+        cnt += m8;
+    }
+    const u32 big8 = bigs & (nzs ^ rem);                  // levels above 1 among the first 8 non-zero ones
+    const int anybig = big8 != 0, fb = 31 - clz_nz(big8 | 1u);
+    const int g2 = (int)((g2s >> fb) & 1u) & anybig;     // greater-2 flag of the first of them (:1232-1238)
+    tb[cnt] = (u16)(((CX_GT2 + set) << 1) | g2);
+    cnt += anybig;
+    int signs = 0;
+    UNROLL_FULL
+    for (int n = 15; n >= 0; n--) { const int v = L.v[n]; signs = (signs << (int)((nzs >> (2 * n)) & 1u)) | (int)((u32)v >> 31); }
+    {   // sign bins open the group's bypass run: full chunks leave at once, the rest waits for the remaining-level bins
+        int nb = nnz;
+        tb[cnt] = (u16)tk_chunk_word((signs >> (nb & 7)) >> (nb >= 16 ? 8 : 0) & 0xFF, 8); cnt += nb >= 8;
+        tb[cnt] = (u16)tk_chunk_word(signs & 0xFF, 8); cnt += nb >= 16;
+        nb &= 7;
+        B.run.nb = nb; B.run.acc = (u32)signs & ((1u << nb) - 1u);
+    }
+    B.esc = (nnz > 8) | (popc32(big8) > 1) | g2;
+    return cnt | (anybig << 16);
+}
 // remaining absolute levels of scan positions hi..lo (:1243-1262), appended to the group's bypass run; returns the token count so far.
 // Both binarisations are "l1 ones, a zero, the low m bits of val" (:1150-1167):
 //     r <  3 << rice :  l1 = r >> rice,         m = rice, val = r                                  (at most 7 bins)
@@ -1141,14 +1237,17 @@ HD void ls_end(LaneStream &s, TokW &w, WaveMem &W, int c) {
 }
 
 // the 16 levels of a 4x4 group (raster x[r][c]) in scan order `st`, and their non-zero mask
-HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag) {
+// *mc receives min(|level|, 3) of scan position n in bits 2n, 2n+1 ("magnitude codes": the flags of part A are bit tricks on them)
+HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag, u32 *mc) {
     const int diag[16] = { 0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15 };      // T.incg[0]
-    u32 nzm = 0;
+    u32 nzm = 0, P = 0;
     for (int n = 0; n < 16; n++) {
         const int d = x[diag[n] >> 2][diag[n] & 3];
         const int v = fixed_diag ? d : (st == 0 ? d : st == 1 ? x[n >> 2][n & 3] : x[n & 3][n >> 2]);
         L.v[n] = v; nzm |= (u32)(v != 0) << n;
+        P |= (u32)imin(iabs(v), 3) << (2 * n);
     }
+    *mc = P;
     return nzm;
 }
 
@@ -1202,8 +1301,8 @@ HD void p1_run_4(int wave, const P1Args &P) {
             prof_add(PF_T_GEN, t4); t4 = prof_now();
             const int st = scan_type_of(4, mode);
             if (P.tok) {                                    // the TU's tokens: cbf_luma, last position, the one group
-                Lv16 L; u32 nzm = 0;
-                if (any) nzm = scan_levels(L, x, st, 0);
+                Lv16 L; u32 nzm = 0, mcode = 0;
+                if (any) nzm = scan_levels(L, x, st, 0, &mcode);
                 LaneStream ls;
                 TokW w = ls_begin(ls, W, c, lane_row(W, l), P.tok + (size_t)c * TOK_CAP);
                 tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
@@ -1212,7 +1311,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                     w.n = last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, in >> 2, in & 3));
                     ls_flush(ls, w);                        // <= 7 tokens stay staged: each part below then fits the row
                     TgB B;
-                    w.n = tokg_a<true, true>(w.o, w.n, L, nzm, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
+                    w.n = tokg_a_fast<0>(w.o.tb, w.n, L, nzm, mcode, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
                     if (B.esc) {
                         ls_flush(ls, w);
                         w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B);
@@ -1271,11 +1370,11 @@ HD void p1_run_4(int wave, const P1Args &P) {
 
 // some level among the first 8 non-zero ones (coding order: scan positions 15 .. 0) exceeds 1 — the flag tokg_a reports as
 // "this group ends with c1 == 0"; the next coded group's greater-1 context set depends on it (:1218-1221)
-HD int group_big(const Lv16 &L) {
-    int seen = 0, big = 0;
-    UNROLL_FULL
-    for (int n = 15; n >= 0; n--) { const int mg = iabs(L.v[n]); big |= (mg > 1) & (seen < 8); seen += (mg != 0); }
-    return big;
+// = the highest-placed level above 1 has fewer than 8 non-zero levels before it (in coding order)
+HD int group_big(u32 P) {
+    const u32 bigs = mc_big(P);
+    const int fb = 31 - clz_nz(bigs | 1u);
+    return (bigs != 0) & (popc32(mc_nz(P) >> fb) <= 8);
 }
 // A lane's staged group tokens row[0..c) to tokens o.. of a stream (dst = stream base, 16-byte aligned): dword stores, a
 // 16-bit store at an odd start and for an odd tail.
@@ -1376,8 +1475,8 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 any = rdoq_group<s>(acc, Q);
                 MARK("rdoq");
             }
-            Lv16 L; u32 nzm = 0;
-            if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
+            Lv16 L; u32 nzm = 0, mcode = 0;
+            if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16, &mcode); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
             const u64 cm = P.tok ? wave_ballot(any) : 0;
             uint2 dq[4];                                    // dequantised levels, packed; stored once the token buffer (which lives in res/tmp) is done with
             for (int r4 = 0; r4 < 4; r4++) {
@@ -1402,7 +1501,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 MARK("scan_dequant_cfg");
                 const long long ptk0 = prof_now();
                 // greater-1 context set carry (:1218-1221): needs only the levels, not the tokens
-                const int big = (talk && nzm != 0) ? group_big(L) : 0;
+                const int big = (talk && nzm != 0) ? group_big(mcode) : 0;
                 const u64 bmask = wave_ballot(big);
                 if (above != 0 && ((bmask >> (sb + r + 1 + ctz64(above))) & 1)) cfg |= TG_C1Z;
                 // TU header (cbf_luma, last position) is written by the lane of the last coded group, first in coding order
@@ -1418,7 +1517,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 if (talk) {
                     TokOut o; o.tb = row; o.pos = 0; o.cap = ROWCAP; o.glob = 0;
                     if (seg == 0) { to_put(o, 0, (cbf_ctx << 1) | 0); cg = 1; }
-                    else { TgB B; const int ra = tokg_a<true, true>(o, 0, L, nzm, cfg, B); cg = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, ra & 0xFFFF, L, B), B); }
+                    else { TgB B; const int ra = tokg_a_fast<s>(row, 0, L, nzm, mcode, cfg, B); cg = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, ra & 0xFFFF, L, B), B); }
                 }
                 MARK("group_tokens");
                 prof_add(PF_T_SETUP, ptk0);
@@ -1516,7 +1615,12 @@ HD void p1_run(int wave, const P1Args &P) {
     else if (P.N == 8) p1_run_t<3>(wave, P);
     else p1_run_4(wave, P);
 }
-HDN void p1_run_cold(int wave, const P1Args P) { p1_run(wave, P); }     // the winner's reconstruction: once per CU, kept out of line
+HDN void p1_run_cold(int wave_, const P1Args P_) {
+    P1Args P;
+    P.N = uni_i(P_.N); P.y0 = uni_i(P_.y0); P.x0 = uni_i(P_.x0); P.k = uni_i(P_.k); P.per_mode_border = uni_i(P_.per_mode_border); P.out_kind = uni_i(P_.out_kind);
+    P.only_mode = uni_i(P_.only_mode); P.shape = uni_i(P_.shape); P.tok = uni_p(P_.tok); P.q = uni_i(P_.q); P.own = uni_i(P_.own); P.c_lo = uni_i(P_.c_lo); P.c_hi = uni_i(P_.c_hi);
+    p1_run(uni_i(wave_), P);
+}     // the winner's reconstruction: once per CU, kept out of line
 
 // ---------------------------------------------------------------------------------------------------
 // Stream coding.  One lane codes one candidate's token stream with its own arithmetic coder and context copy;

@@ -10,6 +10,7 @@
 #pragma once
 #include "hevc_core.h"
 
+HD int slot_of(int N) { return N == 32 ? SLOT_32 : SLOT_16; }
 struct Avail { int l, bl, a, ar; };
 HD Avail unpack_avail(int m) { Avail a; a.l = m & 1; a.bl = (m >> 1) & 1; a.a = (m >> 2) & 1; a.ar = (m >> 3) & 1; return a; }
 HD int pack_avail(const Avail &a) { return a.l | a.bl << 1 | a.a << 2 | a.ar << 3; }
@@ -47,7 +48,8 @@ struct P1Item { int own, shape, lo, hi; };
 #define SPL16_1 32
 #endif
 HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? SPL32_0 : SPL32_1) : (shape == 0 ? SPL16_0 : SPL16_1); }   // passes come out balanced over the three waves
-HDN_EVAL void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
+HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int avm_) {
+    const int wave = uni_i(wave_); const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q, h = N / 2, big = N >= 16;
@@ -130,7 +132,8 @@ HDN_EVAL void eval_2Nx2N(int wave, int depth, int N, int y0, int x0, int avm) {
 // Slot NMODE holds the NxN stream ([0..) header, then the four winners' tokens) and, from NXN_KEEP on, the winners' copies.
 #define NXN_KEEP 1024
 #define NXN_KEEP_STRIDE 160
-HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
+HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
+    const int wave = uni_i(wave_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
 #ifndef IMCVT_HOSTEMU
     // the NxN chain is the longest of an 8x8 CU's three candidate sets: its wave wins the VALU arbitration of the SIMD it shares
     // with waves of other workgroups (1024 frames in flight: +3 %)
@@ -237,7 +240,8 @@ HDN_EVAL void eval_NxN(int wave, int y0, int x0, int avm) {
 
 // ---- the winner's reconstruction (only the winner's is ever needed, so candidates do not store theirs): the winning
 // 2Nx2N shape is run once more, writing the tile.  All waves call this; wave 0 works.
-HDN void rebuild_winner(int kind, int mode, int N, int y0, int x0, int avm) {
+HDN void rebuild_winner(int kind_, int mode_, int N_, int y0_, int x0_, int avm_) {
+    const int kind = uni_i(kind_); const int mode = uni_i(mode_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     const Avail av = unpack_avail(avm);
     WAVES(w) {
         if (w == 0) {
@@ -264,7 +268,8 @@ HDN void rebuild_winner(int kind, int mode, int N, int y0, int x0, int avm) {
 
 // ---- one CU after its children (if any) are done: evaluate the unsplit shapes, decide, commit ---------------------
 // All waves call this with identical arguments.
-HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
+HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
+    const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES(w) {
         if (w < 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
@@ -323,7 +328,8 @@ HDN void decide_cu(int depth, int N, int y0, int x0, int avm) {
 
 // snapshot the live coder as the entry state of `depth`, optionally after coding split_cu_flag=1 (:1363-1364, :1403)
 HDN void post_request(int depth, int N, int y0, int x0, int avm);
-HDN void enter_cu(int depth, int N, int y0, int x0, int code_split, int avm) {
+HDN void enter_cu(int depth_, int N_, int y0_, int x0_, int code_split_, int avm_) {
+    const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int code_split = uni_i(code_split_); const int avm = uni_i(avm_);
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
@@ -331,7 +337,17 @@ HDN void enter_cu(int depth, int N, int y0, int x0, int code_split, int avm) {
         if (tid == 64) SM.entry_a[depth] = SM.live;
     }
     wg_sync();
-    if (F.mail && N >= 16) post_request(depth, N, y0, x0, avm);     // pool: a helper starts on this CU's 70 unsplit candidates now
+    if (F.mail && N >= 16) {     // pool: a helper starts on this CU's 70 unsplit candidates now — unless requests already wait unclaimed (every
+        WAVES(w) LANES(l) {      // helper is busy): then this workgroup evaluates the CU itself when it comes back from the children
+            if (w == 0 && l == 0) {
+                const int slot = slot_of(N);
+                const PoolShard *q = &F.pq->sh[F.main_id % POOL_SHARDS];
+                F.posted[depth] = (i32)(m_ld32(&q->tail[slot]) - m_ld32(&q->head[slot])) < F.lim[slot];
+            }
+        }
+        wg_sync();
+        if (F.posted[depth]) post_request(depth, N, y0, x0, avm);
+    }
     if (code_split) {
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
@@ -348,7 +364,8 @@ HDN void enter_cu(int depth, int N, int y0, int x0, int code_split, int avm) {
 }
 
 // cost of keeping the split (:1408-1409): SSE of the children's reconstruction + bits spent since entry
-HDN void price_split(int depth, int N, int y0, int x0) {
+HDN void price_split(int depth_, int N_, int y0_, int x0_) {
+    const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
     WAVES(w) LANES(l) { if (w == 0 && l == 0) SM.red[0] = 0; }
     wg_sync();
     WAVES(w) LANES(l) {
@@ -394,7 +411,7 @@ HD void pool_push(int slot) {
     drain_stores();
     wg_sync();
     WAVES(w) LANES(l) {
-        if (w == 0 && l == 0) { PoolQ *q = F.pq; const u32 t = m_add32(&q->tail[slot], 1u); m_st32(&q->ring[slot][t % POOL_QCAP], (u32)F.main_id + 1u); }
+        if (w == 0 && l == 0) { PoolShard *q = &F.pq->sh[F.main_id % POOL_SHARDS]; const u32 t = m_add32(&q->tail[slot], 1u); m_st32(&q->ring[slot][t % POOL_QCAP], (u32)F.main_id + 1u); }
     }
 }
 // await: returns once flag == v; mail loads issued afterwards see what the publisher stored before publishing
@@ -404,11 +421,11 @@ HD void team_await(i32 *flag, i32 v) {
     }
     wg_sync();
 }
-HD int slot_of(int N) { return N == 32 ? SLOT_32 : SLOT_16; }
 HD int ld_i(const i32 *p) { return (i32)m_ld32(p); }
 
 // main: post the entry state of the CU at (y0,x0,N) — call right after enter_cu's snapshot, before the split flag is coded
-HDN void post_request(int depth, int N, int y0, int x0, int avm) {
+HDN void post_request(int depth_, int N_, int y0_, int x0_, int avm_) {
+    const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     const int slot = slot_of(N);
     MailSlot *m = &F.mail->s[slot];
     const int uy = y0 >> 2, ux = x0 >> 2;
@@ -442,7 +459,8 @@ HDN void post_request(int depth, int N, int y0, int x0, int avm) {
 }
 
 // main: the CU's children are done and the split is priced — take the helper's answer and decide (:1439, :1475)
-HDN void decide_remote(int depth, int N, int y0, int x0) {
+HDN void decide_remote(int depth_, int N_, int y0_, int x0_) {
+    const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
     const int slot = slot_of(N);
     MailSlot *m = &F.mail->s[slot];
     u8 *live_sink = F.job.out + F.out_pos;
@@ -494,7 +512,8 @@ HDN void decide_remote(int depth, int N, int y0, int x0) {
 }
 
 // helper: serve one request — stage what the candidate sets read, evaluate the 70 candidates, answer with the last minimum
-HDN void serve_request(const ColdTables *gK, const FrameJob *jobs, MailSlot *m) {
+HDN void serve_request(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m_) {
+    const ColdTables *const gK = uni_p(gK_); const FrameJob *const jobs = uni_p(jobs_); MailSlot *const m = uni_p(m_);
     const HelpReq *Q = &m->req;
     const int seq = ld_i(&Q->seq);
     HelpRes *R = &m->res;
@@ -625,11 +644,11 @@ HD void encode_ctu() {
             decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
-        if (team) decide_remote(1, 16, y16, x16);
+        if (team && F.posted[1]) decide_remote(1, 16, y16, x16);
         else decide_cu(1, 16, y16, x16, pack_avail(a16));
     }
     price_split(0, 32, 0, 0);
-    if (team) decide_remote(0, 32, 0, 0); else decide_cu(0, 32, 0, 0, pack_avail(a32));
+    if (team && F.posted[0]) decide_remote(0, 32, 0, 0); else decide_cu(0, 32, 0, 0, pack_avail(a32));
 
     // ---- store the reconstruction, end_of_slice_segment_flag, hand the CTU's bytes over (:1625-1630)
     u8 *live_sink = J.out + F.out_pos;
@@ -716,7 +735,8 @@ HD void stage_tables(const Tables *gT) {
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
     }
 }
-HDN void helper_loop(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const Scratch sc, TeamMail *mail, PoolQ *pq, int nmains, int role) {
+HDN void helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int nmains_, int home_, int role_) {
+    const Tables *const gT = uni_p(gT_); const ColdTables *const gK = uni_p(gK_); const FrameJob *const jobs = uni_p(jobs_); TeamMail *const mail = uni_p(mail_); PoolQ *const pq = uni_p(pq_); const int nmains = uni_i(nmains_); const int home = uni_i(home_); const int role = uni_i(role_);
     stage_tables(gT);
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if ((threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
@@ -727,17 +747,21 @@ HDN void helper_loop(const Tables *gT, const ColdTables *gK, const FrameJob *job
         const long long tidle = prof_now();
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
-                int pick = -1, id = -1, round = 0; u32 ticket = 0;
-                for (;;) {                                  // 16x16 requests first: their main workgroups need the answers sooner
-                    for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++) {
-                        const u32 h = m_ld32(&pq->head[s_]), t = m_ld32(&pq->tail[s_]);
-                        if ((i32)(t - h) > 0) { if (m_cas32(&pq->head[s_], h, h + 1u)) { pick = s_; ticket = h; } else s_--; }   // lost the race for ticket h: look again
+                int pick = -1, id = -1, round = 0, shard = home; u32 ticket = 0;
+                for (;;) {                                  // home shard first, then one other shard per round; 16x16 requests before 32x32 ones (their
+                    for (int pass = 0; pass < 2 && pick < 0; pass++) {      // main workgroups need the answers sooner)
+                        shard = pass == 0 ? home : (home + 1 + round % (POOL_SHARDS - 1)) % POOL_SHARDS;
+                        PoolShard *q = &pq->sh[shard];
+                        for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++) {
+                            const u32 h = m_ld32(&q->head[s_]), t = m_ld32(&q->tail[s_]);
+                            if ((i32)(t - h) > 0) { if (m_cas32(&q->head[s_], h, h + 1u)) { pick = s_; ticket = h; } else s_--; }   // lost the race for ticket h: look again
+                        }
                     }
-                    if (pick >= 0 || m_ld32(&pq->done) == (u32)nmains) break;     // every main workgroup has left: no request can follow
+                    if (pick >= 0 || ((round & 3) == 3 && m_ld32(&pq->done) == (u32)nmains)) break;     // every main workgroup has left: no request can follow
                     mail_idle_pause(round++);
                 }
                 if (pick >= 0) {                            // the ticket's owner publishes its index right after taking the ticket
-                    u32 *e = &pq->ring[pick][ticket % POOL_QCAP]; u32 v;
+                    u32 *e = &pq->sh[shard].ring[pick][ticket % POOL_QCAP]; u32 v;
                     while ((v = m_ld32(e)) == 0u) mail_poll_pause();
                     m_st32(e, 0u);
                     id = (int)v - 1;
@@ -763,6 +787,7 @@ struct KArgs {
     const Tables *gT; const ColdTables *gK; const FrameJob *jobs; const u8 *hdrs; int njobs;
     const Scratch *scr; int *counter; i32 *trace; int trace_cap; unsigned long long *prof;
     TeamMail *mail; PoolQ *pq;
+    int lim16, lim32, prio;                     // pool tuning: unclaimed requests per shard beyond which a main workgroup keeps a CU (16x16 / 32x32); wave priority of the main workgroups
     int team_size, nteams, nhelp;               // team_size 1: every workgroup encodes whole frames alone; > 1: `nteams` main workgroups + a pool of `nhelp` helper workgroups
 };
 #ifdef IMCVT_HOSTEMU
@@ -785,6 +810,11 @@ HD void kernel_main(const KArgs &A, int block) {
         return;
     }
 #endif
+#ifndef IMCVT_HOSTEMU
+    // residency diagnostic: counter[2] = workgroups of this launch running now, counter[3] = the most there ever were (imcvt_hevc_last_resident)
+    if (threadIdx.x == 0) atomicMax(A.counter + 3, atomicAdd(A.counter + 2, 1) + 1);
+    struct Leave { int *c; __device__ ~Leave() { if (threadIdx.x == 0) atomicAdd(c + 2, -1); } } leave_{ A.counter };
+#endif
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     const int mi0 = pool ? (int)((long long)block * nm / tot) : block, mi1 = pool ? (int)((long long)(block + 1) * nm / tot) : block + 1;
@@ -793,16 +823,16 @@ HD void kernel_main(const KArgs &A, int block) {
     sc.trace_cap = A.trace_cap; sc.prof = A.prof;
     if (role != 0) {
         sc.trace = (i32 *)0;
-        helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, role);
+        helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, (block - mi0) % POOL_SHARDS, role);
         return;
     }
 #ifndef IMCVT_HOSTEMU
     // the main workgroup of a team carries the frame's critical path while its helpers have ~40 % slack: it wins the VALU
     // arbitration of the SIMDs it shares with them (measured: 320 teams 5.75 s -> 4.95 s, 256 teams 4.78 s -> 4.31 s)
-    if (pool) __builtin_amdgcn_s_setprio(2);
+    if (pool && A.prio >= 2) __builtin_amdgcn_s_setprio(2);
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.prio_base = pool ? 2 : 0; }
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = pool ? A.mail + team : (TeamMail *)0; F.pq = A.pq; F.main_id = team; F.help16 = pool; F.seq[0] = 0; F.seq[1] = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.prio_base = (pool && A.prio >= 2) ? 2 : 0; }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = pool ? A.mail + team : (TeamMail *)0; F.pq = A.pq; F.main_id = team; F.lim[SLOT_16] = A.lim16; F.lim[SLOT_32] = A.lim32; F.posted[0] = 0; F.posted[1] = 0; F.seq[0] = 0; F.seq[1] = 0; } }
     // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
     // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)
     wg_sync();

@@ -17,10 +17,10 @@
 
 __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp) {
+                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int lim16, int lim32, int prio) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
-    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp;
+    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio;
     kernel_main(A, (int)blockIdx.x);
 }
 
@@ -40,6 +40,7 @@ struct imcvt_hevc_ctx {
     unsigned long long *d_prof = nullptr;   // [3 roles][NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
     int force_team = 0;                     // 0: choose per launch; 1: no helpers; 2 / 3: one / two helper workgroups per main workgroup
     int force_mains = 0, force_help = 0;    // > 0: exactly this launch shape (debug / tuning)
+    int lim16 = -1, lim32 = -1, prio = -1;  // pool tuning (IMCVT_POOL_LIM16 / _LIM32 / _PRIO; < 0: defaults from the launch shape)
     int last_mains = 0, last_help = 0;
 };
 
@@ -60,9 +61,19 @@ extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 3
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// A main workgroup posts a request only while fewer than this many requests of its kind wait unclaimed in its queue shard; beyond
+// that every helper is busy and the workgroup evaluates the CU itself (hevc_frame.h enter_cu).  With two helpers per main
+// workgroup a request never waits, and the limit is out of the way.
+static int pool_limit(int nmains, int nhelp, int kind) {
+    if (nhelp >= 2 * nmains) return 1 << 20;
+    const int per_shard = (nhelp + POOL_SHARDS - 1) / POOL_SHARDS;
+    const int v = kind == 0 ? per_shard / 4 : per_shard / 2;
+    return v > 1 ? v : 1;
+}
 static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp) {
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
-                       (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp);
+                       (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
+                       c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0));
 }
 
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
@@ -82,6 +93,9 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     }
     c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
     if (const char *e = getenv("IMCVT_HEVC_TEAM")) imcvt_hevc_set_team(c, atoi(e));      // clamped to 0..3 like the API call
+    if (const char *e = getenv("IMCVT_POOL_LIM16")) c->lim16 = atoi(e);
+    if (const char *e = getenv("IMCVT_POOL_LIM32")) c->lim32 = atoi(e);
+    if (const char *e = getenv("IMCVT_POOL_PRIO")) c->prio = atoi(e);
     c->mail_cap = c->max_wg / 2 + 8;
     Tables *T = new Tables(); ColdTables *K = new ColdTables();
     imcvt::build_tables(*T, *K);
@@ -92,7 +106,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
            && hipMemcpy(c->d_cold, K, sizeof(ColdTables), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
-           && hipMalloc(&c->d_counter, 2 * sizeof(int)) == hipSuccess
+           && hipMalloc(&c->d_counter, 4 * sizeof(int)) == hipSuccess
            && hipMalloc(&c->d_mail, sizeof(TeamMail) * c->mail_cap) == hipSuccess
            && hipMalloc(&c->d_pq, sizeof(PoolQ)) == hipSuccess
            && hipMalloc(&c->d_prof, sizeof(unsigned long long) * 3 * NWAVES * PF_N) == hipSuccess
@@ -110,7 +124,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     // every workgroup leaves at once) bring the ring to size before real work arrives.
     if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
         for (int i = 0; i < 3 && ok; i++) {
-            ok = hipMemset(c->d_counter, 0, sizeof(int)) == hipSuccess;
+            ok = hipMemset(c->d_counter, 0, 4 * sizeof(int)) == hipSuccess;
             if (ok) launch(c, c->max_wg, 0, 0, 1, 0, 0);
             ok = ok && hipDeviceSynchronize() == hipSuccess;
         }
@@ -177,7 +191,7 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         h = 2 * m < max_wg - m ? 2 * m : max_wg - m;
     }
     if (m > mail_cap) m = mail_cap;
-    if (2 * m > POOL_QCAP) m = POOL_QCAP / 2;
+    if (2 * m > POOL_SHARDS * POOL_QCAP) m = POOL_SHARDS * POOL_QCAP / 2;
     *nmains = m; *nhelp = h;
     return 2;
 }
@@ -188,6 +202,7 @@ static int pick_shape(const imcvt_hevc_ctx *c, int n, int *nmains, int *nhelp) {
     }
     return imcvt_hevc_plan(n, c->max_wg, c->force_team, nmains, nhelp);
 }
+extern "C" void imcvt_hevc_set_pool_tuning(imcvt_hevc_ctx *c, int lim16, int lim32, int prio) { if (c) { c->lim16 = lim16; c->lim32 = lim32; c->prio = prio; } }
 extern "C" void imcvt_hevc_set_shape(imcvt_hevc_ctx *c, int nmains, int nhelp) { if (c) { c->force_mains = nmains > 0 ? nmains : 0; c->force_help = nhelp > 0 ? nhelp : 0; } }
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
@@ -219,7 +234,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(int), stream));
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, 4 * sizeof(int), stream));
     int nmains = 0, nhelp = 0;
     const int mode = pick_shape(c, n, &nmains, &nhelp);
     const int grid = nmains + nhelp;
@@ -227,7 +242,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nmains, stream));     // sequence numbers restart with every launch
         HIPCHK(hipMemsetAsync(c->d_pq, 0, sizeof(PoolQ), stream));
     }
-    if (grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_QCAP))) { fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
+    if (grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) { fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
     c->last_mains = nmains; c->last_help = nhelp;
     HIPCHK(hipEventRecord(c->ev0, stream));
     launch(c, grid, stream, n, mode, nmains, nhelp);
@@ -254,12 +269,21 @@ extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
     if (!c || grid < 1) return IMCVT_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
-    HIPCHK(hipMemset(c->d_counter, 0, 2 * sizeof(int)));
+    HIPCHK(hipMemset(c->d_counter, 0, 4 * sizeof(int)));
     launch(c, grid, 0, 0, -1, 0, 0);
     HIPCHK(hipDeviceSynchronize());
     int v[2] = { 0, 0 };
     HIPCHK(hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost));
     return v[1];
+}
+
+extern "C" int imcvt_hevc_last_resident(imcvt_hevc_ctx *c) {
+    if (!c) return IMCVT_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
+    int v = 0;
+    HIPCHK(hipMemcpy(&v, c->d_counter + 3, sizeof v, hipMemcpyDeviceToHost));
+    return v;
 }
 
 extern "C" int imcvt_hevc_debug_prof(imcvt_hevc_ctx *c, unsigned long long *out, int n, int reset) {

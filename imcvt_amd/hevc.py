@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_plan")
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_plan")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -84,12 +84,16 @@ def load_library():
     lib.imcvt_hevc_batch_devices.argtypes = []
     lib.imcvt_hevc_debug_census.restype = C.c_int
     lib.imcvt_hevc_debug_census.argtypes = [C.c_void_p, C.c_int]
+    lib.imcvt_hevc_last_resident.restype = C.c_int
+    lib.imcvt_hevc_last_resident.argtypes = [C.c_void_p]
     lib.imcvt_hevc_plan.restype = C.c_int
     lib.imcvt_hevc_plan.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.imcvt_hevc_last_shape.restype = C.c_int
     lib.imcvt_hevc_last_shape.argtypes = [C.c_void_p, _ip, _ip]
     lib.imcvt_hevc_set_shape.restype = None
     lib.imcvt_hevc_set_shape.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.imcvt_hevc_set_pool_tuning.restype = None
+    lib.imcvt_hevc_set_pool_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.imcvt_hevc_shutdown.restype = None
     lib.imcvt_hevc_shutdown.argtypes = []
     _lib = lib
@@ -187,6 +191,14 @@ class DeviceEncoder:
     def set_shape(self, nmains: int, nhelp: int):
         """Debug / tuning: exactly this many main and helper workgroups for the next launches; (0, 0) = automatic again."""
         self.lib.imcvt_hevc_set_shape(self.ctx, int(nmains), int(nhelp))
+
+    def set_pool_tuning(self, lim16: int = -1, lim32: int = -1, prio: int = -1):
+        """Debug / tuning: posting limits per queue shard and main-workgroup priority of launches with helpers (< 0: defaults)."""
+        self.lib.imcvt_hevc_set_pool_tuning(self.ctx, int(lim16), int(lim32), int(prio))
+
+    def last_resident(self):
+        """Most workgroups of the last launch that ran at the same time."""
+        return int(self.lib.imcvt_hevc_last_resident(self.ctx))
 
     def last_shape(self):
         """(main workgroups, helper workgroups) of the last launch."""

@@ -112,6 +112,11 @@ int imcvt_hevc_last_shape(imcvt_hevc_ctx *ctx, int *nmains, int *nhelp);
 /* Debug / tuning aid: the next launches use exactly nmains main and nhelp helper workgroups (both > 0 and together within the
  * context's workgroups; fewer mains when there are fewer frames); (0, 0) returns to imcvt_hevc_set_team's choice. */
 void imcvt_hevc_set_shape(imcvt_hevc_ctx *ctx, int nmains, int nhelp);
+/* Debug / tuning aid for launches with helpers: a main workgroup posts a 16x16 / 32x32 request only while fewer than lim16 / lim32
+ * requests of that kind wait unclaimed in its queue shard (otherwise it evaluates the CU itself); prio >= 2 raises the wave
+ * priority of the main workgroups.  Negative values return to the defaults derived from the launch shape.  Environment
+ * overrides at context creation: IMCVT_POOL_LIM16, IMCVT_POOL_LIM32, IMCVT_POOL_PRIO.  Results do not depend on any of them. */
+void imcvt_hevc_set_pool_tuning(imcvt_hevc_ctx *ctx, int lim16, int lim32, int prio);
 
 /* Kernel-only time of the last imcvt_hevc_encode_device call on this context, in milliseconds, from HIP
  * events recorded on the launch stream (synchronises that stream).  <0 if nothing was launched. */
@@ -120,6 +125,9 @@ float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *ctx);
 /* Debug aid: decision trace of frame 0 of the next launch (8 ints per CU: y, x, size, kind, mode(s), cost, 0, 0)
  * into a device buffer of cap ints; pass NULL to disable. */
 void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
+
+/* Debug aid: the largest number of workgroups of the context's last launch that ran at the same time (waits for the launch). */
+int imcvt_hevc_last_resident(imcvt_hevc_ctx *ctx);
 
 /* Debug aid: per-wave cycle totals by phase ([3 roles][waves][categories], zeros unless the library was built with
  * -DIMCVT_PROF); copies up to n counters to `out`, optionally resets them; returns the number available. */
