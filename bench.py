@@ -23,6 +23,10 @@ roofline: the HBM view the metric asks for — algorithmic bytes (W*H read + Wp*
 written) per launch / HIP-event duration of the kernel on its launch stream.
 roofline_issue: the bound that binds (VALU issue).  cpu_baseline: the CPU checker on a bounded sample (N=1 only).
 latency_view: one 1080p frame and one 4K frame alone on the GPU (BASELINE configs 1 and 2), kernel ms (N=1 only).
+host_abi_view: the reference-shaped host-pointer entry point over ALL the bench frames, PCIe copies included (N=1 only).
+solo_1000f: secondary throughput with the device full (1000 frames, a frame per workgroup), same kernel (N=1 only).
+jls_view: BASELINE config 5 (1920x1080 gray8 -> .jls, NEAR=0): one plane and 64 planes, kernel ms, reference digest (N=1 only).
+All of these run after the timed region and do not enter `value`.
 """
 import argparse
 import hashlib
@@ -264,7 +268,9 @@ def main():
                                       "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": "instruction count per CTU from " + iv["source"] + "; time from this run"}
         if world == 1 and not args.no_latency_view:
             line["latency_view"] = latency_view(enc, dev, args.qpd6)
+            line["solo_1000f"] = solo_view(enc, big, last, args.qpd6)
             line["host_abi_view"] = host_abi_view(big, last, args.qpd6)
+            line["jls_view"] = jls_view(dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.qpd6)
         print(json.dumps(line), flush=True)
@@ -274,8 +280,56 @@ def main():
         dist.destroy_process_group()
 
 
-def host_abi_view(big, digests, qpd6, n=32):
-    """The reference-shaped entry point (HOST pointers in and out): wall time of HEVCImageEncoderBatch over the first n
+def solo_view(enc, big, digests, qpd6, n=1000):
+    """The same kernel with the device full: n frames (the bench frames, repeated), a frame per workgroup — the throughput the
+    path reaches when the batch is large enough to fill every workgroup slot.  One warm launch, one timed; kernel ms from HIP events."""
+    import torch
+    F = big.shape[0]
+    if F < 1:
+        return None
+    b = enc.make_batch([big[i % F] for i in range(n)], qpd6)
+    enc.set_team(1)
+    enc.encode(b); torch.cuda.synchronize()
+    enc.encode(b); torch.cuda.synchronize()
+    ms = enc.last_kernel_ms()
+    enc.set_team(0)
+    lens = b["lens"].cpu().tolist()
+    same = all(hashlib.sha256(b["outs"][i][:lens[i]].cpu().numpy().tobytes()).hexdigest() == digests[i % F] for i in list(range(0, n, 37)) + [n - 1])
+    if not same:
+        raise SystemExit("solo_1000f: streams differ from the timed batch's")
+    return {"frames": n, "kernel_ms": round(ms, 1), "mpx_s": round(n * W * H / ms / 1e3, 3), "shape": list(enc.last_shape()),
+            "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
+
+
+def jls_view(dev):
+    """BASELINE config 5: 1920x1080 gray8 -> .jls (NEAR=0, src/imageio_jls.c:240-399) on the device: one plane alone and 64 planes
+    in one launch (kernel ms from HIP events, inputs resident), digest against the reference's (tests/golden/jls_kat.json), and the
+    CPU checker's one-core time for the same plane beside it."""
+    import torch
+    from imcvt_amd import jls, synth
+    img = synth.syn(W, H, 0)
+    gold = next((e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "jls_kat.json")))
+                 if e["input"] == {"kind": "syn", "w": W, "h": H, "arg": 0} and e["near"] == 0), None)
+    out = {}
+    for name, n in (("1_plane", 1), ("64_planes", 64)):
+        d = jls.DevicePlanes([torch.from_numpy(img).to(dev) for _ in range(n)], 0)
+        ms = []
+        for _ in range(3):
+            d.encode(); torch.cuda.synchronize(); ms.append(d.last_kernel_ms())
+        res = d.results()
+        okd = all(len(r) == gold["bytes"] and hashlib.sha256(r).hexdigest() == gold["sha256"] for r in (res[0], res[-1])) if gold else None
+        if okd is False:
+            raise SystemExit(f"jls_view {name}: stream differs from the reference digest")
+        out[name] = {"kernel_ms": round(min(ms), 2), "mpx_s": round(n * W * H / min(ms) / 1e3, 2), "bytes_per_plane": len(res[0]), "sha256_equal_to_reference": okd,
+                     "path": "planes spread over the device" if d.last_path() == 1 else "one walker per plane"}
+    from oracle import oracle                                  # (checker leg, like cpu_baseline)
+    t = time.perf_counter(); oracle.jls_cpu_encode(img, 0); cs = time.perf_counter() - t
+    out["cpu_1core"] = {"seconds": round(cs, 3), "mpx_s": round(W * H / cs / 1e6, 2), "kind": "reference" if oracle.jls_have_ref() else "port"}
+    return out
+
+
+def host_abi_view(big, digests, qpd6, n=512):
+    """The reference-shaped entry point (HOST pointers in and out): wall time of HEVCImageEncoderBatch over the
     bench frames, PCIe copies in both directions, slab management and the launch included — next to `value`, which is measured
     with inputs resident in HBM (BASELINE.md §3 asks for both)."""
     import imcvt_amd

@@ -329,7 +329,9 @@ struct alignas(256) PoolShard {
     u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> main workgroup index + 1 (0: not published yet)
 };
 struct alignas(256) PoolQ {
-    u32 done; u32 pad_[63];                      // main workgroups that have left (no frames remain): helpers leave when all have
+    u32 done;                                    // main workgroups that have left (no frames remain): helpers leave when all have
+    u32 alive;                                   // helper workgroups that have started: requests are only posted once there is one to serve them
+    u32 pad_[62];
     PoolShard sh[POOL_SHARDS];
 };
 struct FrameCtx {
@@ -345,6 +347,7 @@ struct FrameCtx {
     i32 prio_base;      // wave priority of this workgroup outside its critical sections (2: main workgroup of a team, 0 otherwise)
     i32 lim[MAIL_SLOTS];   // a request of this kind is only posted while fewer than this many wait unclaimed in the workgroup's shard (else the CU is evaluated here)
     i32 posted[3];      // the CU of depth 0 / 1 being walked has a request out
+    i32 kept;           // CUs of this frame evaluated here because the helpers were busy (debug statistic)
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
 };
 
@@ -624,10 +627,16 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
 #ifndef HDN_BORDER
 #define HDN_BORDER HDN
 #endif
+#ifndef HDN_BFT
+#define HDN_BFT HDN_BORDER
+#endif
+#ifndef HDN_BTS
+#define HDN_BTS HDN_BORDER
+#endif
 #ifndef HDN_EVAL
 #define HDN_EVAL HDN
 #endif
-HDN_BORDER void border_from_tile(int wave_, int N_, int y0_, int x0_, int hl_, int hbl_, int ha_, int har_) {
+HDN_BFT void border_from_tile(int wave_, int N_, int y0_, int x0_, int hl_, int hbl_, int ha_, int har_) {
     const int wave = uni_i(wave_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int hl = uni_i(hl_); const int hbl = uni_i(hbl_); const int ha = uni_i(ha_); const int har = uni_i(har_);
     WaveMem &W = WM(wave);
     Border &b = W.bsh;
@@ -728,7 +737,7 @@ HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int ha
     }
     wave_sync();
 }
-HDN_BORDER void border_tu_split(int N_, int y0_, int x0_, int k_, int hl_, int hbl_, int ha_, int har_, int c_lo_, int c_hi_) {
+HDN_BTS void border_tu_split(int N_, int y0_, int x0_, int k_, int hl_, int hbl_, int ha_, int har_, int c_lo_, int c_hi_) {
     const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int k = uni_i(k_); const int hl = uni_i(hl_); const int hbl = uni_i(hbl_); const int ha = uni_i(ha_); const int har = uni_i(har_); const int c_lo = uni_i(c_lo_); const int c_hi = uni_i(c_hi_);      // modes c_lo .. c_hi-1
     if (k == 1) border_tu_split_k<1>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);
     else if (k == 2) border_tu_split_k<2>(N, y0, x0, hl, hbl, ha, har, c_lo, c_hi);

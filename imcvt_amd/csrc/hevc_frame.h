@@ -293,8 +293,14 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
             if (F.sc.trace && F.trace_n + 8 <= F.sc.trace_cap) {
                 i32 *t = F.sc.trace + F.trace_n;
                 t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = N; t[3] = kind; t[4] = (kind == 3) ? (WM(2).pu_mode[0] | WM(2).pu_mode[1] << 8 | WM(2).pu_mode[2] << 16 | WM(2).pu_mode[3] << 24) : mode;
-                t[5] = best; t[6] = 0; t[7] = 0;
+                t[5] = best; t[6] = m1; t[7] = m2;             // (the minima of the one-TU and the four-TU candidate sets)
                 F.trace_n += 8;
+                if (N == 8 && F.trace_n + 8 <= F.sc.trace_cap) {      // 8x8 CUs: a second row (size 4) for the NxN candidate
+                    t += 8;
+                    t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = 4; t[3] = 3; t[4] = WM(2).pu_mode[0] | WM(2).pu_mode[1] << 8 | WM(2).pu_mode[2] << 16 | WM(2).pu_mode[3] << 24;
+                    t[5] = WM(2).nxn_cost; t[6] = WM(2).pu_sse[0] + WM(2).pu_sse[1]; t[7] = WM(2).pu_sse[2] + WM(2).pu_sse[3];
+                    F.trace_n += 8;
+                }
             }
         }
     }
@@ -342,7 +348,8 @@ HDN void enter_cu(int depth_, int N_, int y0_, int x0_, int code_split_, int avm
             if (w == 0 && l == 0) {
                 const int slot = slot_of(N);
                 const PoolShard *q = &F.pq->sh[F.main_id % POOL_SHARDS];
-                F.posted[depth] = (i32)(m_ld32(&q->tail[slot]) - m_ld32(&q->head[slot])) < F.lim[slot];
+                F.posted[depth] = (i32)(m_ld32(&q->tail[slot]) - m_ld32(&q->head[slot])) < F.lim[slot] && m_ld32(&F.pq->alive) != 0u;
+                F.kept += !F.posted[depth];
             }
         }
         wg_sync();
@@ -741,7 +748,7 @@ HDN void helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *j
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if ((threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = (TeamMail *)0; F.pq = pq; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = (TeamMail *)0; F.pq = pq; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; m_add32(&pq->alive, 1u); } }
     wg_sync();
     for (;;) {
         const long long tidle = prof_now();
@@ -787,6 +794,7 @@ struct KArgs {
     const Tables *gT; const ColdTables *gK; const FrameJob *jobs; const u8 *hdrs; int njobs;
     const Scratch *scr; int *counter; i32 *trace; int trace_cap; unsigned long long *prof;
     TeamMail *mail; PoolQ *pq;
+    unsigned long long *fclk;                   // optional debug buffer, 4 words per frame: start clock, end clock (100 MHz), block, requests kept local
     int lim16, lim32, prio;                     // pool tuning: unclaimed requests per shard beyond which a main workgroup keeps a CU (16x16 / 32x32); wave priority of the main workgroups
     int team_size, nteams, nhelp;               // team_size 1: every workgroup encodes whole frames alone; > 1: `nteams` main workgroups + a pool of `nhelp` helper workgroups
 };
@@ -796,8 +804,10 @@ HD int next_job(int *counter) { return (*counter)++; }
 HD int next_job(int *counter) { return atomicAdd(counter, 1); }
 #endif
 HD void kernel_main(const KArgs &A, int block) {
-    // Main and helper workgroups are interleaved in proportion over the block indices, so that every run of consecutive blocks
-    // — in particular the resident prefix, if fewer workgroups are resident than were launched — holds both kinds.
+    // The main workgroups are the first blocks of the grid, the helpers follow: if fewer workgroups are resident than were
+    // launched, the ones that are missing are helpers.  Nothing depends on a workgroup that is not running: a main workgroup
+    // posts requests only once a helper has reported in (helpers stay until every main workgroup has left, so what is posted
+    // is served), evaluates the CUs itself until then, and frames are pulled by whichever main workgroups run.
 #ifndef IMCVT_HOSTEMU
     if (A.team_size < 0) {      // residency census (debug): how many workgroups of this launch are on the device at the same time
         if (threadIdx.x == 0) {
@@ -812,18 +822,22 @@ HD void kernel_main(const KArgs &A, int block) {
 #endif
 #ifndef IMCVT_HOSTEMU
     // residency diagnostic: counter[2] = workgroups of this launch running now, counter[3] = the most there ever were (imcvt_hevc_last_resident)
-    if (threadIdx.x == 0) atomicMax(A.counter + 3, atomicAdd(A.counter + 2, 1) + 1);
+    if (threadIdx.x == 0) {
+        atomicMax(A.counter + 3, atomicAdd(A.counter + 2, 1) + 1);
+        const unsigned long long now = wall_clock64();                  // 100 MHz: when the first and the last workgroup of the launch started
+        atomicMin((unsigned long long *)(A.counter + 4), now); atomicMax((unsigned long long *)(A.counter + 6), now);
+    }
     struct Leave { int *c; __device__ ~Leave() { if (threadIdx.x == 0) atomicAdd(c + 2, -1); } } leave_{ A.counter };
 #endif
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
-    const int mi0 = pool ? (int)((long long)block * nm / tot) : block, mi1 = pool ? (int)((long long)(block + 1) * nm / tot) : block + 1;
-    const int role = mi1 > mi0 ? 0 : 1, team = mi0;          // block b is main workgroup mi0 iff the count of mains steps at b
+    const int role = (pool && block >= nm) ? 1 : 0, team = block;
+    (void)tot;
     Scratch sc = A.scr[block];
     sc.trace_cap = A.trace_cap; sc.prof = A.prof;
     if (role != 0) {
         sc.trace = (i32 *)0;
-        helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, (block - mi0) % POOL_SHARDS, role);
+        helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, (block - nm) % POOL_SHARDS, role);
         return;
     }
 #ifndef IMCVT_HOSTEMU
@@ -843,8 +857,14 @@ HD void kernel_main(const KArgs &A, int block) {
         wg_sync();
         if (f >= A.njobs) break;
         sc.trace = (f == 0) ? A.trace : (i32 *)0;
-        WAVES(w) LANES(l) { if (w == 0 && l == 0) F.frame = f; }
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.frame = f; F.kept = 0; } }
+#ifndef IMCVT_HOSTEMU
+        if (A.fclk && threadIdx.x == 0) A.fclk[4 * f] = wall_clock64();
+#endif
         encode_frame(A.gT, A.gK, A.jobs[f], sc, A.hdrs + (size_t)HDR_MAX * f);
+#ifndef IMCVT_HOSTEMU
+        if (A.fclk && threadIdx.x == 0) { A.fclk[4 * f + 1] = wall_clock64(); A.fclk[4 * f + 2] = (unsigned long long)block; A.fclk[4 * f + 3] = (unsigned long long)F.kept; }
+#endif
     }
     if (pool) { WAVES(w) LANES(l) { if (w == 0 && l == 0) m_add32(&A.pq->done, 1u); } }      // this main workgroup posts no further request
 }

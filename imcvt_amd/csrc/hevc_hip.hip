@@ -17,10 +17,10 @@
 
 __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int lim16, int lim32, int prio) {
+                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int lim16, int lim32, int prio, unsigned long long *fclk) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
-    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio;
+    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio; A.fclk = fclk;
     kernel_main(A, (int)blockIdx.x);
 }
 
@@ -37,6 +37,7 @@ struct imcvt_hevc_ctx {
     FrameJob *h_jobs = nullptr; u8 *h_hdrs = nullptr;      // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
     int *d_trace = nullptr; int trace_cap = 0;
+    unsigned long long *d_fclk = nullptr;   // optional per-frame clocks (imcvt_hevc_set_frame_clock)
     unsigned long long *d_prof = nullptr;   // [3 roles][NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
     int force_team = 0;                     // 0: choose per launch; 1: no helpers; 2 / 3: one / two helper workgroups per main workgroup
     int force_mains = 0, force_help = 0;    // > 0: exactly this launch shape (debug / tuning)
@@ -73,7 +74,7 @@ static int pool_limit(int nmains, int nhelp, int kind) {
 static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp) {
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
                        (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
-                       c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0));
+                       c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), c->d_fclk);
 }
 
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
@@ -106,7 +107,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
            && hipMemcpy(c->d_cold, K, sizeof(ColdTables), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&c->d_pool, per_wg * c->max_wg) == hipSuccess
            && hipMalloc(&c->d_scratch, sizeof(Scratch) * c->max_wg) == hipSuccess
-           && hipMalloc(&c->d_counter, 4 * sizeof(int)) == hipSuccess
+           && hipMalloc(&c->d_counter, 8 * sizeof(int)) == hipSuccess
            && hipMalloc(&c->d_mail, sizeof(TeamMail) * c->mail_cap) == hipSuccess
            && hipMalloc(&c->d_pq, sizeof(PoolQ)) == hipSuccess
            && hipMalloc(&c->d_prof, sizeof(unsigned long long) * 3 * NWAVES * PF_N) == hipSuccess
@@ -124,7 +125,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     // every workgroup leaves at once) bring the ring to size before real work arrives.
     if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
         for (int i = 0; i < 3 && ok; i++) {
-            ok = hipMemset(c->d_counter, 0, 4 * sizeof(int)) == hipSuccess;
+            ok = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;
             if (ok) launch(c, c->max_wg, 0, 0, 1, 0, 0);
             ok = ok && hipDeviceSynchronize() == hipSuccess;
         }
@@ -146,6 +147,7 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
     delete c;
 }
 
+extern "C" void imcvt_hevc_set_frame_clock(imcvt_hevc_ctx *c, unsigned long long *d_buf) { if (c) c->d_fclk = d_buf; }
 extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) {
@@ -235,6 +237,8 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(c->d_counter, 0, 4 * sizeof(int), stream));
+    HIPCHK(hipMemsetAsync(c->d_counter + 4, 0xFF, 2 * sizeof(int), stream));      // earliest start: a minimum
+    HIPCHK(hipMemsetAsync(c->d_counter + 6, 0, 2 * sizeof(int), stream));
     int nmains = 0, nhelp = 0;
     const int mode = pick_shape(c, n, &nmains, &nhelp);
     const int grid = nmains + nhelp;
@@ -269,7 +273,7 @@ extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
     if (!c || grid < 1) return IMCVT_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
-    HIPCHK(hipMemset(c->d_counter, 0, 4 * sizeof(int)));
+    HIPCHK(hipMemset(c->d_counter, 0, 8 * sizeof(int)));
     launch(c, grid, 0, 0, -1, 0, 0);
     HIPCHK(hipDeviceSynchronize());
     int v[2] = { 0, 0 };
@@ -284,6 +288,14 @@ extern "C" int imcvt_hevc_last_resident(imcvt_hevc_ctx *c) {
     int v = 0;
     HIPCHK(hipMemcpy(&v, c->d_counter + 3, sizeof v, hipMemcpyDeviceToHost));
     return v;
+}
+extern "C" long long imcvt_hevc_last_start_spread_us(imcvt_hevc_ctx *c) {
+    if (!c) return IMCVT_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
+    unsigned long long v[2] = { 0, 0 };
+    HIPCHK(hipMemcpy(v, c->d_counter + 4, sizeof v, hipMemcpyDeviceToHost));
+    return v[1] >= v[0] ? (long long)((v[1] - v[0]) / 100) : -1;
 }
 
 extern "C" int imcvt_hevc_debug_prof(imcvt_hevc_ctx *c, unsigned long long *out, int n, int reset) {

@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_plan")
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -86,6 +86,10 @@ def load_library():
     lib.imcvt_hevc_debug_census.argtypes = [C.c_void_p, C.c_int]
     lib.imcvt_hevc_last_resident.restype = C.c_int
     lib.imcvt_hevc_last_resident.argtypes = [C.c_void_p]
+    lib.imcvt_hevc_set_frame_clock.restype = None
+    lib.imcvt_hevc_set_frame_clock.argtypes = [C.c_void_p, C.c_void_p]
+    lib.imcvt_hevc_last_start_spread_us.restype = C.c_longlong
+    lib.imcvt_hevc_last_start_spread_us.argtypes = [C.c_void_p]
     lib.imcvt_hevc_plan.restype = C.c_int
     lib.imcvt_hevc_plan.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.imcvt_hevc_last_shape.restype = C.c_int
@@ -199,6 +203,10 @@ class DeviceEncoder:
     def last_resident(self):
         """Most workgroups of the last launch that ran at the same time."""
         return int(self.lib.imcvt_hevc_last_resident(self.ctx))
+
+    def last_start_spread_us(self):
+        """Microseconds between the start of the first and of the last workgroup of the last launch."""
+        return int(self.lib.imcvt_hevc_last_start_spread_us(self.ctx))
 
     def last_shape(self):
         """(main workgroups, helper workgroups) of the last launch."""

@@ -126,8 +126,14 @@ float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *ctx);
  * into a device buffer of cap ints; pass NULL to disable. */
 void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
 
+/* Debug aid: per-frame clocks of the next launches into a device buffer of 4 x n 64-bit words (start, end in 100 MHz ticks, block
+ * index, CUs the main workgroup kept because the helpers were busy); NULL to disable. */
+void imcvt_hevc_set_frame_clock(imcvt_hevc_ctx *ctx, unsigned long long *d_buf);
+
 /* Debug aid: the largest number of workgroups of the context's last launch that ran at the same time (waits for the launch). */
 int imcvt_hevc_last_resident(imcvt_hevc_ctx *ctx);
+/* Debug aid: microseconds between the start of the first and of the last workgroup of the context's last launch. */
+long long imcvt_hevc_last_start_spread_us(imcvt_hevc_ctx *ctx);
 
 /* Debug aid: per-wave cycle totals by phase ([3 roles][waves][categories], zeros unless the library was built with
  * -DIMCVT_PROF); copies up to n counters to `out`, optionally resets them; returns the number available. */

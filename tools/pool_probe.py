@@ -11,6 +11,8 @@ w, h, n, q = (int(a) for a in sys.argv[1:5])
 enc = imcvt_amd.DeviceEncoder()
 frames = [torch.from_numpy(synth.syn(w, h, s)).cuda() for s in range(n)]
 batch = enc.make_batch(frames, q)
+fclk = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
+enc.lib.imcvt_hevc_set_frame_clock(enc.ctx, fclk.data_ptr())
 ref = None
 for sh in sys.argv[5:]:
     if sh == "a:a":
@@ -25,7 +27,15 @@ for sh in sys.argv[5:]:
             enc.set_team(0); enc.set_shape(m, hp)
     ms = []; resid = []
     for _ in range(int(os.environ.get("PP_LAUNCHES", "2"))):
-        enc.encode(batch); torch.cuda.synchronize(); ms.append(enc.last_kernel_ms()); resid.append(enc.last_resident())
+        enc.encode(batch); torch.cuda.synchronize(); ms.append(enc.last_kernel_ms()); resid.append((enc.last_resident(), enc.last_start_spread_us()))
+        if os.environ.get("PP_VERBOSE"):
+            fc = fclk.cpu().numpy().reshape(n, 4); t0 = fc[:, 0].min()
+            end = (fc[:, 1] - t0) / 1e5; start = (fc[:, 0] - t0) / 1e5; late = int(end.argmax())
+            print(f"      launch {ms[-1]:.1f} ms resident/start-spread-us {resid[-1]}  frame ends ms: median {float(sorted(end)[n // 2]):.0f} max {end.max():.0f} (frame {late}: block {fc[late, 2]}, started {start[late]:.0f}, kept {fc[late, 3]}); started late (>100 ms): {int((start > 100).sum())}; kept per frame median {sorted(fc[:, 3])[n // 2]} max {fc[:, 3].max()}", flush=True)
+        if os.environ.get("PP_PROF"):                      # -DIMCVT_PROF build: G-cycles per role summed over the launch's waves
+            pr = enc.debug_prof(True); cats = enc.PROF_CATS
+            pick = ("sync", "wait_help", "idle", "p1_4", "p2_8", "p2_nxn")
+            print("      prof " + "  ".join(f"{'MH'[r]}:" + ",".join(f"{c}={sum(pr[3 * r + w][cats.index(c)] for w in range(3)) / 1e9:.1f}" for c in pick) for r in range(2)), flush=True)
     dig = hashlib.sha256(b"".join(s for s, _ in enc.results(batch))).hexdigest()[:16]
     if ref is None:
         ref = dig
