@@ -49,6 +49,7 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD int m_cas32(void *p, u32 expect, u32 desired) { if (*(volatile u32 *)p != expect) return 0; *(volatile u32 *)p = desired; return 1; }
   HD void mail_poll_pause() { emu_yield(); }
   HD void mail_idle_pause(int) { emu_yield(); }
+  HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
   HD void drain_stores() {}
 #else
   #define HD __device__ __forceinline__
@@ -87,6 +88,7 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   // an idle helper backs off (round r of an unsuccessful poll): ~0.9 us doubling to ~7 us, so that hundreds of idle helpers do not hammer the queue words
   HD void mail_idle_pause(int r) { const int n = r < 3 ? 1 << r : 8; for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(MAIL_POLL_SLEEP); }
   HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  HD unsigned long long wd_now() { return wall_clock64(); }
 #endif
 
 #if defined(IMCVT_HOSTEMU)
@@ -94,6 +96,11 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
 #define NOUNROLL
 #else
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef IMCVT_NO_PRIO
+#define SETPRIO(x) do {} while (0)
+#else
+#define SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 #define NOUNROLL _Pragma("unroll 1")
 #endif
 struct alignas(16) U4 { u32 x, y, z, w; };
@@ -142,6 +149,11 @@ template <class T_> HD T_ *uni_p(T_ *p) {
     const u64 v = (u64)p;
     const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
     return (T_ *)(((u64)hi << 32) | lo);
+}
+// the compute unit this wave runs on, as a key below POOL_CU_KEYS: XCC_ID[3:0] | HW_ID.se_id[15:13] | sh_id[12] | cu_id[11:8]
+HD int hw_cu_key() {
+    const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // hwreg(HW_REG_HW_ID), hwreg(HW_REG_XCC_ID)
+    return (int)(((xcc & 15u) << 8) | ((hw >> 8) & 255u));
 }
 HD int hibit(u32 v) { return 31 - __clz((int)v); }
 HD int clz_nz(u32 v) { return __builtin_clz(v); }          // v != 0 where the result is used
@@ -232,11 +244,12 @@ HD Arith unpack_arith(const FinState &f) {
 #endif
 #define LEADQ 10           // per-lane queue of byte leads: at most one per token of an 8-token block, plus the slot the idle write lands in
 struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
+#define P1_RES_BYTES 2304   // 16 tiles of 8x8 + 4 or 4 tiles of 16x16 + 16 i16 (padded against LDS bank conflicts), 16-byte multiple
 #define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
 struct alignas(16) WaveMem {
     Border  bsh;                 // border shared by all modes of a block
     i32 tokn[NMODE + 1];         // tokens written so far to each candidate's stream (slot NMODE: the NxN stream)
-    i32 tnz[NMODE];              // the TU tokenised last has a non-zero level
+    u8  tnz[NMODE + 1];          // the TU tokenised last has a non-zero level
     i32 sse[NMODE];
     i32 cost[NMODE];
     FinState fin[NMODE];         // coder state each trial ended in
@@ -244,7 +257,7 @@ struct alignas(16) WaveMem {
     i32 nxn_cost;
     alignas(16) u16 pend[NMODE + 1][8];     // the partial last 8-token block of each candidate's stream (rest: idle tokens)
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
-        struct { u8 rows_[1024]; i16 res[1024]; i32 tmp[1024]; } p1;                                  // one pipeline pass (the first KB only ever holds token rows)
+        struct { i16 res[P1_RES_BYTES / 2]; i32 tmp[(7168 - P1_RES_BYTES) / 4]; } p1;                    // one pipeline pass: residual / dequantised tiles, stage outputs (tile strides: p1_run_t)
         u32 raw[1792];                                                                                // per-lane token staging (4x4 blocks, CU headers): lane l at raw + 33 l
         struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
@@ -322,6 +335,19 @@ struct TeamMail { MailSlot s[MAIL_SLOTS]; };
 // POOL_SHARDS shards on their own cache lines (main workgroup i posts to shard i mod POOL_SHARDS; a helper looks at its home
 // shard first and then at one other shard per poll), so that hundreds of polling workgroups do not meet on one line.
 #define POOL_SHARDS 16
+// A main workgroup waits this long for an answer (100 MHz ticks; answers take 0.3 - 2 ms, queueing included), then evaluates the CU
+// itself and leaves the request to arrive whenever it does: a helper can be held up for seconds by things outside this code
+// (wave preemption on a full device, profiles/r03q_hb_probe.log).  The host emulation has no clock and counts polls instead.
+#ifndef ABANDON_TICKS
+#define ABANDON_TICKS 1000000ull
+#endif
+#ifndef ABANDON_POLLS
+#define ABANDON_POLLS (1 << 30)
+#endif
+#ifndef WD_TICKS
+#define WD_TICKS 2000000000ull   // 20 s of the 100 MHz clock: no wait between workgroups comes near (a request is served in ~1 ms)
+#endif
+#define POOL_CU_KEYS 4096     // XCC (4 bits) | shader engine (3) | shader array (1) | CU (4)
 #define POOL_QCAP 256        // per shard and kind: >= 2 x the main workgroups that share a shard (POOL_SHARDS x POOL_QCAP / 2 = 2048 mains)
 struct alignas(256) PoolShard {
     u32 head[MAIL_SLOTS], tail[MAIL_SLOTS];      // tickets claimed / issued, per request kind
@@ -329,10 +355,15 @@ struct alignas(256) PoolShard {
     u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> main workgroup index + 1 (0: not published yet)
 };
 struct alignas(256) PoolQ {
-    u32 done;                                    // main workgroups that have left (no frames remain): helpers leave when all have
+    u32 frames_done;                             // frames finished: helpers leave when all are (no request can follow)
     u32 alive;                                   // helper workgroups that have started: requests are only posted once there is one to serve them
-    u32 pad_[62];
+    u32 mains_taken;                             // main-workgroup indices handed out so far
+    u32 progress;                                // sum over the main workgroups of the share of their frames they have finished, in 1/65536 frames (pace control)
+    u32 abort;                                   // watchdog: a wait between workgroups exceeded WD_TICKS — every wait gives up, every workgroup leaves (host: IMCVT_ERR_WATCHDOG)
+    u32 dbg[8];                                  // what the wait that gave up was waiting for
+    u32 pad_[51];
     PoolShard sh[POOL_SHARDS];
+    u32 cu_count[POOL_CU_KEYS];                  // workgroups of this launch that have started on each compute unit (role choice, hevc_frame.h kernel_main)
 };
 struct FrameCtx {
     FrameJob job;
@@ -346,8 +377,14 @@ struct FrameCtx {
     i32 main_id;        // index of this main workgroup (= of its mailboxes)
     i32 prio_base;      // wave priority of this workgroup outside its critical sections (2: main workgroup of a team, 0 otherwise)
     i32 lim[MAIL_SLOTS];   // a request of this kind is only posted while fewer than this many wait unclaimed in the workgroup's shard (else the CU is evaluated here)
+    i32 post_pm[MAIL_SLOTS], post_acc[MAIL_SLOTS];   // share of the CUs of a kind that is offered to the helpers at all, per mille, and its running remainder
     i32 posted[3];      // the CU of depth 0 / 1 being walked has a request out
+    i32 stale[MAIL_SLOTS], gaveup;   // sequence number of a request this workgroup stopped waiting for (its mailbox is not reused before that answer has arrived); the last wait gave up
     i32 kept;           // CUs of this frame evaluated here because the helpers were busy (debug statistic)
+    i32 aborted;        // the launch's watchdog has fired (read once per CTU and after every wait)
+    unsigned long long hb_last, hb_gap, hb_when;   // heartbeat (debug): clock of the last beat, longest gap between two beats and when it began
+    u32 waited, waited_max;   // 100 MHz ticks this frame's main workgroup spent waiting for answers, and the longest single wait (debug statistics)
+    i32 pace_inc, pace_mine, pace_n, pace_base;   // pace control: 65536 / CTUs of this frame, this workgroup's share done, main workgroups of the launch, configured base priority
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
 };
 
@@ -380,6 +417,9 @@ struct alignas(16) Shm {
     alignas(16) u8 wraw[NWAVES * sizeof(WaveMem)];   // wave slices (wave 2 runs full pipeline passes for the 16x16 / 32x32 CUs too)
 };
 
+#ifndef IMCVT_PROF
+static_assert(sizeof(Shm) <= 40960, "four workgroups per compute unit need an LDS image of at most 160 KB / 4");
+#endif
 // The workgroup's LDS image is one file-scope object, so non-inlined callees still address it with ds_* ops.
 #ifdef IMCVT_HOSTEMU
 static Shm *g_shm_host;
@@ -789,14 +829,15 @@ HD void mac_MX(int acc[4][4], const i8 *C, const i16 *X, int row0, int col0) {
     }
 }
 // acc[r][c] += sum_kk Y[row0+r][k0+kk] * M[col0+c][k0+kk]      (Y: i32 rows of stride N)
+// (sw: the column swizzle of Y's rows row0..row0+3, see p1_run_t — 0 for unswizzled tiles)
 template <int N>
-HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0) {
+HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0, int sw) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
         for (int c = 0; c < 4; c++) mw[c] = *(const u32a *)(M + (col0 + c) * N + k0);
         for (int r = 0; r < 4; r++) {
-            const int4 y = *(const int4 *)(Y + (row0 + r) * N + k0);
+            const int4 y = *(const int4 *)(Y + (row0 + r) * N + (k0 ^ sw));
             for (int c = 0; c < 4; c++)
                 acc[r][c] += mul24(y.x, sx8(mw[c], 0)) + mul24(y.y, sx8(mw[c], 1)) + mul24(y.z, sx8(mw[c], 2)) + mul24(y.w, sx8(mw[c], 3));   // |tmp| <= 45900 (17 bits)
         }
@@ -804,13 +845,13 @@ HD void mac_YM32(int acc[4][4], const i32 *Y, const i8 *M, int row0, int col0) {
 }
 // acc[r][c] += sum_kk Y[row0+r][k0+kk] * C[k0+kk][col0+c]      (Y: i16 rows; the multiplier is C itself, i.e. the transpose of mac_YM32's)
 template <int N>
-HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *C, int row0, int col0) {
+HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *C, int row0, int col0, int sw) {
     NOUNROLL
     for (int k0 = 0; k0 < N; k0 += 4) {
         u32 mw[4];
         for (int kk = 0; kk < 4; kk++) mw[kk] = *(const u32a *)(C + (k0 + kk) * N + col0);
         for (int r = 0; r < 4; r++) {
-            const uint2 yw = *(const uint2 *)(Y + (row0 + r) * N + k0);
+            const uint2 yw = *(const uint2 *)(Y + (row0 + r) * N + (k0 ^ sw));
             const int y0 = lo16(yw.x), y1 = hi16(yw.x), y2 = lo16(yw.y), y3 = hi16(yw.y);
             for (int c = 0; c < 4; c++)
                 acc[r][c] += y0 * sx8(mw[0], c) + y1 * sx8(mw[1], c) + y2 * sx8(mw[2], c) + y3 * sx8(mw[3], c);
@@ -1330,7 +1371,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                     w.n = tokg_end<true, true>(w.o, w.n, B);
                 } else if (P.shape == 3) w.n = last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));   // PU pricing codes the residual syntax of an all-zero block (:1515)
                 ls_end(ls, w, W, c);
-                W.tnz[c] = (nzm != 0);
+                W.tnz[c] = (u8)(nzm != 0);
             }
             MARK("b4_tokens");
             prof_add(threadIdx_wave() == 2 ? PF_P2_8 : PF_T_NTOK, t4); t4 = prof_now();
@@ -1429,6 +1470,12 @@ HD void p1_run_t(int wave, const P1Args &P) {
     const int ncand = P.c_hi;
     constexpr int a1 = s + 1, ra = 1 << a1 >> 1, rb = 1 << (a1 + 7) >> 1;
     const QConst Q = qconst<s>(P.q);
+    // LDS layout of a pass, chosen against bank conflicts (wave64 b64 / b128 reads are served 32 / 16 lanes at a time over 64 banks):
+    // the candidates' tiles are a few dwords apart from a multiple of 64 (8x8: 16 tiles, otherwise all on the same banks), and
+    // the rows of the stage outputs of 16x16 / 32x32 tiles — whose lanes read block-rows 64 .. 512 dwords apart — are stored with
+    // the 4-element column index XOR-ed by the block-row (writers and readers of a row agree on its block-row).
+    constexpr int TR = NN + (N == 8 ? 4 : N == 16 ? 16 : 0), TT = NN + (N == 8 ? 4 : 0), TI = NN + (N == 8 ? 4 : N == 16 ? 4 : 0);
+    static_assert(G * TR * 2 <= P1_RES_BYTES && G * TT * 4 <= 7168 - P1_RES_BYTES && G * TI * 2 <= G * TT * 4, "pass buffer");
 
     NOUNROLL
     for (int c0 = P.c_lo; c0 < ncand; c0 += G) {
@@ -1438,12 +1485,14 @@ HD void p1_run_t(int wave, const P1Args &P) {
         const int mode = (P.only_mode >= 0) ? P.only_mode : (live ? c : 0);
         const int st = scan_type_of(N, mode);
         const int gp = cg_pos(st, s, r), by = gp >> 3, bx = gp & 7;
+        const int sw = (N >= 16) ? (by & (nb - 1)) << 2 : 0;
+        i16 *const rt = W.u.p1.res + sl * TR; i32 *const tt = W.u.p1.tmp + sl * TT; i16 *const it = (i16 *)W.u.p1.tmp + sl * TI;
         const int tokn0 = (P.tok && live) ? WO.tokn[c] : 0;
         u32 predw[4] = { 0, 0, 0, 0 };                  // this lane's 4x4 block of the prediction, a packed row per dword (kept in registers until step 5)
         MARK("pass_setup");
         // ---- step 1: prediction and residual
         if (live) {
-            i16 *rp = W.u.p1.res + sl * NN;
+            i16 *rp = rt;
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4];
             pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
@@ -1464,11 +1513,11 @@ HD void p1_run_t(int wave, const P1Args &P) {
         if (live) {
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = ra;
-            mac_MX<N, false>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
-            i32 *tp = W.u.p1.tmp + sl * NN;
+            mac_MX<N, false>(acc, C, rt, by * 4, bx * 4);
+            i32 *tp = tt;
             for (int r4 = 0; r4 < 4; r4++) {
                 int4 o; o.x = acc[r4][0] >> a1; o.y = acc[r4][1] >> a1; o.z = acc[r4][2] >> a1; o.w = acc[r4][3] >> a1;
-                *(int4 *)(tp + (by * 4 + r4) * N + bx * 4) = o;
+                *(int4 *)(tp + (by * 4 + r4) * N + ((bx * 4) ^ sw)) = o;
             }
         }
         wave_sync_lds();
@@ -1479,7 +1528,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             int any = 0;
             if (live) {
                 for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = rb;
-                mac_YM32<N>(acc, W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
+                mac_YM32<N>(acc, tt, C, by * 4, bx * 4, sw);
                 MARK("fwd_stage2");
                 any = rdoq_group<s>(acc, Q);
                 MARK("rdoq");
@@ -1559,7 +1608,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                     if (r == 0) {                                           // the DC lane, last in coding order, pads the final block with idle tokens
                         const int e7 = (tokn0 + total) & 7;
                         for (int i = 0; i < 7; i++) to_put_if(w.o, w.n + i, (int)TOK_IDLE, e7 != 0 && e7 + i < 8);
-                        WO.tokn[c] = tokn0 + total; WO.tnz[c] = (seg != 0);
+                        WO.tokn[c] = tokn0 + total; WO.tnz[c] = (u8)(seg != 0);
                     }
                 }
                 MARK("tokens_to_stream");
@@ -1567,7 +1616,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 wave_sync_lds();                                            // rows are done with before res is written again
             }
             if (live) {
-                i16 *dp = W.u.p1.res + sl * NN;
+                i16 *dp = rt;
                 for (int r4 = 0; r4 < 4; r4++) *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = dq[r4];
             }
         }
@@ -1577,13 +1626,13 @@ HD void p1_run_t(int wave, const P1Args &P) {
         if (live) {
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 64;
-            mac_MX<N, true>(acc, C, W.u.p1.res + sl * NN, by * 4, bx * 4);
-            i16 *ip = (i16 *)W.u.p1.tmp + sl * NN;       // tmp (i32) was last read in step 3; reuse it as i16
+            mac_MX<N, true>(acc, C, rt, by * 4, bx * 4);
+            i16 *ip = it;                                // tmp (i32) was last read in step 3; reuse it as i16
             for (int r4 = 0; r4 < 4; r4++) {
                 uint2 o;
                 o.x = (u32)(clip16(acc[r4][0] >> 7) & 0xFFFF) | (u32)clip16(acc[r4][1] >> 7) << 16;
                 o.y = (u32)(clip16(acc[r4][2] >> 7) & 0xFFFF) | (u32)clip16(acc[r4][3] >> 7) << 16;
-                *(uint2 *)(ip + (by * 4 + r4) * N + bx * 4) = o;
+                *(uint2 *)(ip + (by * 4 + r4) * N + ((bx * 4) ^ sw)) = o;
             }
         }
         wave_sync_lds();
@@ -1592,7 +1641,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
         if (live) {
             int acc[4][4];
             for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = 2048;
-            mac_YM16<N>(acc, (const i16 *)W.u.p1.tmp + sl * NN, C, by * 4, bx * 4);
+            mac_YM16<N>(acc, it, C, by * 4, bx * 4, sw);
             int part = 0;
             for (int r4 = 0; r4 < 4; r4++) {
                 const int y = by * 4 + r4;

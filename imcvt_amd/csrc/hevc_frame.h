@@ -23,6 +23,12 @@ HD Avail child_avail(const Avail &p, int k) {       // Z-order availability of q
     return c;
 }
 #define F (SM.F)
+// debug heartbeat (thread 0): the longest interval between two beats of this workgroup and when it began
+HD void hb_beat() {
+    const unsigned long long now = wd_now();
+    if (F.hb_last && now - F.hb_last > F.hb_gap) { F.hb_gap = now - F.hb_last; F.hb_when = F.hb_last; }
+    F.hb_last = now;
+}
 #ifndef NXN_PRIO_SOLO
 #define NXN_PRIO_SOLO 1
 #endif
@@ -107,7 +113,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     const RdW rw = rd_weights(q);
     pt = prof_now();
 #ifndef IMCVT_HOSTEMU
-    if (big) { if (F.prio_base) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
+    if (big) { if (F.prio_base) SETPRIO(3); else SETPRIO(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
 #endif
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
@@ -117,11 +123,14 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
         if (on) {
             W.fin[l] = pack_arith(a);
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
+#ifdef IMCVT_TOKSTAT
+            fprintf(stderr, "TS %d %d %d %d %d %d %d %d\n", N, wave, l, W.tokn[l], W.cost[l], W.sse[l], arith_len(a) - len0, (N > 8) ? SM.split_cost[depth] : -1);
+#endif
         }
     }
     wave_sync();
 #ifndef IMCVT_HOSTEMU
-    if (big) { if (F.prio_base) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+    if (big) { if (F.prio_base) SETPRIO(2); else SETPRIO(0); }
 #endif
 
     prof_add(N == 32 ? PF_P2_32 : N == 16 ? PF_P2_16 : PF_P2_8, pt);
@@ -137,7 +146,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 #ifndef IMCVT_HOSTEMU
     // the NxN chain is the longest of an 8x8 CU's three candidate sets: its wave wins the VALU arbitration of the SIMD it shares
     // with waves of other workgroups (1024 frames in flight: +3 %)
-    if (F.prio_base) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(NXN_PRIO_SOLO);
+    if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);
 #endif
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
@@ -166,6 +175,9 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             Arith a; arith_reset(a);
             run_trial(a, SM.cx0, W.u.p2.cx[ll], &W.u.p2.lm[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP + 8, W.tokn[ll] - 8, on);
             if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
+#ifdef IMCVT_TOKSTAT
+            if (on) fprintf(stderr, "TS %d %d %d %d %d %d %d %d\n", 4, wave, l, W.tokn[l] - 8, W.cost[l], W.sse[l], arith_len(a), -1);
+#endif
         }
         wave_sync_lds();
         prof_add(PF_P2_PU, pt); pt = prof_now();
@@ -234,7 +246,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     wave_sync();
     prof_add(PF_P2_NXN, ptn);
 #ifndef IMCVT_HOSTEMU
-    if (F.prio_base) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+    if (F.prio_base) SETPRIO(2); else SETPRIO(0);
 #endif
 }
 
@@ -348,7 +360,14 @@ HDN void enter_cu(int depth_, int N_, int y0_, int x0_, int code_split_, int avm
             if (w == 0 && l == 0) {
                 const int slot = slot_of(N);
                 const PoolShard *q = &F.pq->sh[F.main_id % POOL_SHARDS];
-                F.posted[depth] = (i32)(m_ld32(&q->tail[slot]) - m_ld32(&q->head[slot])) < F.lim[slot] && m_ld32(&F.pq->alive) != 0u;
+                // a fixed share of the CUs is offered (the launch shape's balance between the main workgroups' own work and what
+                // the pool can take, hevc_hip.hip pool_split), evenly spread; an offered CU is still kept while requests wait unclaimed
+                hb_beat();
+                F.post_acc[slot] += F.post_pm[slot];
+                const int offer = F.post_acc[slot] >= 1000;
+                if (offer) F.post_acc[slot] -= 1000;
+                if (F.stale[slot] && (i32)m_ld32(&F.mail->s[slot].res_flag) == F.stale[slot]) F.stale[slot] = 0;     // the answer this workgroup stopped waiting for has arrived: the mailbox is free again
+                F.posted[depth] = offer && !F.stale[slot] && (i32)(m_ld32(&q->tail[slot]) - m_ld32(&q->head[slot])) < F.lim[slot] && m_ld32(&F.pq->alive) != 0u;
                 F.kept += !F.posted[depth];
             }
         }
@@ -422,9 +441,34 @@ HD void pool_push(int slot) {
     }
 }
 // await: returns once flag == v; mail loads issued afterwards see what the publisher stored before publishing
-HD void team_await(i32 *flag, i32 v) {
+// Waits between workgroups carry a watchdog: a wait that lasts WD_TICKS (nothing legitimate comes near) records what it was
+// waiting for, raises the launch's abort flag and gives up; every other wait sees the flag and gives up too, every workgroup leaves
+// at its next CTU / request, and the host reports IMCVT_ERR_WATCHDOG instead of hanging.  `code`, a, b: for the record.
+HD int wd_poll(PoolQ *pq, unsigned long long t0, int n, int code, int a, int b) {      // thread 0, every few polls; returns non-zero to give up
+    if ((n & 15) != 15) return 0;
+    if (m_ld32(&pq->abort) != 0u) return 1;
+    if (wd_now() - t0 < WD_TICKS) return 0;
+    if (m_cas32(&pq->abort, 0u, (u32)code)) { m_st32(&pq->dbg[0], (u32)code); m_st32(&pq->dbg[1], (u32)a); m_st32(&pq->dbg[2], (u32)b); m_st32(&pq->dbg[3], (u32)F.main_id); m_st32(&pq->dbg[4], (u32)F.frame);
+        if (code == 1) { const PoolShard *q = &pq->sh[F.main_id % POOL_SHARDS]; m_st32(&pq->dbg[5], m_ld32(&q->head[a])); m_st32(&pq->dbg[6], m_ld32(&q->tail[a])); m_st32(&pq->dbg[7], m_ld32(&F.mail->s[a].req_flag));
+            for (int i = 0; i < 4; i++) m_st32(&pq->pad_[i], m_ld32(&F.mail->s[a].pad0_[i])); m_st32(&pq->pad_[4], (u32)wd_now()); m_st32(&pq->pad_[5], (u32)t0); } }
+    return 1;
+}
+HD void team_await(i32 *flag, i32 v, int slot) {
     WAVES(w) LANES(l) {
-        if (w == 0 && l == 0) { while ((i32)m_ld32(flag) != v) mail_poll_pause(); }
+        if (w == 0 && l == 0) {
+            const unsigned long long t0 = wd_now();
+            for (int n = 0; (i32)m_ld32(flag) != v; n++) {
+                if (wd_poll(F.pq, t0, n, 1, slot, v)) { F.aborted = 1; break; }
+#ifdef IMCVT_HOSTEMU
+                if (n >= ABANDON_POLLS) { F.gaveup = 1; break; }
+#else
+                if ((n & 3) == 3 && wd_now() - t0 > ABANDON_TICKS) { F.gaveup = 1; break; }
+#endif
+                mail_poll_pause();
+            }
+            const u32 dt = (u32)(wd_now() - t0); F.waited += dt; if (dt > F.waited_max) F.waited_max = dt;
+            F.hb_last = wd_now();                   // (waiting is not a gap)
+        }
     }
     wg_sync();
 }
@@ -461,19 +505,28 @@ HDN void post_request(int depth_, int N_, int y0_, int x0_, int avm_) {
         }
     }
     wg_sync();
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.seq[slot]++; }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.seq[slot]++; m_st32(&m->req_flag, 0u); } }      // (req_flag: debug marker, set by the helper that takes the request)
     pool_push(slot);
 }
 
-// main: the CU's children are done and the split is priced — take the helper's answer and decide (:1439, :1475)
-HDN void decide_remote(int depth_, int N_, int y0_, int x0_) {
+// main: the CU's children are done and the split is priced — take the helper's answer and decide (:1439, :1475).  Returns non-zero
+// when the answer did not come in time: the caller then evaluates the CU itself (same result), and the mailbox stays out of use
+// until the late answer has arrived (enter_cu).
+HDN int decide_remote(int depth_, int N_, int y0_, int x0_) {
     const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
     const int slot = slot_of(N);
     MailSlot *m = &F.mail->s[slot];
     u8 *live_sink = F.job.out + F.out_pos;
     const long long t0 = prof_now();
-    team_await(&m->res_flag, F.seq[slot]);
+    team_await(&m->res_flag, F.seq[slot], slot);
     prof_add(PF_DECIDE, t0);                                // (booked as "wait_help": waiting for the helper's answer)
+    if (F.aborted) return 0;                                // (watchdog: there is no answer to read)
+    if (F.gaveup) {
+        wg_sync();
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.stale[slot] = F.seq[slot]; F.gaveup = 0; F.kept++; } }
+        wg_sync();
+        return 1;
+    }
     const HelpRes *R = &m->res;
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) {
@@ -516,6 +569,7 @@ HDN void decide_remote(int depth_, int N_, int y0_, int x0_) {
         }
         wg_sync();
     }
+    return 0;
 }
 
 // helper: serve one request — stage what the candidate sets read, evaluate the 70 candidates, answer with the last minimum
@@ -562,8 +616,10 @@ HDN void serve_request(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m
         }
     }
     wg_sync();
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->pad0_[1], (u32)wd_now()); hb_beat(); } }      // (debug stamps: staged / evaluated / about to publish)
     WAVES(w) eval_2Nx2N(w, depth, N, y0, x0, avm);
     wg_sync();
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->pad0_[2], (u32)wd_now()); hb_beat(); } }
     WAVES(w) LANES(l) {
         if (w == 0) {
             int m1, m2;
@@ -600,6 +656,7 @@ HDN void serve_request(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m
             m_st32(R->rec + y * N + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
         }
     }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->pad0_[3], (u32)wd_now()); hb_beat(); } }
     team_publish(&m->res_flag, seq);
 }
 
@@ -651,11 +708,10 @@ HD void encode_ctu() {
             decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
-        if (team && F.posted[1]) decide_remote(1, 16, y16, x16);
-        else decide_cu(1, 16, y16, x16, pack_avail(a16));
+        if (!(team && F.posted[1]) || decide_remote(1, 16, y16, x16)) decide_cu(1, 16, y16, x16, pack_avail(a16));
     }
     price_split(0, 32, 0, 0);
-    if (team && F.posted[0]) decide_remote(0, 32, 0, 0); else decide_cu(0, 32, 0, 0, pack_avail(a32));
+    if (!(team && F.posted[0]) || decide_remote(0, 32, 0, 0)) decide_cu(0, 32, 0, 0, pack_avail(a32));
 
     // ---- store the reconstruction, end_of_slice_segment_flag, hand the CTU's bytes over (:1625-1630)
     u8 *live_sink = J.out + F.out_pos;
@@ -700,7 +756,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
         NOUNROLL
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
         for (int i = tid; i < job.hdr_len; i += WG_THREADS) g_st8(job.out + i, g_ld8(hdr + i));
-        if (tid == 0) { F.job = job; F.sc = sc; F.out_pos = job.hdr_len; F.trace_n = 0; F.ctu_y = 0; F.ctu_x = 0; }
+        if (tid == 0) { F.job = job; F.sc = sc; F.out_pos = job.hdr_len; F.trace_n = 0; F.ctu_y = 0; F.ctu_x = 0; F.pace_mine = 0; F.pace_inc = 65536 / ((job.hp / 32) * (job.wp / 32)); }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
         if (l < PF_N) SM.prof[w][l] = 0;
 #endif
@@ -715,8 +771,27 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
     wg_sync();
     for (int cy = 0; cy < job.hp; cy += 32)
         for (int cx = 0; cx < job.wp; cx += 32) {
-            WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.ctu_y = cy; F.ctu_x = cx; } }
+            WAVES(w) LANES(l) {
+                if (w == 0 && l == 0) {
+                    F.ctu_y = cy; F.ctu_x = cx;
+                    if (F.mail) {
+                        if (m_ld32(&F.pq->abort) != 0u) F.aborted = 1;
+                        // Pace control.  The launch ends with its slowest frame, and on a full device a workgroup's speed depends on
+                        // the age of its waves (the older wave of a SIMD wins the issue arbitration, the guide's two-waves-per-SIMD
+                        // section: workgroups dispatched later run their frames up to 1.5x slower).  So every main workgroup compares the
+                        // share of its frame it has finished with the average over all of them, and one that lags more than a CTU and
+                        // a half runs at raised wave priority until it has caught up to within half a CTU (priority outranks age).
+                        if ((cy | cx) != 0) { F.pace_mine += F.pace_inc; m_add32(&F.pq->progress, (u32)F.pace_inc); }
+                        const int avg = (int)(m_ld32(&F.pq->progress) / (u32)F.pace_n), lag = avg - F.pace_mine;
+                        if (lag * 2 > 3 * F.pace_inc) F.prio_base = 2; else if (lag * 2 < F.pace_inc) F.prio_base = F.pace_base;
+                    }
+                }
+            }
             wg_sync();
+            if (F.aborted) return;                                    // (watchdog: the launch is being abandoned)
+#ifndef IMCVT_HOSTEMU
+            if (F.mail) { if (F.prio_base) SETPRIO(2); else SETPRIO(0); }
+#endif
             encode_ctu();
         }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
@@ -742,8 +817,14 @@ HD void stage_tables(const Tables *gT) {
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
     }
 }
-HDN void helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int nmains_, int home_, int role_) {
+// Returns -1 when every frame is finished, or the main-workgroup index this workgroup took over: an idle helper becomes a main
+// workgroup when frames wait in the queue and indices are left (fewer workgroups started as mains than there are frames to
+// encode at once — e.g. compute units that hold fewer workgroups of this launch than expected).
+HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int nmains_, int home_, int role_, int *counter_, int njobs_) {
     const Tables *const gT = uni_p(gT_); const ColdTables *const gK = uni_p(gK_); const FrameJob *const jobs = uni_p(jobs_); TeamMail *const mail = uni_p(mail_); PoolQ *const pq = uni_p(pq_); const int nmains = uni_i(nmains_); const int home = uni_i(home_); const int role = uni_i(role_);
+    int *const counter = uni_p(counter_); const int njobs = uni_i(njobs_);
+    int taken = -1, served = 0;
+    const int home_blk = home;
     stage_tables(gT);
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if ((threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
@@ -755,38 +836,63 @@ HDN void helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *j
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
                 int pick = -1, id = -1, round = 0, shard = home; u32 ticket = 0;
-                for (;;) {                                  // home shard first, then one other shard per round; 16x16 requests before 32x32 ones (their
-                    for (int pass = 0; pass < 2 && pick < 0; pass++) {      // main workgroups need the answers sooner)
+                hb_beat(); F.hb_last = 0;                   // (idle time is not a gap)
+                // Home shard first, then one other shard per round.  16x16 requests go before 32x32 ones (their main workgroups need the
+                // answers sooner) three times out of four: requests arrive in that ratio (four 16x16 CUs — three quarters of them
+                // offered — per 32x32 CU), and with a strict order a busy pool never got to the 32x32 queue: main workgroups were
+                // seen waiting seconds for an answer that takes a millisecond (profiles/r03l_wd_probe.log).
+                const int first = (served & 3) == 3 ? SLOT_32 : SLOT_16;
+                for (;;) {
+                    for (int pass = 0; pass < 2 && pick < 0; pass++) {
                         shard = pass == 0 ? home : (home + 1 + round % (POOL_SHARDS - 1)) % POOL_SHARDS;
                         PoolShard *q = &pq->sh[shard];
-                        for (int s_ = 0; s_ < MAIL_SLOTS && pick < 0; s_++) {
+                        for (int k_ = 0; k_ < MAIL_SLOTS && pick < 0; k_++) {
+                            const int s_ = k_ == 0 ? first : (first ^ 1);
                             const u32 h = m_ld32(&q->head[s_]), t = m_ld32(&q->tail[s_]);
-                            if ((i32)(t - h) > 0) { if (m_cas32(&q->head[s_], h, h + 1u)) { pick = s_; ticket = h; } else s_--; }   // lost the race for ticket h: look again
+                            if ((i32)(t - h) > 0) { if (m_cas32(&q->head[s_], h, h + 1u)) { pick = s_; ticket = h; } else k_--; }   // lost the race for ticket h: look again
                         }
                     }
-                    if (pick >= 0 || ((round & 3) == 3 && m_ld32(&pq->done) == (u32)nmains)) break;     // every main workgroup has left: no request can follow
+                    if (pick >= 0) break;
+                    if ((round & 3) == 3) {
+                        if (m_ld32(&pq->frames_done) == (u32)njobs || m_ld32(&pq->abort) != 0u) break;   // every frame is finished: no request can follow (or the watchdog fired)
+                        if (round >= 127 && (i32)m_ld32(counter) < njobs && m_ld32(&pq->mains_taken) < (u32)nmains) {
+                            // frames wait and a main-workgroup index is free: take it — unless this is the last helper (requests that
+                            // were posted while a helper was alive must find one)
+                            if (m_add32(&pq->alive, (u32)-1) <= 1u) m_add32(&pq->alive, 1u);
+                            else {
+                                const u32 m = m_add32(&pq->mains_taken, 1u);
+                                if (m < (u32)nmains) { id = (int)m; pick = -2; break; }
+                                m_add32(&pq->alive, 1u);
+                            }
+                        }
+                    }
                     mail_idle_pause(round++);
                 }
                 if (pick >= 0) {                            // the ticket's owner publishes its index right after taking the ticket
                     u32 *e = &pq->sh[shard].ring[pick][ticket % POOL_QCAP]; u32 v;
-                    while ((v = m_ld32(e)) == 0u) mail_poll_pause();
-                    m_st32(e, 0u);
-                    id = (int)v - 1;
+                    const unsigned long long t0 = wd_now();
+                    for (int n = 0; (v = m_ld32(e)) == 0u; n++) { if (wd_poll(pq, t0, n, 2, shard, (int)ticket)) break; mail_poll_pause(); }
+                    if (v == 0u) pick = -1;                 // (watchdog)
+                    else { m_st32(e, 0u); id = (int)v - 1; }
                 }
+                F.hb_last = wd_now();
                 SM.red[1] = pick; SM.red[2] = id;
             }
         }
         wg_sync();
         prof_add(PF_CTUIO, tidle);                          // (booked as "idle": waiting for a request)
         const int slot = SM.red[1], id = SM.red[2];
-        if (slot < 0) break;
+        if (slot < 0) { taken = slot == -2 ? id : -1; break; }
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&mail[id].s[slot].req_flag, 0x10000u | (u32)home_blk); m_st32(&mail[id].s[slot].pad0_[0], (u32)wd_now()); } }      // (debug: who took the request, when)
         serve_request(gK, jobs, &mail[id].s[slot]);
+        served++;
         wg_sync();
     }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if (sc.prof && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(role * NWAVES + (threadIdx.x >> 6)) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);
 #endif
     (void)role;
+    return taken;
 }
 
 // ---- kernel body (shared by the gfx950 kernel and the host emulation) -------------------------------------------------
@@ -795,7 +901,8 @@ struct KArgs {
     const Scratch *scr; int *counter; i32 *trace; int trace_cap; unsigned long long *prof;
     TeamMail *mail; PoolQ *pq;
     unsigned long long *fclk;                   // optional debug buffer, 4 words per frame: start clock, end clock (100 MHz), block, requests kept local
-    int lim16, lim32, prio;                     // pool tuning: unclaimed requests per shard beyond which a main workgroup keeps a CU (16x16 / 32x32); wave priority of the main workgroups
+    int post16, post32;                         // per mille of the 16x16 / 32x32 CUs a main workgroup offers to the helpers
+    int lim16, lim32, prio, quota;              // quota: workgroups per compute unit that start as main workgroups                     // pool tuning: unclaimed requests per shard beyond which a main workgroup keeps a CU (16x16 / 32x32); wave priority of the main workgroups
     int team_size, nteams, nhelp;               // team_size 1: every workgroup encodes whole frames alone; > 1: `nteams` main workgroups + a pool of `nhelp` helper workgroups
 };
 #ifdef IMCVT_HOSTEMU
@@ -827,26 +934,51 @@ HD void kernel_main(const KArgs &A, int block) {
         const unsigned long long now = wall_clock64();                  // 100 MHz: when the first and the last workgroup of the launch started
         atomicMin((unsigned long long *)(A.counter + 4), now); atomicMax((unsigned long long *)(A.counter + 6), now);
     }
-    struct Leave { int *c; __device__ ~Leave() { if (threadIdx.x == 0) atomicAdd(c + 2, -1); } } leave_{ A.counter };
+    struct Leave { int *c; unsigned long long *dbg; int blk; __device__ ~Leave() { if (threadIdx.x == 0) { atomicAdd(c + 2, -1);
+        if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
+    if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
-    const int role = (pool && block >= nm) ? 1 : 0, team = block;
     (void)tot;
+    // Roles are chosen when a workgroup starts, by where it landed: the first `quota` workgroups of the launch on a compute unit
+    // become main workgroups (while indices last), the others helpers — so every compute unit carries the same mix whatever
+    // order the dispatcher fills them in, and if fewer workgroups are resident than were launched it is helpers that are
+    // missing.  Nothing depends on a workgroup that is not running: a main workgroup posts requests only once a helper has
+    // reported in (helpers stay until every frame is finished, so what is posted is served) and evaluates the CUs itself until
+    // then; frames are pulled by whichever main workgroups run, and an idle helper takes a free main index when frames wait.
+    int team = block;
     Scratch sc = A.scr[block];
     sc.trace_cap = A.trace_cap; sc.prof = A.prof;
-    if (role != 0) {
-        sc.trace = (i32 *)0;
-        helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, (block - nm) % POOL_SHARDS, role);
-        return;
+    if (pool) {
+        WAVES(w) LANES(l) {
+            if (w == 0 && l == 0) {
+#ifdef IMCVT_HOSTEMU
+                const int key = block % POOL_CU_KEYS;
+#else
+                const int key = hw_cu_key() % POOL_CU_KEYS;
+#endif
+                int mid = -1;
+                if ((int)m_add32(&A.pq->cu_count[key], 1u) < A.quota && m_ld32(&A.pq->mains_taken) < (u32)nm) { const u32 m = m_add32(&A.pq->mains_taken, 1u); if (m < (u32)nm) mid = (int)m; }
+                SM.red[0] = mid;
+            }
+        }
+        wg_sync();
+        team = SM.red[0];
+        wg_sync();
+        if (team < 0) {
+            sc.trace = (i32 *)0;
+            team = helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, block % POOL_SHARDS, 1, A.counter, A.njobs);
+            if (team < 0) return;
+        }
     }
 #ifndef IMCVT_HOSTEMU
     // the main workgroup of a team carries the frame's critical path while its helpers have ~40 % slack: it wins the VALU
     // arbitration of the SIMDs it shares with them (measured: 320 teams 5.75 s -> 4.95 s, 256 teams 4.78 s -> 4.31 s)
-    if (pool && A.prio >= 2) __builtin_amdgcn_s_setprio(2);
+    if (pool && A.prio >= 2) SETPRIO(2);
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.prio_base = (pool && A.prio >= 2) ? 2 : 0; }
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = pool ? A.mail + team : (TeamMail *)0; F.pq = A.pq; F.main_id = team; F.lim[SLOT_16] = A.lim16; F.lim[SLOT_32] = A.lim32; F.posted[0] = 0; F.posted[1] = 0; F.seq[0] = 0; F.seq[1] = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.prio_base = (pool && A.prio >= 2) ? 2 : 0; F.pace_base = F.prio_base; F.pace_n = nm; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = pool ? A.mail + team : (TeamMail *)0; F.pq = A.pq; F.main_id = team; F.lim[SLOT_16] = A.lim16; F.lim[SLOT_32] = A.lim32; F.post_pm[SLOT_16] = A.post16; F.post_pm[SLOT_32] = A.post32; F.post_acc[SLOT_16] = 500; F.post_acc[SLOT_32] = 500; F.posted[0] = 0; F.posted[1] = 0; F.stale[0] = 0; F.stale[1] = 0; F.gaveup = 0; F.seq[0] = 0; F.seq[1] = 0; F.aborted = 0; } }
     // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
     // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)
     wg_sync();
@@ -857,15 +989,16 @@ HD void kernel_main(const KArgs &A, int block) {
         wg_sync();
         if (f >= A.njobs) break;
         sc.trace = (f == 0) ? A.trace : (i32 *)0;
-        WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.frame = f; F.kept = 0; } }
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.frame = f; F.kept = 0; F.waited = 0; F.waited_max = 0; } }
+        if (F.aborted) break;
 #ifndef IMCVT_HOSTEMU
         if (A.fclk && threadIdx.x == 0) A.fclk[4 * f] = wall_clock64();
 #endif
         encode_frame(A.gT, A.gK, A.jobs[f], sc, A.hdrs + (size_t)HDR_MAX * f);
+        if (pool) { WAVES(w) LANES(l) { if (w == 0 && l == 0) m_add32(&A.pq->frames_done, 1u); } }      // (every request of the frame has been answered)
 #ifndef IMCVT_HOSTEMU
-        if (A.fclk && threadIdx.x == 0) { A.fclk[4 * f + 1] = wall_clock64(); A.fclk[4 * f + 2] = (unsigned long long)block; A.fclk[4 * f + 3] = (unsigned long long)F.kept; }
+        if (A.fclk && threadIdx.x == 0) { A.fclk[4 * f + 1] = wall_clock64(); A.fclk[4 * f + 2] = (unsigned long long)block | (unsigned long long)hw_cu_key() << 32; A.fclk[4 * f + 3] = (unsigned long long)F.kept | (unsigned long long)(F.waited / 1000u) << 16 | (unsigned long long)(F.waited_max / 1000u) << 40; }
 #endif
     }
-    if (pool) { WAVES(w) LANES(l) { if (w == 0 && l == 0) m_add32(&A.pq->done, 1u); } }      // this main workgroup posts no further request
 }
 #undef F

@@ -17,16 +17,16 @@
 
 __global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int lim16, int lim32, int prio, unsigned long long *fclk) {
+                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
-    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio; A.fclk = fclk;
+    A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.post16 = post16; A.post32 = post32; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio; A.quota = quota; A.fclk = fclk;
     kernel_main(A, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
 struct imcvt_hevc_ctx {
-    int device = 0, max_wg = 0;
+    int device = 0, max_wg = 0, cus = 0;
     Tables *d_tables = nullptr; ColdTables *d_cold = nullptr;
     Scratch *d_scratch = nullptr;
     void *d_pool = nullptr;            // backing store of all per-workgroup scratch
@@ -41,6 +41,7 @@ struct imcvt_hevc_ctx {
     unsigned long long *d_prof = nullptr;   // [3 roles][NWAVES][PF_N] cycle totals (non-zero only in -DIMCVT_PROF builds)
     int force_team = 0;                     // 0: choose per launch; 1: no helpers; 2 / 3: one / two helper workgroups per main workgroup
     int force_mains = 0, force_help = 0;    // > 0: exactly this launch shape (debug / tuning)
+    int post16 = -1, post32 = -1;           // pool tuning: per mille of the 16x16 / 32x32 CUs offered to the helpers (IMCVT_POOL_POST16 / _POST32; < 0: from the launch shape)
     int lim16 = -1, lim32 = -1, prio = -1;  // pool tuning (IMCVT_POOL_LIM16 / _LIM32 / _PRIO; < 0: defaults from the launch shape)
     int last_mains = 0, last_help = 0;
 };
@@ -62,19 +63,32 @@ extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 3
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// A main workgroup posts a request only while fewer than this many requests of its kind wait unclaimed in its queue shard; beyond
-// that every helper is busy and the workgroup evaluates the CU itself (hevc_frame.h enter_cu).  With two helpers per main
-// workgroup a request never waits, and the limit is out of the way.
+// Balance of a launch with helpers.  Per CTU a main workgroup spends about 1.5 units on the 8x8 CUs (which it always walks itself)
+// where the candidate sets of the four 16x16 CUs and of the 32x32 CU cost about 1 unit each (cycle counters of round 2 and 3,
+// DESIGN.md §4).  With h helpers per main workgroup the shares x (16x16) and y (32x32) that are handed over should make both
+// sides finish together: 1.5 + (1 - x) + (1 - y) = (x + y) / h.  32x32 requests go first (their answers are needed last).
+// Returns the share of kind 0 (16x16) / 1 (32x32) per mille.
+static int pool_split(int nmains, int nhelp, int kind) {
+    if (nmains < 1 || nhelp < 1) return 0;
+    const double h = (double)nhelp / nmains, total = 3.5 * h / (1.0 + h);     // x + y
+    double y = total < 1.0 ? total : 1.0, x = total - y;
+    if (x > 1.0) x = 1.0;
+    const int v = (int)((kind == 0 ? x : y) * 1000.0 + 0.5);
+    return v < 0 ? 0 : v > 1000 ? 1000 : v;
+}
+// An offered CU is still kept while this many requests of its kind wait unclaimed in the main workgroup's queue shard (every
+// helper is busy and the queue is long): a safety net under the split above.
 static int pool_limit(int nmains, int nhelp, int kind) {
     if (nhelp >= 2 * nmains) return 1 << 20;
     const int per_shard = (nhelp + POOL_SHARDS - 1) / POOL_SHARDS;
-    const int v = kind == 0 ? per_shard / 4 : per_shard / 2;
+    const int v = kind == 0 ? per_shard / 2 : per_shard;
     return v > 1 ? v : 1;
 }
 static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp) {
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
                        (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
-                       c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), c->d_fclk);
+                       c->post16 >= 0 ? c->post16 : pool_split(nmains, nhelp, 0), c->post32 >= 0 ? c->post32 : pool_split(nmains, nhelp, 1),
+                       c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1), c->d_fclk);
 }
 
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
@@ -92,8 +106,11 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
             if (cur < need) (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, need < mx ? need : mx);
         } else (void)hipGetLastError();
     }
+    c->cus = prop.multiProcessorCount;
     c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
     if (const char *e = getenv("IMCVT_HEVC_TEAM")) imcvt_hevc_set_team(c, atoi(e));      // clamped to 0..3 like the API call
+    if (const char *e = getenv("IMCVT_POOL_POST16")) c->post16 = atoi(e);
+    if (const char *e = getenv("IMCVT_POOL_POST32")) c->post32 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_LIM16")) c->lim16 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_LIM32")) c->lim32 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_PRIO")) c->prio = atoi(e);
@@ -167,7 +184,7 @@ extern "C" int imcvt_hevc_last_shape(imcvt_hevc_ctx *c, int *nmains, int *nhelp)
 // walks only the 8x8 CUs itself (~4.1 s); the helper work of a frame is about as long as the main workgroup's own, so a pool as
 // large as the mains keeps up with them, and more than two helpers per main cannot be used (a main workgroup has at most one
 // request of each kind outstanding).  Every workgroup of the launch must be resident (helpers poll, mains wait for answers).
-//   n <= max_wg / 2       n mains, min(2 n, max_wg - n) helpers: one round
+//   n <= max_wg / 2       n mains, min(2 n, 15/16 max_wg - n) helpers: one round
 //   n <= 5 max_wg / 8     max_wg / 2 mains and as many helpers; the mains pull the remaining frames as they finish
 //   beyond                a frame per workgroup, max_wg of them, no helpers (the device is full either way and the hand-offs cost)
 // pure: the launch shape for n frames on a device that holds max_wg workgroups (force_team 0: choose; 1: no helpers; 2 / 3: one / two
@@ -190,7 +207,11 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         if ((long long)n * 8 > (long long)max_wg * 5) return 1;
         m = n < max_wg / 2 ? n : max_wg / 2;
         if (m < 1) return 1;
-        h = 2 * m < max_wg - m ? 2 * m : max_wg - m;
+        // (a sixteenth of the workgroup slots stays free: a device filled to the last slot by workgroups that wait for each other
+        // reacts badly to anything that takes a slot away for a moment — profiles/r03q_hb_probe.log — and starts slower)
+        const int room = max_wg - max_wg / 16 - m;
+        h = 2 * m < room ? 2 * m : room;
+        if (h < 1) return 1;
     }
     if (m > mail_cap) m = mail_cap;
     if (2 * m > POOL_SHARDS * POOL_QCAP) m = POOL_SHARDS * POOL_QCAP / 2;
@@ -205,6 +226,7 @@ static int pick_shape(const imcvt_hevc_ctx *c, int n, int *nmains, int *nhelp) {
     return imcvt_hevc_plan(n, c->max_wg, c->force_team, nmains, nhelp);
 }
 extern "C" void imcvt_hevc_set_pool_tuning(imcvt_hevc_ctx *c, int lim16, int lim32, int prio) { if (c) { c->lim16 = lim16; c->lim32 = lim32; c->prio = prio; } }
+extern "C" void imcvt_hevc_set_pool_split(imcvt_hevc_ctx *c, int post16, int post32) { if (c) { c->post16 = post16; c->post32 = post32; } }
 extern "C" void imcvt_hevc_set_shape(imcvt_hevc_ctx *c, int nmains, int nhelp) { if (c) { c->force_mains = nmains > 0 ? nmains : 0; c->force_help = nhelp > 0 ? nhelp : 0; } }
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
@@ -279,6 +301,41 @@ extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
     int v[2] = { 0, 0 };
     HIPCHK(hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost));
     return v[1];
+}
+
+// Waits for the context's last launch and reports how it ended: 0, or IMCVT_ERR_WATCHDOG when a wait between workgroups gave up
+// (hevc_frame.h wd_poll) — the launch's outputs are then invalid.
+extern "C" int imcvt_hevc_last_status(imcvt_hevc_ctx *c) {
+    if (!c) return IMCVT_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->timed) return 0;
+    HIPCHK(hipEventSynchronize(c->ev1));
+    if (c->last_help <= 0) return 0;
+    u32 v[16] = { 0 };
+    HIPCHK(hipMemcpy(v, &c->d_pq->abort, sizeof v, hipMemcpyDeviceToHost));
+    if (v[0] == 0) return 0;
+    fprintf(stderr, "imcvt_hevc: device watchdog: a %s gave up after %.0f s (slot/shard %u, seq/ticket %u, main workgroup %u, frame %d; launch %d + %d workgroups) — results invalid\n",
+            v[1] == 1 ? "main workgroup waiting for a helper's answer" : "helper waiting for a ticket's owner", (double)WD_TICKS / 1e8, v[2], v[3], v[4], (int)v[5], c->last_mains, c->last_help);
+    if (v[1] == 1) fprintf(stderr, "  when it gave up: its shard's queue of that kind had head %u tail %u; request flag %#x (0x1xxxx: taken by the helper with that home shard)\n", v[6], v[7], v[8]);
+    if (v[1] == 1) fprintf(stderr, "  clocks (ms before the watchdog fired): wait began %.2f, request taken %.2f, inputs staged %.2f, candidates evaluated %.2f, answer about to be published %.2f (stamps of an earlier request of this mailbox if larger than the wait)\n",
+                           (double)(i32)(v[13] - v[14]) / 1e5, (double)(i32)(v[13] - v[9]) / 1e5, (double)(i32)(v[13] - v[10]) / 1e5, (double)(i32)(v[13] - v[11]) / 1e5, (double)(i32)(v[13] - v[12]) / 1e5);
+    if (getenv("IMCVT_HEVC_VERBOSE")) {            // the queues as the watchdog left them
+        PoolQ *q = new PoolQ();
+        if (hipMemcpy(q, c->d_pq, sizeof(PoolQ), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "  frames_done %u alive %u mains_taken %u progress %u\n", q->frames_done, q->alive, q->mains_taken, q->progress);
+            for (int i = 0; i < POOL_SHARDS; i++) fprintf(stderr, "  shard %2d: 16x16 head %u tail %u | 32x32 head %u tail %u\n", i, q->sh[i].head[0], q->sh[i].tail[0], q->sh[i].head[1], q->sh[i].tail[1]);
+            if (v[1] == 1 && (int)v[4] < c->mail_cap && v[2] < MAIL_SLOTS) {
+                MailSlot *ms = new MailSlot();
+                if (hipMemcpy(ms, &c->d_mail[v[4]].s[v[2]], sizeof(MailSlot), hipMemcpyDeviceToHost) == hipSuccess)
+                    fprintf(stderr, "  its mailbox: request seq %d (op %d frame %d cy %d cx %d N %d y0 %d x0 %d), result flag %d\n", ms->req.seq, ms->req.op, ms->req.frame, ms->req.cy, ms->req.cx, ms->req.N, ms->req.y0, ms->req.x0, ms->res_flag);
+                const PoolShard &sh = q->sh[v[4] % POOL_SHARDS];
+                for (int k = 0; k < POOL_QCAP; k++) if (sh.ring[v[2]][k]) fprintf(stderr, "  its shard's ring[%u][%d] = %u\n", v[2], k, sh.ring[v[2]][k]);
+                delete ms;
+            }
+        }
+        delete q;
+    }
+    return IMCVT_ERR_WATCHDOG;
 }
 
 extern "C" int imcvt_hevc_last_resident(imcvt_hevc_ctx *c) {
@@ -414,6 +471,7 @@ extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, cons
         if (!d.ctx || d.idx.empty()) continue;
         const int m = (int)d.idx.size();
         if (hipSetDevice(d.dev) != hipSuccess || hipStreamSynchronize(d.st) != hipSuccess) { rc = rc ? rc : IMCVT_ERR_HIP; d.idx.clear(); continue; }
+        if (rc == 0) rc = imcvt_hevc_last_status(d.ctx);
         if (rc == 0 && hipMemcpy(d.lens.data(), d.slab + d.off_len, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) rc = IMCVT_ERR_HIP;
         for (int j = 0; j < m && rc == 0; j++) {
             const int i = d.idx[j], hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);

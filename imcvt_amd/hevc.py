@@ -20,13 +20,13 @@ LIB_PATH = os.environ.get("IMCVT_HEVC_LIB") or os.path.join(_HERE, "csrc", "libi
 _u8p = C.POINTER(C.c_ubyte)
 _ip = C.POINTER(C.c_int)
 
-ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error", -3: "bad argument"}
+ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error", -3: "bad argument", -4: "device watchdog: a wait between workgroups gave up, results invalid"}
 
 # every symbol include/imcvt_hevc.h declares
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan")
+           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -86,6 +86,8 @@ def load_library():
     lib.imcvt_hevc_debug_census.argtypes = [C.c_void_p, C.c_int]
     lib.imcvt_hevc_last_resident.restype = C.c_int
     lib.imcvt_hevc_last_resident.argtypes = [C.c_void_p]
+    lib.imcvt_hevc_last_status.restype = C.c_int
+    lib.imcvt_hevc_last_status.argtypes = [C.c_void_p]
     lib.imcvt_hevc_set_frame_clock.restype = None
     lib.imcvt_hevc_set_frame_clock.argtypes = [C.c_void_p, C.c_void_p]
     lib.imcvt_hevc_last_start_spread_us.restype = C.c_longlong
@@ -98,6 +100,8 @@ def load_library():
     lib.imcvt_hevc_set_shape.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.imcvt_hevc_set_pool_tuning.restype = None
     lib.imcvt_hevc_set_pool_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.imcvt_hevc_set_pool_split.restype = None
+    lib.imcvt_hevc_set_pool_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.imcvt_hevc_shutdown.restype = None
     lib.imcvt_hevc_shutdown.argtypes = []
     _lib = lib
@@ -200,6 +204,10 @@ class DeviceEncoder:
         """Debug / tuning: posting limits per queue shard and main-workgroup priority of launches with helpers (< 0: defaults)."""
         self.lib.imcvt_hevc_set_pool_tuning(self.ctx, int(lim16), int(lim32), int(prio))
 
+    def set_pool_split(self, post16: int = -1, post32: int = -1):
+        """Debug / tuning: per mille of the 16x16 / 32x32 CUs offered to the helpers (< 0: from the launch shape)."""
+        self.lib.imcvt_hevc_set_pool_split(self.ctx, int(post16), int(post32))
+
     def last_resident(self):
         """Most workgroups of the last launch that ran at the same time."""
         return int(self.lib.imcvt_hevc_last_resident(self.ctx))
@@ -251,10 +259,17 @@ class DeviceEncoder:
         return [[int(buf[w * k + i]) for i in range(k)] for w in range(n // k)]
 
     def last_kernel_ms(self) -> float:
-        return float(self.lib.imcvt_hevc_last_kernel_ms(self.ctx))
+        ms = float(self.lib.imcvt_hevc_last_kernel_ms(self.ctx))
+        self.status()
+        return ms
+
+    def status(self):
+        """Waits for the last launch; raises if its watchdog fired."""
+        _check(self.lib.imcvt_hevc_last_status(self.ctx), "imcvt_hevc_last_status")
 
     def results(self, batch):
         import torch
         torch.cuda.synchronize()
+        self.status()
         lens = batch["lens"].cpu().tolist()
         return [(batch["outs"][i][:lens[i]].cpu().numpy().tobytes(), batch["rcons"][i].cpu().numpy()) for i in range(batch["n"])]

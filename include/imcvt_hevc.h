@@ -22,6 +22,7 @@ extern "C" {
 #define IMCVT_ERR_NO_DEVICE  (-1)
 #define IMCVT_ERR_HIP        (-2)
 #define IMCVT_ERR_ARG        (-3)
+#define IMCVT_ERR_WATCHDOG   (-4)   /* a wait between cooperating workgroups on the device gave up: the launch was abandoned */
 
 /* ---------------------------------------------------------------------------------------------------
  * 1. Drop-in replacements
@@ -117,6 +118,9 @@ void imcvt_hevc_set_shape(imcvt_hevc_ctx *ctx, int nmains, int nhelp);
  * priority of the main workgroups.  Negative values return to the defaults derived from the launch shape.  Environment
  * overrides at context creation: IMCVT_POOL_LIM16, IMCVT_POOL_LIM32, IMCVT_POOL_PRIO.  Results do not depend on any of them. */
 void imcvt_hevc_set_pool_tuning(imcvt_hevc_ctx *ctx, int lim16, int lim32, int prio);
+/* Debug / tuning aid: per mille of the 16x16 / 32x32 CUs a main workgroup offers to the helpers (the rest it evaluates itself);
+ * negative: derived from the launch shape.  Environment overrides: IMCVT_POOL_POST16, IMCVT_POOL_POST32. */
+void imcvt_hevc_set_pool_split(imcvt_hevc_ctx *ctx, int post16, int post32);
 
 /* Kernel-only time of the last imcvt_hevc_encode_device call on this context, in milliseconds, from HIP
  * events recorded on the launch stream (synchronises that stream).  <0 if nothing was launched. */
@@ -125,6 +129,11 @@ float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *ctx);
 /* Debug aid: decision trace of frame 0 of the next launch (8 ints per CU: y, x, size, kind, mode(s), cost, 0, 0)
  * into a device buffer of cap ints; pass NULL to disable. */
 void imcvt_hevc_set_trace(imcvt_hevc_ctx *ctx, int *d_trace, int cap);
+
+/* Waits for the context's last launch and returns how it ended: 0, or IMCVT_ERR_WATCHDOG (one line on stderr) when a wait
+ * between cooperating workgroups exceeded 20 s and the launch was abandoned — its outputs are invalid.  The host-pointer entry
+ * points check this themselves; callers of imcvt_hevc_encode_device call it after synchronising. */
+int imcvt_hevc_last_status(imcvt_hevc_ctx *ctx);
 
 /* Debug aid: per-frame clocks of the next launches into a device buffer of 4 x n 64-bit words (start, end in 100 MHz ticks, block
  * index, CUs the main workgroup kept because the helpers were busy); NULL to disable. */

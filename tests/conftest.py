@@ -60,6 +60,13 @@ def hostemu_row(built):
     return _hostemu_lib("libhostemu_row.so", ["-DROWCAP=6"])
 
 
+@pytest.fixture(scope="session")
+def hostemu_abn(built):
+    """Same, with main workgroups that stop waiting for a helper's answer after three polls: exercises the path on which a late
+    answer is abandoned, the CU evaluated by the main workgroup itself and the mailbox left alone until the answer has arrived."""
+    return _hostemu_lib("libhostemu_abn.so", ["-DABANDON_POLLS=3"])
+
+
 def kat_entries():
     import json
     return json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json")))

@@ -153,7 +153,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     memset(pq, 0, sizeof(PoolQ));
     int counter[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     g_args.gT = &T; g_args.gK = &K; g_args.jobs = jobs; g_args.hdrs = hdrs; g_args.njobs = n; g_args.scr = sc; g_args.counter = counter;
-    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0;
+    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.post16 = 750; g_args.post32 = 1000; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0; g_args.quota = getenv("HOSTEMU_QUOTA") ? atoi(getenv("HOSTEMU_QUOTA")) : 1; g_args.fclk = nullptr;      // (quota 0: no workgroup starts as a main one — idle helpers take the roles)
     g_nfib = nwg * EMU_WG_THREADS; g_spins = 0;
     emu_run(emu_entry);
     for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); }

@@ -149,6 +149,27 @@ def test_rare_paths_on_the_device(amd, flag, tmp_path):
     assert r.returncode == 0 and "FAILURES: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+INL = "__device__ __forceinline__"
+
+
+@pytest.mark.parametrize("flags", [["-DHDN_BORDER=" + INL], ["-DHDN_EVAL=" + INL], ["-DHDN_BORDER=" + INL, "-DHDN_EVAL=" + INL]],
+                         ids=["borders-inlined", "candidate-sets-inlined", "both-inlined"])
+def test_results_do_not_depend_on_inlining(amd, flags, tmp_path):
+    """The border and candidate-set functions are out of line for code size only: built inline (either or both), the kernel
+    gives the same bytes.  (In round 2 inlining the border functions changed results: their wave-uniform arguments arrived in
+    vector registers and everything derived from them — branch conditions around the wave-level syncs included — was vector
+    code; the arguments are now moved to scalar registers on entry, uni_i / uni_p in hevc_core.h, and the branches are scalar.)"""
+    import subprocess, sys
+    from conftest import ROOT
+    so = str(tmp_path / "libimcvt_hevc_variant.so")
+    src = os.path.join(ROOT, "imcvt_amd", "csrc", "hevc_hip.hip")
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                    *flags, src, "-o", so], check=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity.py")], env=dict(os.environ, IMCVT_HEVC_LIB=so),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FAILURES: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_more_frames_than_workgroup_slots(amd):
     """A batch larger than the 1024 resident workgroups: the persistent workgroups keep pulling frames from the queue."""
     from oracle import oracle, synth

@@ -148,6 +148,30 @@ def test_pool_modes_match_golden(hostemu, q, nmains, nhelp):
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
 
 
+@pytest.mark.parametrize("nmains,nhelp", [(1, 1), (2, 2), (4, 1)])
+@pytest.mark.parametrize("q", [0, 3])
+def test_abandoned_answers_are_recomputed_by_the_main_workgroup(hostemu_abn, q, nmains, nhelp):
+    """A main workgroup that does not get an answer in time evaluates the CU itself and does not reuse the mailbox before the late
+    answer has landed (on the device: helpers held up by wave preemption).  Built to give up after three polls, so that most
+    requests are abandoned: same bytes."""
+    es = [e for e in OVF if e["qpd6"] == q] or [e for e in OVF][:2]
+    res = emu_encode_pool(hostemu_abn, [kat_input(e["input"]) for e in es], es[0]["qpd6"], nmains, nhelp)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
+def test_idle_helpers_take_over_as_main_workgroups(hostemu, monkeypatch):
+    """No workgroup starts as a main one (quota 0, as if every compute unit had filled up before this launch's workgroups arrived):
+    idle helpers take the free main indices, encode the frames and are served by the remaining helpers; same bytes."""
+    monkeypatch.setenv("HOSTEMU_QUOTA", "0")
+    es = [e for e in OVF if e["qpd6"] == 0]
+    res = emu_encode_pool(hostemu, [kat_input(e["input"]) for e in es], 0, 2, 3)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
 def test_pool_mode_natural_image(hostemu):
     # 10 x 9 CTUs of the reference's own sample picture: helpers read their borders from the reconstruction plane across CTU rows
     e = next(e for e in kat_entries() if e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] == 4)

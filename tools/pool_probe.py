@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """[developer check script — TEST INFRASTRUCTURE like tests/] Launch-shape probe: n frames of w x h at qpd6 q under a list of
 (mains, helpers) shapes; kernel ms per shape, digests compared between shapes (and with the first shape's).
-usage: pool_probe.py w h n q  m:h[:lim16:lim32:prio] ...      (0:0 = frames per workgroup, a:a = automatic)"""
+usage: pool_probe.py w h n q  m:h[:lim16:lim32:prio[:post16:post32]] ...      (0:0 = frames per workgroup, a:a = automatic)"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,7 @@ w, h, n, q = (int(a) for a in sys.argv[1:5])
 enc = imcvt_amd.DeviceEncoder()
 frames = [torch.from_numpy(synth.syn(w, h, s)).cuda() for s in range(n)]
 batch = enc.make_batch(frames, q)
-fclk = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
+fclk = torch.zeros(4 * n + 4 * 1024, dtype=torch.int64, device="cuda")
 enc.lib.imcvt_hevc_set_frame_clock(enc.ctx, fclk.data_ptr())
 ref = None
 for sh in sys.argv[5:]:
@@ -21,6 +21,7 @@ for sh in sys.argv[5:]:
         f = [int(v) for v in sh.split(":")]
         m, hp = f[0], f[1]
         enc.set_pool_tuning(*(f[2:5] if len(f) >= 5 else (-1, -1, -1)))
+        enc.set_pool_split(*(f[5:7] if len(f) >= 7 else (-1, -1)))
         if m == 0:
             enc.set_shape(0, 0); enc.set_team(1)
         else:
@@ -29,8 +30,17 @@ for sh in sys.argv[5:]:
     for _ in range(int(os.environ.get("PP_LAUNCHES", "2"))):
         enc.encode(batch); torch.cuda.synchronize(); ms.append(enc.last_kernel_ms()); resid.append((enc.last_resident(), enc.last_start_spread_us()))
         if os.environ.get("PP_VERBOSE"):
-            fc = fclk.cpu().numpy().reshape(n, 4); t0 = fc[:, 0].min()
+            allc = fclk.cpu().numpy(); fc = allc[:4 * n].reshape(n, 4).copy(); wg = allc[4 * n:].reshape(1024, 4); t0 = fc[:, 0].min()
+            gaps = [(int(wg[b, 0]) / 1e5, (int(wg[b, 1]) - int(t0)) / 1e5, int(wg[b, 2]) & 0xFFFF, int(wg[b, 2]) >> 32, b) for b in range(1024) if wg[b, 0] > 2e6]
+            if gaps: print('      workgroups with a heartbeat gap > 20 ms (gap ms, began at ms, cu key, main?, block): ' + ' '.join(f'({g[0]:.0f},{g[1]:.0f},{g[2]:#x},{g[3]},{g[4]})' for g in sorted(gaps, reverse=True)[:24]), flush=True)
             end = (fc[:, 1] - t0) / 1e5; start = (fc[:, 0] - t0) / 1e5; late = int(end.argmax())
+            import collections
+            keys = collections.Counter((fc[:, 2] >> 32).tolist())
+            print(f"      main workgroups ran on {len(keys)} compute units; frames per compute unit: {sorted(collections.Counter(keys.values()).items())}", flush=True)
+            fc[:, 2] &= 0xFFFFFFFF
+            waited = ((fc[:, 3] >> 16) & 0xFFFFFF) / 100.0; wmax = (fc[:, 3] >> 40) / 100.0; fc[:, 3] &= 0xFFFF
+            top = sorted(range(n), key=lambda i: -((fc[i, 1] - t0)))[:4]
+            print("      slowest frames: " + "; ".join(f"f{i} blk {fc[i, 2]} end {(fc[i, 1] - t0) / 1e5:.0f} ms waited {waited[i]:.0f} ms (longest {wmax[i]:.1f})" for i in top) + f" | median waited {sorted(waited)[n // 2]:.0f} ms, longest wait anywhere {wmax.max():.1f} ms", flush=True)
             print(f"      launch {ms[-1]:.1f} ms resident/start-spread-us {resid[-1]}  frame ends ms: median {float(sorted(end)[n // 2]):.0f} max {end.max():.0f} (frame {late}: block {fc[late, 2]}, started {start[late]:.0f}, kept {fc[late, 3]}); started late (>100 ms): {int((start > 100).sum())}; kept per frame median {sorted(fc[:, 3])[n // 2]} max {fc[:, 3].max()}", flush=True)
         if os.environ.get("PP_PROF"):                      # -DIMCVT_PROF build: G-cycles per role summed over the launch's waves
             pr = enc.debug_prof(True); cats = enc.PROF_CATS
