@@ -196,20 +196,19 @@ JD int uclamp(int v, int lo, int hi) {
     return t;
 }
 #endif
+// The chain itself only carries the context: it hands out, per sample, what the code word is made from — A and N before the
+// update (A < 2^15, N <= 64), the 8-bit error and the test of :366 on B and N — packed in one word; the code word
+// (regular_word below) is computed where it is consumed, by the per-pixel kernels k6 / k7, off the chain.
+//     state word: A | N << 16 | (e & 255) << 23 | (2 B <= -N) << 31
 JD uint32_t regular_step(const Par &p, Ctx &r, uint32_t el) {
+    (void)p;
     const int v = (int)(el & 255), med = (int)((el >> 8) & 255), m = -(int)((el >> 16) & 1);      // m = -1 for the negative sign
     const int pred = uclamp(med + ((r.c ^ m) - m), 0, 255);                                        // med + sign * C (:349-350)
     int e = v - pred;
     e = (e ^ m) - m;                                                                               // sign * (x - px)
-    e = ((e + 128) & 255) - 128;                                                                   // modRange, qbeta = 256
-    const int ae = iabs(e), neg = (int)((uint32_t)e >> 31);
-    const int k = golomb_k_nb(r.a, r.n);
-    const int map = (k == 0) & (2 * r.b <= -r.n);                                                  // :366
-    const int me = 2 * ae + map - neg * (2 * map + 1);                                             // :367-372: e < 0 ? 2|e| - map - 1 : 2|e| + map
-    const int zeros = me >> k, esc = zeros >= p.limit;
-    const uint32_t val_n = (1u << k) | ((uint32_t)me & ((1u << k) - 1u)), val_e = 256u | ((uint32_t)(me - 1) & 255u);
-    const uint32_t word_n = val_n | (uint32_t)(zeros + 1 + k) << 24, word_e = val_e | (uint32_t)(p.limit + 1 + 8) << 24;   // :187-197 (qbpp = 8)
-    const uint32_t word = word_n ^ ((word_n ^ word_e) & (uint32_t)-esc);                           // (a select without a branch)
+    e = (int)(int8_t)e;                                                                            // modRange with qbeta = 256 (:105-111) is the sign extension of the low byte
+    const int ae = iabs(e);
+    const uint32_t st = (uint32_t)r.a | (uint32_t)r.n << 16 | ((uint32_t)e & 255u) << 23 | (uint32_t)(2 * r.b <= -r.n) << 31;
     const int rs = r.n >> 6;                                                                       // N >= 64 (N never exceeds 64): :376-381
     int B = (r.b + e) >> rs, N = (r.n >> rs) + 1;
     r.a = (r.a + ae) >> rs;
@@ -218,7 +217,19 @@ JD uint32_t regular_step(const Par &p, Ctx &r, uint32_t el) {
     B = lo ? b_lo : hi ? b_hi : B;
     r.c = uclamp(r.c + hi - lo, -128, 127);
     r.b = B; r.n = N;
-    return word;
+    return st;
+}
+// code word (value | length << 24) of a regular-mode sample from its state word (:363-375, :187-197 with qbpp = 8)
+JD uint32_t regular_word(const Par &p, uint32_t st) {
+    const int a = (int)(st & 0xFFFFu), n = (int)((st >> 16) & 127u), e = (int)(int8_t)(st >> 23), nb = (int)(st >> 31);
+    const int ae = iabs(e), neg = (int)((uint32_t)e >> 31);
+    const int k = golomb_k_nb(a, n);
+    const int map = (k == 0) & nb;                                                                 // :366
+    const int me = 2 * ae + map - neg * (2 * map + 1);                                             // :367-372: e < 0 ? 2|e| - map - 1 : 2|e| + map
+    const int zeros = me >> k, esc = zeros >= p.limit;
+    const uint32_t val_n = (1u << k) | ((uint32_t)me & ((1u << k) - 1u)), val_e = 256u | ((uint32_t)(me - 1) & 255u);
+    const uint32_t word_n = val_n | (uint32_t)(zeros + 1 + k) << 24, word_e = val_e | (uint32_t)(p.limit + 1 + 8) << 24;
+    return esc ? word_e : word_n;
 }
 
 // ---- k5: one thread per chain.  t < 364: regular context t; t == 364: the run chain
@@ -283,7 +294,7 @@ JD void k5_chain(const ParPlane &P, long t) {
 JD void k6_len(const ParPlane &P, long t) {
     const int cl = P.cls[t];
     int n = 0;
-    if (cl == CL_REG) n = (int)(P.code[P.pos[t]] >> 24);
+    if (cl == CL_REG) n = (int)(regular_word(make_par(0), P.code[P.pos[t]]) >> 24);
     else if (cl != CL_RUN) { const uint32_t e = P.pos[t]; n = (int)P.evout[3 * e] + (int)(P.evout[3 * e + 1] >> 24) + (int)(P.evout[3 * e + 2] >> 24); }
     P.len[t] = (uint8_t)n;
 }
@@ -322,7 +333,7 @@ JD void k7_pack(const ParPlane &P, long t) {
     const int cl = P.cls[t];
     if (cl == CL_RUN || P.len[t] == 0) return;
     unsigned long long at = P.rowbits[t / P.w] + P.bitpos[t];
-    if (cl == CL_REG) { const uint32_t c = P.code[P.pos[t]]; put_at(P, at, c & 0xFFFFFFu, (int)(c >> 24)); return; }
+    if (cl == CL_REG) { const uint32_t c = regular_word(make_par(0), P.code[P.pos[t]]); put_at(P, at, c & 0xFFFFFFu, (int)(c >> 24)); return; }
     const uint32_t e = P.pos[t];
     const int ones = (int)P.evout[3 * e];
     put_at(P, at, ones >= 32 ? 0xFFFFFFFFu : (1u << ones) - 1u, ones); at += ones;
