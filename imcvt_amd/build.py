@@ -9,6 +9,18 @@ DEPS = ["hevc_hip.hip", "hevc_core.h", "hevc_frame.h", "hevc_tables.h", os.path.
 OUT = os.path.join(CSRC, "libimcvt_hevc.so")
 
 
+def _run_to(cmd, out):
+    """Run a compile/link command whose output path is `out` through a private temporary file and rename it into place:
+    concurrent builders (pytest -n) never see, execute or overwrite a half-written binary."""
+    tmp = f"{out}.tmp.{os.getpid()}"
+    try:
+        subprocess.run([*cmd, "-o", tmp], check=True)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
@@ -23,8 +35,8 @@ JLS_DEPS = ["jls_hip.hip", "jls_core.h", os.path.join("..", "..", "include", "im
 def build_jls(force: bool = False) -> str:
     if force or not os.path.exists(JLS_OUT) or any(os.path.getmtime(os.path.join(CSRC, d)) > os.path.getmtime(JLS_OUT) for d in JLS_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                        os.path.join(CSRC, "jls_hip.hip"), "-o", JLS_OUT], check=True)
+        _run_to([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                 os.path.join(CSRC, "jls_hip.hip")], JLS_OUT)
     return JLS_OUT
 
 
@@ -41,9 +53,9 @@ def build_host(force: bool = False) -> str:
     deps = srcs + [OUT, JLS_OUT, os.path.join(CSRC, "..", "..", "include", "imcvt_hevc.h")]
     stale = lambda o: force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps)
     if stale(PNM_SO):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *srcs[1:], "-o", PNM_SO], check=True)
+        _run_to(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *srcs[1:]], PNM_SO)
     if stale(CLI):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-DIMCVT_WITH_JLS", *srcs, "-L" + CSRC, "-limcvt_hevc", "-limcvt_jls", "-Wl,-rpath,$ORIGIN", "-o", CLI], check=True)
+        _run_to(["g++", "-O2", "-std=c++17", "-DIMCVT_WITH_JLS", *srcs, "-L" + CSRC, "-limcvt_hevc", "-limcvt_jls", "-Wl,-rpath,$ORIGIN"], CLI)
     return CLI
 
 
@@ -53,10 +65,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           *[os.path.join(CSRC, s) for s in SRC], "-o", OUT]
+           *[os.path.join(CSRC, s) for s in SRC]]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True)
+    _run_to(cmd, OUT)
     build_host(force=True)
     return OUT
 

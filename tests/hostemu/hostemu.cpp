@@ -72,8 +72,40 @@ static int emu_shfl(int v, int src_lane) {                  // value of `v` held
     emu_wave_sync();
     return r;
 }
+// Matrix instructions (wave collectives): every lane deposits its operand registers, then computes the result registers
+// the hardware would hand it.  Layouts as verified on the device by tools/mfma_probe.hip.
+static uint32_t g_mx[3 * EMU_MAX_WG][64][8];                // per lane: a[0..3], b[0..3]
+static int emu_sx8(uint32_t w, int k) { return (int)(int8_t)(w >> (8 * k)); }
+// v_mfma_i32_32x32x32_i8: lane l holds A[l%32][16*(l/32) .. +15], B[16*(l/32) .. +15][l%32]; acc r: D[8*(r/4) + 4*(l/32) + r%4][l%32]
+static void emu_mfma32(const uint32_t *a, const uint32_t *b, int *acc) {
+    const int w = g_cur >> 6, l = g_cur & 63, i = l & 31, h = l >> 5;
+    for (int d = 0; d < 4; d++) { g_mx[w][l][d] = a[d]; g_mx[w][l][4 + d] = b[d]; }
+    emu_wave_sync();
+    for (int r = 0; r < 16; r++) {
+        const int m = 8 * (r / 4) + 4 * h + r % 4;
+        int s = 0;
+        for (int hh = 0; hh < 2; hh++) for (int e = 0; e < 16; e++)
+            s += emu_sx8(g_mx[w][m + 32 * hh][e / 4], e % 4) * emu_sx8(g_mx[w][i + 32 * hh][4 + e / 4], e % 4);
+        acc[r] += s;
+    }
+    emu_wave_sync();
+}
+// v_mfma_i32_16x16x32_i8: lane l holds A[l%16][8*(l/16) .. +7], B[8*(l/16) .. +7][l%16]; acc r: D[4*(l/16) + r][l%16]
+static void emu_mfma16(const uint32_t *a, const uint32_t *b, int *acc) {
+    const int w = g_cur >> 6, l = g_cur & 63, i = l & 15, h = l >> 4;
+    for (int d = 0; d < 2; d++) { g_mx[w][l][d] = a[d]; g_mx[w][l][4 + d] = b[d]; }
+    emu_wave_sync();
+    for (int r = 0; r < 4; r++) {
+        const int m = 4 * h + r;
+        int s = 0;
+        for (int hh = 0; hh < 4; hh++) for (int e = 0; e < 8; e++)
+            s += emu_sx8(g_mx[w][m + 16 * hh][e / 4], e % 4) * emu_sx8(g_mx[w][i + 16 * hh][4 + e / 4], e % 4);
+        acc[r] += s;
+    }
+    emu_wave_sync();
+}
 struct Shm;
-static Shm *g_shm_of[EMU_MAX_WG];                           // each emulated workgroup's LDS image
+static Shm *g_shm_of[EMU_MAX_WG];                          // each emulated workgroup's LDS image
 static long g_spins;
 static void emu_set_shm(int wg);                            // (defined below, next to the device source's LDS pointer)
 static void emu_trampoline() {

@@ -46,6 +46,15 @@ __global__ void k16x16x64(const int8_t *A, const int8_t *B, int *D) {
     c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
     for (int r = 0; r < 4; r++) D[(4 * h + r) * 16 + i] = c[r];
 }
+//   16x16x32 (v_mfma_i32_16x16x32_i8): lane l holds A[l%16][8*(l/16) .. +7], B[8*(l/16) .. +7][l%16] (one i64 each); result as 16x16x64
+__global__ void k16x16x32(const int8_t *A, const int8_t *B, int *D) {
+    const int l = threadIdx.x, i = l & 15, h = l >> 4;
+    long a = 0, b = 0;
+    for (int t = 0; t < 8; t++) { a |= (long)(uint8_t)A[i * 32 + 8 * h + t] << (8 * t); b |= (long)(uint8_t)B[(8 * h + t) * 16 + i] << (8 * t); }
+    v4i c = {0};
+    c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; r++) D[(4 * h + r) * 16 + i] = c[r];
+}
 static int check(const char *name, int M, int N, int K, void (*launch)(const int8_t *, const int8_t *, int *)) {
     int8_t *hA = (int8_t *)malloc(M * K), *hB = (int8_t *)malloc(K * N); int *hD = (int *)malloc(M * N * 4), *ref = (int *)malloc(M * N * 4);
     unsigned s = 12345; for (int i = 0; i < M * K; i++) { s = s * 1664525u + 1013904223u; hA[i] = (int8_t)(s >> 24); }
@@ -65,5 +74,6 @@ int main() {
     bad += check("v_mfma_i32_32x32x16_i8", 32, 32, 16, [](const int8_t *a, const int8_t *b, int *d) { hipLaunchKernelGGL(k32x32x16, 1, 64, 0, 0, a, b, d); });
     bad += check("v_mfma_i32_32x32x32_i8", 32, 32, 32, [](const int8_t *a, const int8_t *b, int *d) { hipLaunchKernelGGL(k32x32x32, 1, 64, 0, 0, a, b, d); });
     bad += check("v_mfma_i32_16x16x64_i8", 16, 16, 64, [](const int8_t *a, const int8_t *b, int *d) { hipLaunchKernelGGL(k16x16x64, 1, 64, 0, 0, a, b, d); });
+    bad += check("v_mfma_i32_16x16x32_i8", 16, 16, 32, [](const int8_t *a, const int8_t *b, int *d) { hipLaunchKernelGGL(k16x16x32, 1, 64, 0, 0, a, b, d); });
     return bad != 0;
 }
