@@ -660,6 +660,47 @@ HD void pred_block4(const Tables &T, const BorderRef &b, int N, int lg, int mode
     }
 }
 
+// Prediction of the vertical strip (y0 .. y0+3, x) of an N x N predictor, packed one sample per byte (row y0 + t in byte t):
+// the layout of the matrix-core passes (a lane owns a column and four-row strips of it).  `mode` is wave-uniform there.
+HD u32 pred_strip4(const Tables &T, const BorderRef &b, int N, int lg, int mode, int y0, int x) {
+    const int f = uses_filtered(N, mode);
+    const u8 *L = f ? b.fl : b.ul, *A = f ? b.fa : b.ua;
+    const int corner = f ? b.fc : b.uc;
+    int v[4];
+    if (mode == 0) {
+        const int ax = A[x], ln = L[N], base = mul24(x + 1, A[N]) + N;
+        for (int t = 0; t < 4; t++) { const int y = y0 + t; v[t] = (mul24(N - 1 - x, L[y]) + base + mul24(N - 1 - y, ax) + mul24(y + 1, ln)) >> (lg + 1); }
+    } else if (mode == 1) {
+        const int dc = b.dc;
+        for (int t = 0; t < 4; t++) v[t] = dc;
+        if (N <= 16) {
+            if (x == 0) for (int t = 0; t < 4; t++) v[t] = (2 + 3 * dc + L[y0 + t]) >> 2;
+            if (y0 == 0) v[0] = (x == 0) ? (2 + 2 * dc + L[0] + A[0]) >> 2 : (2 + 3 * dc + A[x]) >> 2;
+        }
+    } else if (mode == 10) {
+        for (int t = 0; t < 4; t++) v[t] = L[y0 + t];
+        if (N <= 16 && y0 == 0) v[0] = clip3(((A[x] - corner) >> 1) + L[0], 0, 255);
+    } else if (mode == 26) {
+        const int ax = A[x];
+        for (int t = 0; t < 4; t++) v[t] = ax;
+        if (N <= 16 && x == 0) for (int t = 0; t < 4; t++) v[t] = clip3(((L[y0 + t] - corner) >> 1) + A[0], 0, 255);
+    } else {
+        const int ang = (int)T.ang[mode] - 32, iang = T.iang[mode];
+        if (mode < 18) {                                          // horizontal family: the angle term belongs to the column
+            const int off = mul24(ang, x + 1), oi = off >> 5, of = off & 31, t0 = oi + y0 + 1;
+            int p[5];
+            for (int k = 0; k < 5; k++) p[k] = ref_line(L, A, corner, iang, t0 + k);
+            for (int t = 0; t < 4; t++) v[t] = (mul24(32 - of, p[t]) + mul24(of, p[t + 1]) + 16) >> 5;
+        } else {                                                  // vertical family: one angle term per row
+            for (int t = 0; t < 4; t++) {
+                const int off = mul24(ang, y0 + t + 1), oi = off >> 5, of = off & 31, t1 = oi + x + 1;
+                v[t] = (mul24(32 - of, ref_line(A, L, corner, iang, t1)) + mul24(of, ref_line(A, L, corner, iang, t1 + 1)) + 16) >> 5;
+            }
+        }
+    }
+    return (u32)v[0] | (u32)v[1] << 8 | (u32)v[2] << 16 | (u32)v[3] << 24;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Border assembly
 // ---------------------------------------------------------------------------------------------------
@@ -858,6 +899,82 @@ HD void mac_YM16(int acc[4][4], const i16 *Y, const i8 *C, int row0, int col0, i
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The N = 16 / 32 transforms on the matrix cores (:469-516, matrices :391-464).
+// i8 x i8 -> i32 matrix instructions are exact, so every stage is an integer product whose wider operand is cut into i8
+// limbs (layouts verified on the device by tools/mfma_probe.hip):
+//   forward 1   tmp  = (C (O - P) + r) >> a       O - P = (O - 128) + (127 - P) + 1: two products with i8 operands
+//                                                 (O ^ 0x80, P ^ 0x7F) and the row sums of C (64 N in row 0, else 0)
+//   forward 2   coef = tmp C^T + r                tmp (17 bits + sign) = l0 + 256 l1 + 65536 l2, limbs signed: the bytes of
+//                                                 tmp + 0x8080 with the low two XOR 0x80 (the bias rides in stage 1's rounding constant)
+//   inverse 1/2 X (i16) = 256 hi + (lo - 128) + 128: hi = the high byte as it is, lo ^ 0x80, and 128 x the column sums of C
+// Limbs are chained Horner-wise through the accumulator (acc = (acc << 8) + constant between the products).
+// A lane (i, h) of the wave owns column / row i and the reduction slots rows(h): for N = 32 (v_mfma_i32_32x32x32_i8, i = l % 32,
+// h = l / 32) the rows 8 j + 4 h + t — register 4 j + t, byte t of operand dword j; for N = 16 (v_mfma_i32_16x16x32_i8 with the
+// upper half of the reduction zero, i = l % 16, h = l / 16) the rows 4 h + t of each of the pass's four candidates — register
+// 4 slot + t, operand dword `slot`.  The results of one stage are the operand slots of the next, so tmp and the inverse's
+// intermediate never leave the registers; prediction, reconstruction and SSE are computed in the same layout (column i, the
+// lane's rows).  Only the coefficients travel through LDS (to the lanes that own the 4x4 coefficient groups: RDOQ, tokens)
+// and the dequantised levels back (as byte limbs, column-major).
+// ---------------------------------------------------------------------------------------------------
+#ifndef P1_MFMA
+#define P1_MFMA 1            // 0: the N = 16 / 32 transforms as vector code like N = 8 (A/B measurements, tests)
+#endif
+#ifdef IMCVT_HOSTEMU
+static void emu_mfma32(const u32 *a, const u32 *b, int *acc);
+static void emu_mfma16(const u32 *a, const u32 *b, int *acc);
+HD void mfma32(int acc[16], const u32 a[4], const u32 b[4]) { emu_mfma32(a, b, acc); }
+HD void mfma16(int acc[4], u32 a, u32 b) { const u32 aa[2] = { a, 0 }, bb[2] = { b, 0 }; emu_mfma16(aa, bb, acc); }
+HD u32 perm_b32(u32 hi, u32 lo, u32 sel) {          // v_perm_b32 with selectors 0..7
+    const u64 v = (u64)hi << 32 | lo; u32 r = 0;
+    for (int k = 0; k < 4; k++) r |= (u32)((v >> (8 * ((sel >> (8 * k)) & 7))) & 255) << (8 * k);
+    return r;
+}
+#else
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+HD void mfma32(int acc[16], const u32 a[4], const u32 b[4]) {
+    v4i_t A, B; v16i_t Cc;
+    for (int d = 0; d < 4; d++) { A[d] = (int)a[d]; B[d] = (int)b[d]; }
+    for (int r = 0; r < 16; r++) Cc[r] = acc[r];
+    Cc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, Cc, 0, 0, 0);
+    for (int r = 0; r < 16; r++) acc[r] = Cc[r];
+}
+HD void mfma16(int acc[4], u32 a, u32 b) {
+    v4i_t Cc;
+    for (int r = 0; r < 4; r++) Cc[r] = acc[r];
+    Cc = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(u64)a, (long)(u64)b, Cc, 0, 0, 0);
+    for (int r = 0; r < 4; r++) acc[r] = Cc[r];
+}
+HD u32 perm_b32(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#endif
+// acc (16 registers) += a x b: one 32x32x32 product, or the 16x16 products of the pass's live candidates (slots 0 .. nlive-1)
+template <int LG>
+HD void mx_mm(int acc[16], const u32 a[4], const u32 b[4], int nlive) {
+    if constexpr (LG == 5) mfma32(acc, a, b);
+    else for (int sl = 0; sl < 4; sl++) if (sl < nlive) mfma16(acc + 4 * sl, a[sl], b[sl]);
+}
+// byte k of the four values of a register group -> one operand dword per limb
+#define SEL_PAIR 0x05010400u     // perm(v1, v0): v0.b0 v1.b0 v0.b1 v1.b1
+#define SEL_PAIR2 0x05010602u    // perm(v1, v0): v0.b2 v1.b2 (then bytes that are not used)
+#define SEL_LO 0x05040100u       // perm(Y, X): X.b0 X.b1 Y.b0 Y.b1
+#define SEL_HI 0x07060302u       // perm(Y, X): X.b2 X.b3 Y.b2 Y.b3
+// v = x + 0x8080 with x in 17 bits + sign: x = l0 + 256 l1 + 65536 l2
+HD void mx_limbs3(const int v[16], u32 l0[4], u32 l1[4], u32 l2[4]) {
+    for (int d = 0; d < 4; d++) {
+        const u32 X = perm_b32((u32)v[4 * d + 1], (u32)v[4 * d], SEL_PAIR), Y = perm_b32((u32)v[4 * d + 3], (u32)v[4 * d + 2], SEL_PAIR);
+        l0[d] = perm_b32(Y, X, SEL_LO) ^ 0x80808080u; l1[d] = perm_b32(Y, X, SEL_HI) ^ 0x80808080u;
+        const u32 X2 = perm_b32((u32)v[4 * d + 1], (u32)v[4 * d], SEL_PAIR2), Y2 = perm_b32((u32)v[4 * d + 3], (u32)v[4 * d + 2], SEL_PAIR2);
+        l2[d] = perm_b32(Y2, X2, SEL_LO);
+    }
+}
+// four i16 values (in i32 registers): w = 256 hi + (lo - 128) + 128
+HD void mx_limbs2(int w0, int w1, int w2, int w3, u32 &lo, u32 &hi) {
+    const u32 X = perm_b32((u32)w1, (u32)w0, SEL_PAIR), Y = perm_b32((u32)w3, (u32)w2, SEL_PAIR);
+    lo = perm_b32(Y, X, SEL_LO) ^ 0x80808080u; hi = perm_b32(Y, X, SEL_HI);
+}
+HD int sum_bytes_i8(u32 w) { return sx8(w, 0) + sx8(w, 1) + sx8(w, 2) + sx8(w, 3); }
 
 // quantiser constants of one (size, qpd6) pair (:546-554, :606-608)
 struct QConst { int sh, add, dmax, thr, dq, dqs; RdW rw; };
@@ -1476,10 +1593,34 @@ HD void p1_run_t(int wave, const P1Args &P) {
     // the 4-element column index XOR-ed by the block-row (writers and readers of a row agree on its block-row).
     constexpr int TR = NN + (N == 8 ? 4 : N == 16 ? 16 : 0), TT = NN + (N == 8 ? 4 : 0), TI = NN + (N == 8 ? 4 : N == 16 ? 4 : 0);
     static_assert(G * TR * 2 <= P1_RES_BYTES && G * TT * 4 <= 7168 - P1_RES_BYTES && G * TI * 2 <= G * TT * 4, "pass buffer");
+    // matrix-core passes (N = 16, 32; see mx_mm above).  Pass buffer: the coefficients as i32 rows of CST dwords per candidate
+    // (stage 2 -> group lanes), later the dequantised levels as two byte-limb tiles per candidate, column-major, DCS bytes per
+    // column (group lanes -> inverse stage 1).  The strides keep the 16-lane groups of a b128 access / the 32 lanes of a b32 access on distinct banks.
+    constexpr bool MX = P1_MFMA && LG >= 4;
+    constexpr int MI = MX ? N - 1 : 63, MHS = MX ? LG : 6;                    // lane -> (i, h) of the matrix layout
+    constexpr int CST = N + 4, CTILE = N * CST, DCS = N + 4, DTILE = N * DCS;
+    static_assert(!MX || (G * CTILE * 4 <= 7168 && G * 2 * DTILE <= 7168), "pass buffer (matrix-core layout)");
 
+    LANES(l) {
+      // loop-invariant operands of the matrix-core passes: this lane's strips of the source column (as O - 128), column i of C
+      // restricted to the lane's rows (the inverse stages' operand) and 128 x the sum of that whole column (limb bias)
+      const int mi = l & MI, mh = l >> MHS;
+      u32 oq[4] = { 0, 0, 0, 0 }, ccol[4] = { 0, 0, 0, 0 };
+      int cs128 = 0;
+      if constexpr (MX) {
+          for (int d = 0; d < (LG == 5 ? 4 : 1); d++) {
+              const int yb = (LG == 5 ? 8 * d : 0) + 4 * mh;
+              u32 ow = 0, cw = 0;
+              for (int t = 0; t < 4; t++) { ow |= (u32)SM.org[P.y0 + yb + t][P.x0 + mi] << (8 * t); cw |= (u32)(u8)C[(yb + t) * N + mi] << (8 * t); }
+              oq[d] = ow ^ 0x80808080u; ccol[d] = cw; cs128 += sum_bytes_i8(cw);
+          }
+          if constexpr (LG == 4) { oq[1] = oq[2] = oq[3] = oq[0]; ccol[1] = ccol[2] = ccol[3] = ccol[0]; cs128 += wave_shfl(cs128, l ^ 16); }
+          cs128 += wave_shfl(cs128, l ^ 32);
+          cs128 *= 128;
+      }
     NOUNROLL
     for (int c0 = P.c_lo; c0 < ncand; c0 += G) {
-      LANES(l) {
+      {
         // lane <-> coefficient group: slot sl of this pass, group of scan rank r of that candidate's TU
         const int sl = l / lpc, r = l % lpc, c = c0 + sl, live = c < ncand;
         const int mode = (P.only_mode >= 0) ? P.only_mode : (live ? c : 0);
@@ -1490,6 +1631,44 @@ HD void p1_run_t(int wave, const P1Args &P) {
         const int tokn0 = (P.tok && live) ? WO.tokn[c] : 0;
         u32 predw[4] = { 0, 0, 0, 0 };                  // this lane's 4x4 block of the prediction, a packed row per dword (kept in registers until step 5)
         MARK("pass_setup");
+        u32 pq[4] = { 0, 0, 0, 0 };                     // matrix-core passes: this lane's strips of the prediction (a sample per byte)
+        if constexpr (MX) {
+            // ---- steps 1-3a on the matrix cores: prediction in the operand layout, tmp^T = res^T C^T, coef^T = C tmp^T (limbs)
+            const int nlive = imin(G, ncand - c0);
+            u32 crow[4], pn[4];
+            for (int d = 0; d < 4; d++) {
+                const int sc_ = (LG == 5) ? 0 : d, cm = c0 + sc_;
+                crow[d] = *(const u32a *)(C + mi * N + (LG == 5 ? 8 * d : 0) + 4 * mh);
+                if (sc_ < nlive) {
+                    const int md = (P.only_mode >= 0) ? P.only_mode : cm;
+                    BorderRef br; fill_border_ref(br, W, P.per_mode_border, cm);
+                    pq[d] = pred_strip4(T, br, N, LG, md, (LG == 5 ? 8 * d : 0) + 4 * mh, mi);
+                }
+                pn[d] = pq[d] ^ 0x7F7F7F7Fu;
+            }
+            MARK("mx_predict");
+            int acc[16];
+            const int i1 = ra + (0x8080 << a1) + (mi == 0 ? 64 * N : 0);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = i1;
+            mx_mm<LG>(acc, oq, crow, nlive);
+            mx_mm<LG>(acc, pn, crow, nlive);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] >>= a1;                              // tmp + 0x8080
+            u32 l0[4], l1[4], l2[4];
+            mx_limbs3(acc, l0, l1, l2);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = 0;
+            mx_mm<LG>(acc, crow, l2, nlive);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = (int)((u32)acc[r4] << 8);
+            mx_mm<LG>(acc, crow, l1, nlive);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = (int)(((u32)acc[r4] << 8) + (u32)rb);
+            mx_mm<LG>(acc, crow, l0, nlive);
+            i32 *const ct = (i32 *)W.u.raw;
+            for (int d = 0; d < 4; d++) {
+                int4 o; o.x = acc[4 * d]; o.y = acc[4 * d + 1]; o.z = acc[4 * d + 2]; o.w = acc[4 * d + 3];
+                if (LG == 5) *(int4 *)(ct + mi * CST + 8 * d + 4 * mh) = o;
+                else if (d < nlive) *(int4 *)(ct + d * CTILE + mi * CST + 4 * mh) = o;
+            }
+            MARK("mx_forward");
+        } else {
         // ---- step 1: prediction and residual
         if (live) {
             i16 *rp = rt;
@@ -1520,6 +1699,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 *(int4 *)(tp + (by * 4 + r4) * N + ((bx * 4) ^ sw)) = o;
             }
         }
+        }
         wave_sync_lds();
         MARK("fwd_stage1");
         // ---- step 3: coef = (tmp * C^T + rb) >> b ; RDOQ ; tokens ; dequantise                 (:515, :540-614, :1172-1268)
@@ -1527,8 +1707,13 @@ HD void p1_run_t(int wave, const P1Args &P) {
             int acc[4][4];
             int any = 0;
             if (live) {
+                if constexpr (MX) {
+                    const i32 *ct = (const i32 *)W.u.raw + sl * CTILE + (by * 4) * CST + bx * 4;
+                    for (int r4 = 0; r4 < 4; r4++) { const int4 o = *(const int4 *)(ct + r4 * CST); acc[r4][0] = o.x; acc[r4][1] = o.y; acc[r4][2] = o.z; acc[r4][3] = o.w; }
+                } else {
                 for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = rb;
                 mac_YM32<N>(acc, tt, C, by * 4, bx * 4, sw);
+                }
                 MARK("fwd_stage2");
                 any = rdoq_group<s>(acc, Q);
                 MARK("rdoq");
@@ -1537,10 +1722,10 @@ HD void p1_run_t(int wave, const P1Args &P) {
             if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16, &mcode); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
             const u64 cm = P.tok ? wave_ballot(any) : 0;
             uint2 dq[4];                                    // dequantised levels, packed; stored once the token buffer (which lives in res/tmp) is done with
-            for (int r4 = 0; r4 < 4; r4++) {
+            for (int r4 = 0; r4 < 4; r4++)
                 for (int cc = 0; cc < 4; cc++) acc[r4][cc] = any ? clip16(acc[r4][cc] * (1 << Q.dqs)) : 0;      // :613 (a shift; levels may be negative)
-                dq[r4].x = (u32)(acc[r4][0] & 0xFFFF) | (u32)acc[r4][1] << 16; dq[r4].y = (u32)(acc[r4][2] & 0xFFFF) | (u32)acc[r4][3] << 16;
-            }
+            if constexpr (MX) { for (int cc = 0; cc < 4; cc++) mx_limbs2(acc[0][cc], acc[1][cc], acc[2][cc], acc[3][cc], dq[cc].x, dq[cc].y); }      // per column: low / high byte limbs of its four rows
+            else for (int r4 = 0; r4 < 4; r4++) { dq[r4].x = (u32)(acc[r4][0] & 0xFFFF) | (u32)acc[r4][1] << 16; dq[r4].y = (u32)(acc[r4][2] & 0xFFFF) | (u32)acc[r4][3] << 16; }
             if (P.tok) {
                 const int sb = sl * lpc;
                 const u64 seg = (lpc == 64) ? cm : ((cm >> sb) & ((1ull << (lpc & 63)) - 1));
@@ -1615,6 +1800,13 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 prof_add(PF_T_HDR, ptk2);
                 wave_sync_lds();                                            // rows are done with before res is written again
             }
+            if constexpr (MX) {
+                if (!P.tok) wave_sync_lds();                // the limb tiles lie over the coefficient tiles: every lane has read its group
+                if (live) {
+                    u8 *dt = (u8 *)W.u.raw + sl * 2 * DTILE + by * 4;
+                    for (int cc = 0; cc < 4; cc++) { *(u32a *)(dt + (bx * 4 + cc) * DCS) = dq[cc].x; *(u32a *)(dt + DTILE + (bx * 4 + cc) * DCS) = dq[cc].y; }
+                }
+            } else
             if (live) {
                 i16 *dp = rt;
                 for (int r4 = 0; r4 < 4; r4++) *(uint2 *)(dp + (by * 4 + r4) * N + bx * 4) = dq[r4];
@@ -1622,6 +1814,49 @@ HD void p1_run_t(int wave, const P1Args &P) {
         }
         wave_sync_lds();
         MARK("dequant_store");
+        if constexpr (MX) {
+            // ---- steps 4-5 on the matrix cores: itmp = clip16((deq^T C + 64) >> 7) as [y][v], rec = clip16((itmp C + 2048) >> 12) as [y][x = i]
+            const int nlive = imin(G, ncand - c0);
+            u32 dl[4], dh[4];
+            for (int d = 0; d < 4; d++) {
+                const u8 *dt = (const u8 *)W.u.raw + (LG == 5 ? 0 : d * 2 * DTILE) + mi * DCS + (LG == 5 ? 8 * d : 0) + 4 * mh;
+                const int on = (LG == 5) || d < nlive;
+                dl[d] = on ? *(const u32a *)dt : 0u; dh[d] = on ? *(const u32a *)(dt + DTILE) : 0u;
+            }
+            int acc[16];
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = 0;
+            mx_mm<LG>(acc, dh, ccol, nlive);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = (int)(((u32)acc[r4] << 8) + (u32)(64 + cs128));
+            mx_mm<LG>(acc, dl, ccol, nlive);
+            u32 il[4], ih[4];
+            for (int d = 0; d < 4; d++) mx_limbs2(clip16(acc[4 * d] >> 7), clip16(acc[4 * d + 1] >> 7), clip16(acc[4 * d + 2] >> 7), clip16(acc[4 * d + 3] >> 7), il[d], ih[d]);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = 0;
+            mx_mm<LG>(acc, ih, ccol, nlive);
+            for (int r4 = 0; r4 < 16; r4++) acc[r4] = (int)(((u32)acc[r4] << 8) + (u32)(2048 + cs128));
+            mx_mm<LG>(acc, il, ccol, nlive);
+            MARK("mx_inverse");
+            int part = 0;
+            for (int d = 0; d < 4; d++) {
+                const int sc_ = (LG == 5) ? 0 : d, cm = c0 + sc_;
+                if (sc_ < nlive) {
+                    const u32 ow = oq[d] ^ 0x80808080u, pw = pq[d];
+                    if (LG == 4) part = 0;
+                    for (int t = 0; t < 4; t++) {
+                        const int y = (LG == 5 ? 8 * d : 0) + 4 * mh + t, x = mi;
+                        const int rc = clip3(clip16(acc[4 * d + t] >> 12) + (int)((pw >> (8 * t)) & 255), 0, 255);
+                        const int dd = (int)((ow >> (8 * t)) & 255) - rc;
+                        part += dd * dd;
+                        if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
+                        else if (P.out_kind == OUT_T3SIDE) {
+                            if (P.k < 3 && y == N - 1) SM.X.t3row[cm][P.k][x] = (u8)rc;
+                            if (P.k < 3 && x == N - 1) SM.X.t3col[cm][P.k][y] = (u8)rc;
+                        }
+                    }
+                    if (LG == 4 && P.only_mode < 0) lds_add(&WO.sse[cm], part);
+                }
+            }
+            if (LG == 5 && P.only_mode < 0) lds_add(&WO.sse[c0], part);
+        } else {
         // ---- step 4: itmp = clip16((C^T * deq + 64) >> 7)                                    (:514 inverse)
         if (live) {
             int acc[4][4];
@@ -1661,9 +1896,11 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
             if (P.only_mode < 0) lds_add(&WO.sse[c], part);
         }
+        }
         MARK("inv_stage2_recon_sse");
         wave_sync_lds();
       }
+    }
     }
 }
 

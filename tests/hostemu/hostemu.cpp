@@ -75,10 +75,12 @@ static int emu_shfl(int v, int src_lane) {                  // value of `v` held
 // Matrix instructions (wave collectives): every lane deposits its operand registers, then computes the result registers
 // the hardware would hand it.  Layouts as verified on the device by tools/mfma_probe.hip.
 static uint32_t g_mx[3 * EMU_MAX_WG][64][8];                // per lane: a[0..3], b[0..3]
+static long g_mfma_calls[2];                                // wave-level matrix instructions issued so far (32x32x32, 16x16x32)
 static int emu_sx8(uint32_t w, int k) { return (int)(int8_t)(w >> (8 * k)); }
 // v_mfma_i32_32x32x32_i8: lane l holds A[l%32][16*(l/32) .. +15], B[16*(l/32) .. +15][l%32]; acc r: D[8*(r/4) + 4*(l/32) + r%4][l%32]
 static void emu_mfma32(const uint32_t *a, const uint32_t *b, int *acc) {
     const int w = g_cur >> 6, l = g_cur & 63, i = l & 31, h = l >> 5;
+    g_mfma_calls[0] += l == 0;
     for (int d = 0; d < 4; d++) { g_mx[w][l][d] = a[d]; g_mx[w][l][4 + d] = b[d]; }
     emu_wave_sync();
     for (int r = 0; r < 16; r++) {
@@ -93,6 +95,7 @@ static void emu_mfma32(const uint32_t *a, const uint32_t *b, int *acc) {
 // v_mfma_i32_16x16x32_i8: lane l holds A[l%16][8*(l/16) .. +7], B[8*(l/16) .. +7][l%16]; acc r: D[4*(l/16) + r][l%16]
 static void emu_mfma16(const uint32_t *a, const uint32_t *b, int *acc) {
     const int w = g_cur >> 6, l = g_cur & 63, i = l & 15, h = l >> 4;
+    g_mfma_calls[1] += l == 0;
     for (int d = 0; d < 2; d++) { g_mx[w][l][d] = a[d]; g_mx[w][l][4 + d] = b[d]; }
     emu_wave_sync();
     for (int r = 0; r < 4; r++) {
@@ -204,6 +207,7 @@ extern "C" int hostemu_HEVCImageEncoderPool(int n, unsigned char *const *pbuffer
                                             int *ysz, int *xsz, int qpd6, int *out_len, int nmains, int nhelp) {
     return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, nmains, nhelp);
 }
+extern "C" long hostemu_mfma_calls(int kind) { return g_mfma_calls[kind & 1]; }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
 
 // The device's RDOQ (rdoq_group, hevc_core.h) on a sz x sz block of transform coefficients, group by group, with the thresholds
