@@ -28,7 +28,9 @@ def _hostemu_lib(name, flags):
     so = os.path.join(d, name)
     srcs = [os.path.join(d, "hostemu.cpp")] + [os.path.join(ROOT, "imcvt_amd", "csrc", f) for f in ("hevc_core.h", "hevc_frame.h", "hevc_tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", *flags, "-o", so, srcs[0]], check=True)
+        tmp = f"{so}.tmp.{os.getpid()}"            # parallel workers (pytest -n) build into private files and rename: nobody loads a half-written library
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", *flags, "-o", tmp, srcs[0]], check=True)
+        os.replace(tmp, so)
     lib = C.CDLL(so)
     u8p = C.POINTER(C.c_ubyte)
     lib.hostemu_HEVCImageEncoder.restype = C.c_int
@@ -58,6 +60,12 @@ def hostemu_esc(built):
 def hostemu_row(built):
     """Same, with 6-token lane rows: nearly every pass overflows its token rows and takes the count-then-write path."""
     return _hostemu_lib("libhostemu_row.so", ["-DROWCAP=6"])
+
+
+@pytest.fixture(scope="session")
+def hostemu_vec(built):
+    """Same, with the N = 16 / 32 transforms as vector code instead of (emulated) matrix instructions: the A/B build."""
+    return _hostemu_lib("libhostemu_vec.so", ["-DP1_MFMA=0"])
 
 
 @pytest.fixture(scope="session")

@@ -133,11 +133,12 @@ def test_device_resident_batch_matches_host_abi(amd):
     enc.close()
 
 
-@pytest.mark.parametrize("flag", ["-DIMCVT_FORCE_OVF", "-DROWCAP=6"], ids=["ring-overflow-path", "token-row-overflow-path"])
+@pytest.mark.parametrize("flag", ["-DIMCVT_FORCE_OVF", "-DROWCAP=6", "-DP1_MFMA=0"], ids=["ring-overflow-path", "token-row-overflow-path", "vector-transforms"])
 def test_rare_paths_on_the_device(amd, flag, tmp_path):
     """The paths that practically never run — a trial coder whose byte ring overflows is repeated on the safe path; a pass
     whose group tokens do not fit the lanes' LDS rows counts and writes them the plain way — forced by a build flag, on the
-    real hardware (the host emulation checks their logic; lock-step execution is what only the GPU has)."""
+    real hardware (the host emulation checks their logic; lock-step execution is what only the GPU has).  Third variant: the
+    N = 16 / 32 transforms as vector code instead of matrix instructions (the A/B build of hevc_core.h p1_run_t) — same bytes."""
     import subprocess, sys
     from conftest import ROOT
     so = str(tmp_path / "libimcvt_hevc_variant.so")

@@ -64,6 +64,40 @@ def test_token_row_overflow_path_matches_golden(hostemu_row, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_vector_transform_build_matches_golden(hostemu_vec, e):
+    # the N = 16 / 32 transforms as vector code (-DP1_MFMA=0, the A/B build): same streams as the matrix-instruction path
+    stream, rcon = emu_encode(hostemu_vec, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
+def _extreme_pictures():
+    rng = np.random.default_rng(1)
+    pics = {"bw_noise": rng.integers(0, 2, (32, 64), dtype=np.uint8) * 255, "noise": rng.integers(0, 256, (32, 64), dtype=np.uint8)}
+    cb = np.zeros((32, 32), np.uint8); cb[::2, 1::2] = 255; cb[1::2, ::2] = 255; pics["checker"] = cb
+    st = np.zeros((32, 64), np.uint8); st[:, 32:] = 255; st[16:, :32] = 255; pics["steps"] = st
+    sp = np.zeros((64, 32), np.uint8); sp[:, ::2] = 255; pics["stripes"] = sp
+    wh = np.full((32, 32), 255, np.uint8); wh[0, 0] = 0; pics["white"] = wh
+    return pics
+
+
+@pytest.mark.parametrize("name", sorted(_extreme_pictures()))
+@pytest.mark.parametrize("q", [0, 4])
+def test_matrix_transforms_on_extreme_residuals(hostemu, name, q):
+    """The matrix-instruction transforms cut their wider operands into i8 limbs (hevc_core.h mx_mm): full-swing residuals drive
+    the intermediate of the forward transform to its 17 bits and the dequantised levels into the 16-bit clip (:511-515, :613) —
+    compared with the CPU checker, and the run must really have issued both matrix instructions."""
+    from oracle import oracle
+    hostemu.hostemu_mfma_calls.restype = C.c_long
+    before = [hostemu.hostemu_mfma_calls(k) for k in (0, 1)]
+    img = np.ascontiguousarray(_extreme_pictures()[name])
+    stream, rcon = emu_encode(hostemu, img, q)
+    want, wr, _ = oracle.cpu_encode(img, q)
+    assert stream == want and (rcon == wr).all()
+    assert all(hostemu.hostemu_mfma_calls(k) > before[k] for k in (0, 1))
+
+
 @pytest.mark.parametrize("q", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("sz", [4, 8, 16, 32])
 def test_rdoq_thresholds_match_reference_loop(hostemu, q, sz):
