@@ -155,7 +155,7 @@ int imcvt_hevc_debug_census(imcvt_hevc_ctx *ctx, int grid);
 /* Debug aid: what the HIP occupancy API reports for the encoder kernel on the current device. */
 int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds_per_block, int *lds_per_cu);
 
-/* Library / build information, e.g. "imcvt_hevc gfx950 r2 ...". */
+/* Library / build information, e.g. "imcvt_hevc gfx950 r3 ...". */
 const char *imcvt_hevc_version(void);
 
 #ifdef __cplusplus

@@ -21,6 +21,8 @@ out = {"source": f"{sys.argv[1].replace('gpurun_out/', 'profiles/')} (rocprofv3 
        "valu_busy_frac": round(g("SQ_ACTIVE_INST_VALU") * 4 / (cycles_per_xcc * simds), 4) if cycles_per_xcc else None,
        "wave_wait_frac": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4) if g("SQ_WAVE_CYCLES") else None,
        "lds_bank_conflict_frac": round(g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"), 4) if g("SQ_LDS_IDX_ACTIVE") else None,
+       "mfma_i8_wave_insts_per_ctu": round(g("SQ_INSTS_VALU_MFMA_I8") / ctus, 1) if "SQ_INSTS_VALU_MFMA_I8" in vals else None,
+       "mfma_busy_frac": round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (cycles_per_xcc * 256), 5) if ("SQ_VALU_MFMA_BUSY_CYCLES" in vals and cycles_per_xcc) else None,
        "units": "SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (x4 = cycles); GRBM_GUI_ACTIVE is summed over the 8 XCCs; 1024 SIMDs",
        "frames": frames, "w": w, "h": h, "qpd6": q}
 print(json.dumps(out, indent=1))
