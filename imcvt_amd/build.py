@@ -29,7 +29,7 @@ def needs_build() -> bool:
 
 
 JLS_OUT = os.path.join(CSRC, "libimcvt_jls.so")   # JPEG-LS (BASELINE config 5)
-JLS_DEPS = ["jls_hip.hip", "jls_core.h", os.path.join("..", "..", "include", "imcvt_jls.h")]
+JLS_DEPS = ["jls_hip.hip", "jls_core.h", "jls_par.h", os.path.join("..", "..", "include", "imcvt_jls.h")]
 
 
 def build_jls(force: bool = False) -> str:

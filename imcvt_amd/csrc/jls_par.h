@@ -51,8 +51,8 @@ struct ParPlane {
     uint32_t *binbase;   // [365] start of each context's list (k3); [364] = number of regular pixels
     unsigned long long *rowbits;   // [h] bits per row -> exclusive sums
     // lists
-    uint32_t *list;      // [npx] x | pred << 8 | sign<0 << 16, context-major, raster order inside a context
-    uint32_t *code;      // [npx] code word value | length << 24, same order
+    uint32_t *list;      // [npx] x | (MED prediction + s) << 8 | s << 17 with s = 1 for the negative sign: context-major, raster order inside a context
+    uint32_t *code;      // [2 npx] what each sample's code word is made from (regular_step below), same order
     uint32_t *ev;        // [2 * nev] run length | type << 16, x | a << 8 | b << 16
     uint32_t *evout;     // [3 * nev] ones, run-count bits (value | len << 24), Golomb code (value | len << 24)
     uint32_t *bits;      // unstuffed bit stream, MSB-first 32-bit words, zeroed before k7
@@ -157,7 +157,8 @@ JD void k4_scatter(const ParPlane &P, long t) {
     if (cl == CL_REG) {
         const uint32_t at = P.binbase[q - 1] + P.rowcnt[(size_t)y * 364 + (q - 1)] + P.rank[t];
         P.pos[t] = at;
-        P.list[at] = (uint32_t)px_at(P, y, x) | (uint32_t)P.med[t] << 8 | (uint32_t)((s >> 9) & 1) << 16;
+        const uint32_t sg = (uint32_t)((s >> 9) & 1);
+        P.list[at] = (uint32_t)px_at(P, y, x) | ((uint32_t)P.med[t] + sg) << 8 | sg << 17;
     } else if (cl == CL_RUN) P.pos[t] = 0xFFFFFFFFu;
     else {
         const uint32_t e = P.rowev[y] + P.rank[t];
@@ -196,32 +197,52 @@ JD int uclamp(int v, int lo, int hi) {
     return t;
 }
 #endif
-// The chain itself only carries the context: it hands out, per sample, what the code word is made from — A and N before the
-// update (A < 2^15, N <= 64), the 8-bit error and the test of :366 on B and N — packed in one word; the code word
-// (regular_word below) is computed where it is consumed, by the per-pixel kernels k6 / k7, off the chain.
-//     state word: A | N << 16 | (e & 255) << 23 | (2 B <= -N) << 31
-JD uint32_t regular_step(const Par &p, Ctx &r, uint32_t el) {
+// The chain itself only carries the context: it hands out, per sample, what the code word is made from — A, N and B before
+// the update (A < 2^15, N <= 64, -64 < B <= 0) and the 8-bit error — as two words of two 16-bit halves (one s_pack each); the
+// code word (regular_word below) is computed where it is consumed, by the per-pixel kernels k6 / k7, off the chain.
+//     w0 = A | N << 16        w1 = (e & 0xFFFF) | B << 16
+// The chain is a lone wave's scalar program and costs its instruction COUNT (one issue per ~4 cycles whatever the instruction), so
+// the list element arrives pre-digested (x, MED + s and s at fixed bit fields: med + sign * C = (MED + s) + (C ^ -s)) and the
+// B / C update of :383-392 is written on the scalar condition code directly: compare, select, add-with-carry.
+#if defined(IMCVT_JLS_HOST) || defined(JLS_CHAIN_VECTOR)
+JD uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | (uint32_t)hi << 16; }
+// B beyond (-N, 0] is pulled back by N (at most to the edge) and C steps (:383-392); nn = -N
+JD void bias_step(int &B, int &c, int N, int nn) {
+    const int lo = B <= nn, hi = B > 0;
+    const int b_lo = imax(B + N, 1 + nn), b_hi = imin(B - N, 0);
+    B = lo ? b_lo : hi ? b_hi : B;
+    c += hi - lo;
+}
+#else
+JD uint32_t pack16(int lo, int hi) { uint32_t t; asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(t) : "s"(lo), "s"(hi)); return t; }
+JD void bias_step(int &B, int &c, int N, int nn) {
+    const int b_lo = imax(B + N, 1 + nn), b_hi = imin(B - N, 0);
+    int Bn = B, cn = c;
+    asm("s_cmp_gt_i32 %2, 0\n\ts_cselect_b32 %0, %3, %2\n\ts_addc_u32 %1, %1, 0\n\t"
+        "s_cmp_le_i32 %2, %5\n\ts_cselect_b32 %0, %4, %0\n\ts_subb_u32 %1, %1, 0"
+        : "=&s"(Bn), "+s"(cn) : "s"(B), "s"(b_hi), "s"(b_lo), "s"(nn) : "scc");
+    B = Bn; c = cn;
+}
+#endif
+JD void regular_step(const Par &p, Ctx &r, uint32_t el, uint32_t &w0, uint32_t &w1) {
     (void)p;
-    const int v = (int)(el & 255), med = (int)((el >> 8) & 255), m = -(int)((el >> 16) & 1);      // m = -1 for the negative sign
-    const int pred = uclamp(med + ((r.c ^ m) - m), 0, 255);                                        // med + sign * C (:349-350)
-    int e = v - pred;
+    const int m = (int)(el << 14) >> 31;                                                           // -1 for the negative sign
+    const int pred = uclamp((int)((el >> 8) & 511u) + (r.c ^ m), 0, 255);                          // med + sign * C (:349-350)
+    int e = (int)el - pred;                                                                        // (only the low byte counts from here on)
     e = (e ^ m) - m;                                                                               // sign * (x - px)
     e = (int)(int8_t)e;                                                                            // modRange with qbeta = 256 (:105-111) is the sign extension of the low byte
     const int ae = iabs(e);
-    const uint32_t st = (uint32_t)r.a | (uint32_t)r.n << 16 | ((uint32_t)e & 255u) << 23 | (uint32_t)(2 * r.b <= -r.n) << 31;
+    w0 = pack16(r.a, r.n); w1 = pack16(e, r.b);
     const int rs = r.n >> 6;                                                                       // N >= 64 (N never exceeds 64): :376-381
-    int B = (r.b + e) >> rs, N = (r.n >> rs) + 1;
+    int B = (r.b + e) >> rs; const int N = (r.n >> rs) + 1;
     r.a = (r.a + ae) >> rs;
-    const int lo = B <= -N, hi = B > 0;                                                            // :383-392
-    const int b_lo = imax(B + N, 1 - N), b_hi = imin(B - N, 0);
-    B = lo ? b_lo : hi ? b_hi : B;
-    r.c = uclamp(r.c + hi - lo, -128, 127);
+    bias_step(B, r.c, N, -N);
+    r.c = uclamp(r.c, -128, 127);
     r.b = B; r.n = N;
-    return st;
 }
-// code word (value | length << 24) of a regular-mode sample from its state word (:363-375, :187-197 with qbpp = 8)
-JD uint32_t regular_word(const Par &p, uint32_t st) {
-    const int a = (int)(st & 0xFFFFu), n = (int)((st >> 16) & 127u), e = (int)(int8_t)(st >> 23), nb = (int)(st >> 31);
+// code word (value | length << 24) of a regular-mode sample from its two state words (:363-375, :187-197 with qbpp = 8)
+JD uint32_t regular_word(const Par &p, uint32_t w0, uint32_t w1) {
+    const int a = (int)(w0 & 0xFFFFu), n = (int)(w0 >> 16), e = (int)(int16_t)(w1 & 0xFFFFu), b = (int)w1 >> 16, nb = 2 * b <= -n;
     const int ae = iabs(e), neg = (int)((uint32_t)e >> 31);
     const int k = golomb_k_nb(a, n);
     const int map = (k == 0) & nb;                                                                 // :366
@@ -243,17 +264,17 @@ JD void k5_chain(const ParPlane &P, long t) {
         // with two blocks of distance both have had a block's time to complete).  Constant indices into fully unrolled
         // loops keep the blocks in registers.  The list is padded, reading past a chain's end is harmless.
         JLS_GLB const uint32_t *list = G(const uint32_t, P.list) + base;
-        JLS_GLB uint32_t *code = G(uint32_t, P.code) + base;
+        JLS_GLB uint32_t *code = G(uint32_t, P.code) + 2 * (size_t)base;
         uint32_t b0[8], b1[8];
         JLS_UNROLL for (int j = 0; j < 8; j++) { b0[j] = UNI(list[j]); b1[j] = UNI(list[8 + j]); }
         uint32_t i0 = 0;
         for (; i0 + 8 <= n; i0 += 8) {
-            uint32_t cur[8];
+            uint32_t cur[8], wa[8], wb[8];
             JLS_UNROLL for (int j = 0; j < 8; j++) { cur[j] = b0[j]; b0[j] = b1[j]; b1[j] = UNI(list[i0 + 16 + j]); }
-            JLS_UNROLL for (int j = 0; j < 8; j++) cur[j] = regular_step(p, r, cur[j]);
-            JLS_UNROLL for (int j = 0; j < 8; j++) code[i0 + j] = cur[j];
+            JLS_UNROLL for (int j = 0; j < 8; j++) regular_step(p, r, cur[j], wa[j], wb[j]);
+            JLS_UNROLL for (int j = 0; j < 8; j++) { code[2 * (i0 + j)] = wa[j]; code[2 * (i0 + j) + 1] = wb[j]; }
         }
-        for (; i0 < n; i0++) code[i0] = regular_step(p, r, UNI(list[i0]));
+        for (; i0 < n; i0++) { uint32_t wa, wb; regular_step(p, r, UNI(list[i0]), wa, wb); code[2 * i0] = wa; code[2 * i0 + 1] = wb; }
     } else {
         const uint32_t nev = P.binbase[365];
         Ctx ri[2];
@@ -294,7 +315,7 @@ JD void k5_chain(const ParPlane &P, long t) {
 JD void k6_len(const ParPlane &P, long t) {
     const int cl = P.cls[t];
     int n = 0;
-    if (cl == CL_REG) n = (int)(regular_word(make_par(0), P.code[P.pos[t]]) >> 24);
+    if (cl == CL_REG) n = (int)(regular_word(make_par(0), P.code[2 * (size_t)P.pos[t]], P.code[2 * (size_t)P.pos[t] + 1]) >> 24);
     else if (cl != CL_RUN) { const uint32_t e = P.pos[t]; n = (int)P.evout[3 * e] + (int)(P.evout[3 * e + 1] >> 24) + (int)(P.evout[3 * e + 2] >> 24); }
     P.len[t] = (uint8_t)n;
 }
@@ -333,7 +354,7 @@ JD void k7_pack(const ParPlane &P, long t) {
     const int cl = P.cls[t];
     if (cl == CL_RUN || P.len[t] == 0) return;
     unsigned long long at = P.rowbits[t / P.w] + P.bitpos[t];
-    if (cl == CL_REG) { const uint32_t c = regular_word(make_par(0), P.code[P.pos[t]]); put_at(P, at, c & 0xFFFFFFu, (int)(c >> 24)); return; }
+    if (cl == CL_REG) { const uint32_t c = regular_word(make_par(0), P.code[2 * (size_t)P.pos[t]], P.code[2 * (size_t)P.pos[t] + 1]); put_at(P, at, c & 0xFFFFFFu, (int)(c >> 24)); return; }
     const uint32_t e = P.pos[t];
     const int ones = (int)P.evout[3 * e];
     put_at(P, at, ones >= 32 ? 0xFFFFFFFFu : (1u << ones) - 1u, ones); at += ones;
@@ -396,7 +417,7 @@ JHD size_t par_workspace(int h, int w) {
     const size_t n = (size_t)h * w;
     return par_align(2 * n) + par_align(n) + par_align(n) + par_align(2 * n) + par_align(2 * n) + par_align(4 * n) + par_align(n) + par_align(4 * n)
          + par_align(4 * (size_t)h * 364) + par_align(4 * (size_t)h) + par_align(4 * 366) + par_align(8 * (size_t)h)
-         + par_align(4 * n + 128) + par_align(4 * n) + par_align(8 * n) + par_align(12 * n) + par_align(8 * n + 16) + par_align(4 * 18 * par_chunks_max(n)) + par_align(16);
+         + par_align(4 * n + 128) + par_align(8 * n) + par_align(8 * n) + par_align(12 * n) + par_align(8 * n + 16) + par_align(4 * 18 * par_chunks_max(n)) + par_align(16);
 }
 JHD void par_carve(ParPlane &P, uint8_t *b) {
     const size_t n = (size_t)P.h * P.w;
@@ -405,7 +426,7 @@ JHD void par_carve(ParPlane &P, uint8_t *b) {
     P.pos = (uint32_t *)b; b += par_align(4 * n);  P.len = b; b += par_align(n);   P.bitpos = (uint32_t *)b; b += par_align(4 * n);
     P.rowcnt = (uint32_t *)b; b += par_align(4 * (size_t)P.h * 364); P.rowev = (uint32_t *)b; b += par_align(4 * (size_t)P.h);
     P.binbase = (uint32_t *)b; b += par_align(4 * 366); P.rowbits = (unsigned long long *)b; b += par_align(8 * (size_t)P.h);
-    P.list = (uint32_t *)b; b += par_align(4 * n + 128); P.code = (uint32_t *)b; b += par_align(4 * n);
+    P.list = (uint32_t *)b; b += par_align(4 * n + 128); P.code = (uint32_t *)b; b += par_align(8 * n);
     P.ev = (uint32_t *)b; b += par_align(8 * n);   P.evout = (uint32_t *)b; b += par_align(12 * n);
     P.bits = (uint32_t *)b; b += par_align(8 * n + 16);
     P.chunk = (uint32_t *)b; b += par_align(4 * 18 * par_chunks_max(n)); P.total = (unsigned long long *)b;

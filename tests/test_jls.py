@@ -24,7 +24,9 @@ def jls_emu(built):
     so, src = os.path.join(d, "libjls_hostemu.so"), os.path.join(d, "jls_hostemu.cpp")
     deps = [src] + [os.path.join(ROOT, "imcvt_amd", "csrc", f) for f in ("jls_core.h", "jls_par.h")]
     if not os.path.exists(so) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(so):
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", so, src], check=True)
+        tmp = f"{so}.tmp.{os.getpid()}"            # private file + rename: parallel test workers never load a half-written library
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", tmp, src], check=True)
+        os.replace(tmp, so)
     lib = C.CDLL(so)
     lib.jls_hostemu_encode.restype = C.c_longlong
     lib.jls_hostemu_encode.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
@@ -100,7 +102,9 @@ def jls_emu_libs(built):
     for name, flags in (("libjls_hostemu.so", []), ("libjls_hostemu_c64.so", ["-DJLS_CHUNK_BITS=64"])):
         so = os.path.join(d, name)
         if not os.path.exists(so) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(so):
-            subprocess.run(["g++", "-O2", "-fPIC", "-shared", *flags, "-o", so, src], check=True)
+            tmp = f"{so}.tmp.{os.getpid()}"
+            subprocess.run(["g++", "-O2", "-fPIC", "-shared", *flags, "-o", tmp, src], check=True)
+            os.replace(tmp, so)
         lib = C.CDLL(so)
         lib.jls_hostemu_encode.restype = C.c_longlong
         lib.jls_hostemu_encode.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
