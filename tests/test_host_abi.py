@@ -61,6 +61,22 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt and "libref_" not in txt, f
 
 
+def test_shipped_kernel_uses_the_matrix_cores(built, tmp_path):
+    """The gfx950 code object inside libimcvt_hevc.so really contains the two i8 matrix instructions the N = 16 / 32 transforms are
+    written for (hevc_core.h mx_mm) — checked on the bundled device code, no GPU needed."""
+    import shutil, subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    so = tmp_path / "libimcvt_hevc.so"
+    shutil.copy(os.path.join(ROOT, "imcvt_amd", "csrc", "libimcvt_hevc.so"), so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / co[0])], check=True, capture_output=True, text=True).stdout
+    assert asm.count("v_mfma_i32_32x32x32_i8") >= 9 and asm.count("v_mfma_i32_16x16x32_i8") >= 36, (asm.count("v_mfma_i32_32x32x32_i8"), asm.count("v_mfma_i32_16x16x32_i8"))
+
+
 REF_SRC = "/root/reference/src"
 
 

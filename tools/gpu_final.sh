@@ -1,6 +1,6 @@
 #!/bin/bash
 # Final measurement pass of round 3 on one box: counters on the bench workload (-> profiles/pmc_*.json, which bench.py reads), the bench line,
-# the same command under rocprofv3 --kernel-trace --stats, JPEG-LS timings, scale prediction.   usage: tools/_round3z.sh TAG
+# the same command under rocprofv3 --kernel-trace --stats, JPEG-LS timings, scale prediction.   usage: tools/gpu_final.sh TAG   (on the GPU box: gpurun -- tools/gpu_final.sh r03z)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out; TAG=${1:-r03z}
 bash tools/gpu_pmc.sh ${TAG} 1920 1080 512 0 > $O/${TAG}_pmc.log 2>&1; tail -3 $O/${TAG}_pmc.log
