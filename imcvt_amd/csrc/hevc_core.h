@@ -20,6 +20,10 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
 
 #define NWAVES 3
 #define WG_THREADS (NWAVES * 64)
+// Optional fourth wavefront ("pipe wave", hevc_frame.h nxn_pipe): launches of 256 threads per workgroup carry one; it takes the
+// NxN trial of every 8x8 CU off the wave that walks the PU chain.  It joins the workgroup barriers and skips everything else.
+#define PIPE_WAVE NWAVES
+#define WG_THREADS_PIPE ((NWAVES + 1) * 64)
 #define NMODE 35
 #define I32MAX 0x7fffffff
 
@@ -31,7 +35,8 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   static int emu_lane(); static int emu_wave(); static void emu_wave_sync(); static void emu_wg_sync();
   static uint64_t emu_ballot(int p); static int emu_shfl(int v, int src_lane);
   #define LANES(l) for (int l = emu_lane(), l##_once = 1; l##_once; l##_once = 0)
-  #define WAVES(w) for (int w = emu_wave(), w##_once = 1; w##_once; w##_once = 0)
+  #define WAVES(w) for (int w = emu_wave(), w##_once = (w < NWAVES); w##_once; w##_once = 0)      // the pipe wave sits these out
+  #define WAVES_ALL(w) for (int w = emu_wave(), w##_once = 1; w##_once; w##_once = 0)
   HD void wave_sync() { emu_wave_sync(); }
   HD void wave_sync_lds() { emu_wave_sync(); }
   HD void wg_sync() { emu_wg_sync(); }
@@ -49,6 +54,12 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD int m_cas32(void *p, u32 expect, u32 desired) { if (*(volatile u32 *)p != expect) return 0; *(volatile u32 *)p = desired; return 1; }
   HD void mail_poll_pause() { emu_yield(); }
   HD void mail_idle_pause(int) { emu_yield(); }
+  // flags between the wavefronts of one workgroup (pipe wave): LDS words, polled
+  HD i32 lds_ld_i32(const i32 *p) { return *(const volatile i32 *)p; }
+  HD void lds_st_i32(i32 *p, i32 v) { *(volatile i32 *)p = v; }
+  HD void pipe_pause() { emu_yield(); }
+  static int emu_pipe_on();
+  HD int wg_has_pipe_wave() { return emu_pipe_on(); }
   HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
   HD void drain_stores() {}
 #else
@@ -57,7 +68,8 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   #define HDN __device__ __noinline__
   #endif
   #define LANES(l) for (int l = (int)(threadIdx.x & 63u), l##_once = 1; l##_once; l##_once = 0)
-  #define WAVES(w) for (int w = (int)(threadIdx.x >> 6), w##_once = 1; w##_once; w##_once = 0)
+  #define WAVES(w) for (int w = (int)(threadIdx.x >> 6), w##_once = (w < NWAVES); w##_once; w##_once = 0)      // the pipe wave sits these out
+  #define WAVES_ALL(w) for (int w = (int)(threadIdx.x >> 6), w##_once = 1; w##_once; w##_once = 0)
   // LDS traffic of one wavefront is in program order; the fence only stops the compiler (and drains
   // global stores, which the trial coders read back from other lanes of the same wave).
   HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
@@ -89,6 +101,13 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD void mail_idle_pause(int r) { const int n = r < 3 ? 1 << r : 8; for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(MAIL_POLL_SLEEP); }
   HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   HD unsigned long long wd_now() { return wall_clock64(); }
+  // flags between the wavefronts of one workgroup (pipe wave): LDS words, polled.  The wavefronts of a workgroup share a compute
+  // unit and its vector L1, so a producer's global stores are visible to the consumer once they have been issued and waited for
+  // (wave_sync() before the flag store), exactly as across a workgroup barrier.
+  HD i32 lds_ld_i32(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  HD void lds_st_i32(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  HD void pipe_pause() { __builtin_amdgcn_s_sleep(2); }
+  HD int wg_has_pipe_wave() { return blockDim.x > (unsigned)WG_THREADS; }
 #endif
 
 #if defined(IMCVT_HOSTEMU)
@@ -244,6 +263,7 @@ HD Arith unpack_arith(const FinState &f) {
 #endif
 #define LEADQ 10           // per-lane queue of byte leads: at most one per token of an 8-token block, plus the slot the idle write lands in
 struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
+#define LSTRIDE_DW 33       // dwords per lane row of the lane-private token staging (LSTRIDE below)
 #define P1_RES_BYTES 2304   // 16 tiles of 8x8 + 4 or 4 tiles of 16x16 + 16 i16 (padded against LDS bank conflicts), 16-byte multiple
 #define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
 struct alignas(16) WaveMem {
@@ -280,7 +300,7 @@ struct FrameJob {
 #define TOK_SLOTS (NMODE + 1)
 struct Scratch {
     u16 *tok;        // [NWAVES][TOK_SLOTS][TOK_CAP] bin tokens of the candidates being priced
-    u8  *bytes;      // [NWAVES][NMODE][TRIAL_BYTES] bytes emitted by trial coders
+    u8  *bytes;      // [NWAVES + 1][NMODE][TRIAL_BYTES] bytes emitted by trial coders (the last block: the pipe wave's)
     u8  *above_sz;   // [wp/4] CU sizes of the CTU row above (:1633-1636)
     i32 *trace;      // optional decision trace (8 ints per CU), or null
     unsigned long long *prof;   // optional [NWAVES][PF_N] cycle totals (IMCVT_PROF builds), or null
@@ -289,10 +309,10 @@ struct Scratch {
 // host side: size and carving of one workgroup's scratch slab
 static inline size_t scratch_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline size_t scratch_tok_bytes() { return scratch_align((size_t)NWAVES * TOK_SLOTS * TOK_CAP * sizeof(u16) + 64); }
-static inline size_t scratch_bytes_per_wg() { return scratch_tok_bytes() + scratch_align((size_t)NWAVES * NMODE * TRIAL_BYTES) + scratch_align(8192 / 4 + 64); }
+static inline size_t scratch_bytes_per_wg() { return scratch_tok_bytes() + scratch_align((size_t)(NWAVES + 1) * NMODE * TRIAL_BYTES) + scratch_align(8192 / 4 + 64); }
 static inline void scratch_carve(Scratch &sc, u8 *base) {
     sc.tok = (u16 *)base; base += scratch_tok_bytes();
-    sc.bytes = base;      base += scratch_align((size_t)NWAVES * NMODE * TRIAL_BYTES);
+    sc.bytes = base;      base += scratch_align((size_t)(NWAVES + 1) * NMODE * TRIAL_BYTES);
     sc.above_sz = base;
     sc.trace = nullptr; sc.trace_cap = 0; sc.prof = nullptr;
 }
@@ -386,6 +406,7 @@ struct FrameCtx {
     u32 waited, waited_max;   // 100 MHz ticks this frame's main workgroup spent waiting for answers, and the longest single wait (debug statistics)
     i32 pace_inc, pace_mine, pace_n, pace_base;   // pace control: 65536 / CTUs of this frame, this workgroup's share done, main workgroups of the launch, configured base priority
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
+    i32 pipe;           // this launch's workgroups carry a pipe wave (256 threads)
 };
 
 struct FourTU {                  // state of the four-TU shape (one wave evaluates it at a time)
@@ -408,6 +429,8 @@ struct alignas(16) Shm {
     i32 win_kind, win_mode;      // decision broadcast
     i32 red[NWAVES];             // small reductions
     i32 next_frame;              // job index pulled from the queue
+    i32 pipe_a, pipe_b;          // PU wave -> pipe wave: the winners of PUs 0..2 / of PU 3 are in place (cleared by the pipe wave)
+    i32 nxn_lane;                // pipe wave: the lane that holds the NxN trial's result (= PU 3's mode)
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
 #endif
@@ -429,6 +452,16 @@ __shared__ Shm g_shm;
 #define SM g_shm
 #endif
 #define WM(w) (*(WaveMem *)(SM.wraw + (w) * sizeof(WaveMem)))
+// The pipe wave's slice (a WaveMem cut off after the trial coders' extent) is dynamic LDS: only 256-thread launches pay for it.
+#define PIPE_LDS_BYTES ((sizeof(WaveMem) - 7168 + 5120 + 15) & ~(size_t)15)
+static_assert(NMODE * LSTRIDE_DW * 4 <= 5120 && W2_PAD <= 5120, "the pipe wave's slice holds 35 token rows / 35 trial coders");
+#ifdef IMCVT_HOSTEMU
+static u8 *g_pipe_host;
+#define PM (*(WaveMem *)g_pipe_host)
+#else
+extern __shared__ __attribute__((aligned(16))) u8 g_pipe_lds[];
+#define PM (*(WaveMem *)g_pipe_lds)
+#endif
 HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
 HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }
 
@@ -436,14 +469,14 @@ HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] 
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
 HD long long prof_now() { return clock64(); }
 HD int threadIdx_wave() { return (int)(threadIdx.x >> 6); }
-HD void prof_add(int cat, long long t0) { if ((threadIdx.x & 63u) == 0) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)(clock64() - t0); }
+HD void prof_add(int cat, long long t0) { if ((threadIdx.x & 63u) == 0 && threadIdx.x < WG_THREADS) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)(clock64() - t0); }
 #else
 HD long long prof_now() { return 0; }
 HD int threadIdx_wave() { return 0; }
 HD void prof_add(int, long long) {}
 #endif
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
-HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)n; }
+HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0 && threadIdx.x < WG_THREADS) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)n; }
 #else
 HD void prof_cnt(int, int) {}
 #endif
@@ -1374,7 +1407,7 @@ HD int tok_write(u16 *p, int k0, const Lv16 &L, u32 nzm, int cfg) {      // stra
 // ---- lane-private token streams (CU headers, 4x4 TUs): the lane stages up to LCAP tokens in its own LDS row and hands
 // whole blocks to its candidate's stream in global memory.
 #define LCAP 64
-#define LSTRIDE 33          // dwords per lane row: 64 tokens + the dump slot; odd -> rows start in different banks
+#define LSTRIDE LSTRIDE_DW  // dwords per lane row: 64 tokens + the dump slot; odd -> rows start in different banks
 struct LaneStream { u16 *buf; u16 *g; int blk0; };      // buf[0] is token 8 * blk0 of the stream g
 HD u16 *lane_row(WaveMem &W, int lane) { return (u16 *)(W.u.raw + lane * LSTRIDE); }
 HD void blk_copy(u32a *d, const u32a *s_) { d[0] = s_[0]; d[1] = s_[1]; d[2] = s_[2]; d[3] = s_[3]; }
@@ -1989,8 +2022,8 @@ HD u32 tok_of(const U4 &b, int j) { const u32 w = (j < 2) ? b.x : (j < 4) ? b.y 
 // Wave collective: every lane calls it, idle lanes with n == 0.  All lanes are in the same phase of their streams, so
 // the token loads (one 16-byte block per lane per 8 steps, issued one block ahead) and the byte flushes are wave-synchronous.
 // Returns non-zero if the lane's ring overflowed (the result is then void, see RingSink).
-HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) {
-    RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+// (stream_seg: one segment of a stream on a sink that outlives it — the pipe wave codes a CU's stream in pieces as they become known)
+HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) {
     // token blocks are loaded unconditionally (index clamped to the stream's last block; p is always a valid address),
     // so the loop carries no conditional load and the only wait for a block is where it is first used, one round later
     const int last_blk = imax((n - 1) >> 3, 0);
@@ -2048,17 +2081,24 @@ HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) 
         cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
 #endif
     }
+}
+HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) {
+    RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+    stream_seg(a, cx, lm, sink, p, n);
     const long long tx3 = prof_now();
     ring_finish(sink, a.cnt);
     prof_add(PF_X3, tx3);
     return sink.ovf;
 }
 // the same on the safe path: bytes go straight to memory, one token load per step
-HD void stream_run_safe(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n) {
-    Sink sink; sink.base = gbuf; sink.off = (u32)(0 - a.cnt);
+HD void stream_seg_safe(Arith &a, u8 *cx, Sink &sink, const u16 *p, int n) {
     NOUNROLL
     for (int k = 0; WAVE_ANY(k < n); k++)
         if (k < n) code_token(a, cx, sink, (u32)(u16)g_ld16((const i16 *)(p + k)));
+}
+HD void stream_run_safe(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n) {
+    Sink sink; sink.base = gbuf; sink.off = (u32)(0 - a.cnt);
+    stream_seg_safe(a, cx, sink, p, n);
 }
 // One trial: contexts copied from cx_src, coder state `a` in/out.  Wave collective (`on` = this lane has a stream).
 #ifdef IMCVT_TOKSTAT

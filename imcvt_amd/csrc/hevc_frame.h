@@ -56,6 +56,10 @@ struct P1Item { int own, shape, lo, hi; };
 HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? SPL32_0 : SPL32_1) : (shape == 0 ? SPL16_0 : SPL16_1); }   // passes come out balanced over the three waves
 HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int avm_) {
     const int wave = uni_i(wave_); const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
+    if (wave >= NWAVES) {                               // the pipe wave has no share in these sets: it only keeps the workgroup's barrier count
+        if (N >= 16) { wg_sync_p(); wg_sync_p(); }
+        return;
+    }
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q, h = N / 2, big = N >= 16;
@@ -151,6 +155,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     const Avail av = unpack_avail(avm);
     WaveMem &W = WM(wave);
     const int q = F.job.q;
+    const int pipe = F.pipe;                            // a pipe wave prices the NxN CU (nxn_pipe below): this wave only walks the PU chain
     u16 *tok = wave_tok(F.sc, wave);
     u16 *nxn = tok + (size_t)NMODE * TOK_CAP;
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
@@ -195,10 +200,21 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             const u16 *src = tok + (size_t)bm * TOK_CAP + 7;
             u16 *dst = nxn + NXN_KEEP + k * NXN_KEEP_STRIDE;
             for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), g_ld16((const i16 *)(src + i)));
+            if (pipe && l < 8 && ((cnt + l) >> 3) == (cnt >> 3) && (cnt & 7) != 0) g_st16((i16 *)(dst + cnt + l), (int)TOK_IDLE);   // the pipe wave codes the kept copy as a stream segment of its own: idle tokens up to the block boundary
             if (l < 16) SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
         }
         wave_sync_lds();
+        if (pipe && k >= 2) {                           // PUs 0..2 are enough for the pipe wave to start (it tries all 35 modes of PU 3 in the header), PU 3 lets it finish
+            wave_sync();                                // the kept tokens are in memory
+            LANES(l) { if (l == 0) lds_st_i32(k == 2 ? &SM.pipe_a : &SM.pipe_b, 1); }
+        }
         prof_add(PF_P1_8, pt);
+    }
+    if (pipe) {
+#ifndef IMCVT_HOSTEMU
+        if (F.prio_base) SETPRIO(2); else SETPRIO(0);
+#endif
+        return;
     }
     // price the whole NxN CU from the entry state (:1530-1543)
     const int uy = y0 >> 2, ux = x0 >> 2;
@@ -250,6 +266,85 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 #endif
 }
 
+// ---- the NxN trial of an 8x8 CU on the pipe wave (256-thread launches) -------------------------------------------------
+// The NxN stream is header, then the four PU winners' residuals (:1530-1543), and the header names all four PU modes — so the
+// trial cannot start before PU 3 is decided, and on the PU wave it is a serial tail of ~190 tokens coded by one lane.  Here
+// lane m of the pipe wave assumes PU 3 = mode m: as soon as PUs 0..2 are decided, 35 lanes code the 35 possible headers and
+// the winners of PUs 0..2 from the CU's entry state, while the PU wave is busy with PU 3.  When PU 3 is decided the lane that
+// guessed its mode codes PU 3's winner and holds the trial's result; what is left of the tail is that one segment.
+// The stream is coded in segments (header, PU 0, .. PU 3), each padded to a token block with idle tokens, which leave the coder
+// untouched: same bins in the same order as :1530-1543.
+#define PIPE_HDR_OFF 2048     // the 35 header streams: token PIPE_HDR_OFF.. of the PU wave's candidate slots (a PU candidate uses < 200)
+HDN_EVAL void nxn_pipe(int y0_, int x0_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
+#ifndef IMCVT_HOSTEMU
+    if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);
+#endif
+    WaveMem &W = PM;
+    const WaveMem &W2 = WM(2);
+    u16 *tok2 = wave_tok(F.sc, 2);
+    const u16 *kept = tok2 + (size_t)NMODE * TOK_CAP + NXN_KEEP;
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
+    const RdW rw = rd_weights(F.job.q);
+    const int uy = y0 >> 2, ux = x0 >> 2;
+    while (lds_ld_i32(&SM.pipe_a) == 0) pipe_pause();
+    wave_sync();
+    LANES(l) {
+        if (l < NMODE) {
+            CuHdr J;
+            J.N = 8; J.shape = 2; J.ctx_split = -1;
+            for (int k = 0; k < 3; k++) J.mode[k] = W2.pu_mode[k];
+            J.mode[3] = l;
+            J.ml[0] = nb_mode(uy, ux - 1);     J.ma[0] = nb_mode(uy - 1, ux);
+            J.ml[1] = J.mode[0];               J.ma[1] = nb_mode(uy - 1, ux + 1);
+            J.ml[2] = nb_mode(uy + 1, ux - 1); J.ma[2] = J.mode[0];
+            J.ml[3] = J.mode[2];               J.ma[3] = J.mode[1];
+            W.tokn[l] = 0;
+            blk_idle((u32a *)W.pend[l]);
+            LaneStream ls;
+            TokW w = ls_begin(ls, W, l, lane_row(W, l), tok2 + (size_t)l * TOK_CAP + PIPE_HDR_OFF);
+            tk_cu_header(w, J);
+            ls_end(ls, w, W, l);
+        }
+    }
+    wave_sync();                                        // the headers are in memory; the token rows make room for the coders' contexts
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        const int nh = W.tokn[ll];
+        u8 *cx = W.u.p2.cx[ll]; LaneMem *lm = &W.u.p2.lm[ll];
+        u8 *gbuf = ubytes + (size_t)(PIPE_WAVE * NMODE + ll) * TRIAL_BYTES;
+        const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
+        Arith a = SM.entry_a[2];
+        const int len0 = arith_len(a);
+        if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i);
+        RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+        stream_seg(a, cx, lm, sink, hdr, on ? nh : 0);
+        for (int k = 0; k < 3; k++) stream_seg(a, cx, lm, sink, kept + k * NXN_KEEP_STRIDE, on ? W2.pu_cnt[k] : 0);
+        while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
+        wave_sync();
+        const int mine = on & (l == W2.pu_mode[3]);
+        stream_seg(a, cx, lm, sink, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+        if (mine) ring_finish(sink, a.cnt);
+        const int ovf = mine & (sink.ovf != 0);
+        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — the whole stream again on the safe path
+            if (ovf) { a = SM.entry_a[2]; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i); }
+            Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
+            stream_seg_safe(a, cx, ss, hdr, ovf ? nh : 0);
+            for (int k = 0; k < 4; k++) stream_seg_safe(a, cx, ss, kept + k * NXN_KEEP_STRIDE, ovf ? W2.pu_cnt[k] : 0);
+        }
+        if (mine) {
+            W.fin[0] = pack_arith(a);
+            WM(2).nxn_cost = rd_cost(rw, W2.pu_sse[0] + W2.pu_sse[1] + W2.pu_sse[2] + W2.pu_sse[3], arith_len(a) - len0);
+            SM.nxn_lane = l;
+        }
+        if (l == 0) { lds_st_i32(&SM.pipe_a, 0); lds_st_i32(&SM.pipe_b, 0); }      // (the PU wave sets them again only after the workgroup barrier that ends this CU)
+    }
+    wave_sync();
+#ifndef IMCVT_HOSTEMU
+    if (F.prio_base) SETPRIO(2); else SETPRIO(0);
+#endif
+}
+
 // ---- the winner's reconstruction (only the winner's is ever needed, so candidates do not store theirs): the winning
 // 2Nx2N shape is run once more, writing the tile.  All waves call this; wave 0 works.
 HDN void rebuild_winner(int kind_, int mode_, int N_, int y0_, int x0_, int avm_) {
@@ -283,8 +378,9 @@ HDN void rebuild_winner(int kind_, int mode_, int N_, int y0_, int x0_, int avm_
 HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     u8 *live_sink = F.job.out + F.out_pos;
-    WAVES(w) {
-        if (w < 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
+    WAVES_ALL(w) {
+        if (w >= NWAVES && N < 16) nxn_pipe(y0, x0);
+        else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else eval_NxN(2, y0, x0, avm);
     }
     wg_sync_p();
@@ -319,14 +415,16 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     wg_sync_p();
     const int kind = SM.win_kind, mode = SM.win_mode;
     if (kind != 0) {
-        const int ww = (kind == 3) ? 2 : kind - 1, wl = (kind == 3) ? 0 : mode;
-        const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WM(ww).fin[wl].w2 >> 16);
+        const int pk = (kind == 3) && F.pipe;             // the NxN trial ran on the pipe wave: its result sits in that wave's slice, lane nxn_lane
+        const int ww = pk ? PIPE_WAVE : (kind == 3) ? 2 : kind - 1, wl = pk ? SM.nxn_lane : (kind == 3) ? 0 : mode, fl = pk ? 0 : wl;
+        const WaveMem &WW = pk ? PM : WM(ww);
+        const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WW.fin[fl].w2 >> 16);
         const u8 *src = lane_bytes(F.sc, ww, wl);
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
             for (int i = tid; i < cnt1 - cnt0; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(src + i));
-            if (tid < CTX_STRIDE) SM.cx[tid] = WM(ww).u.p2.cx[wl][tid];
-            if (tid == 64) SM.live = unpack_arith(WM(ww).fin[wl]);
+            if (tid < CTX_STRIDE) SM.cx[tid] = WW.u.p2.cx[wl][tid];
+            if (tid == 64) SM.live = unpack_arith(WW.fin[fl]);
             if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445, :1549-1553)
                 const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
                 if (i < n && j < n) {
@@ -617,7 +715,7 @@ HDN void serve_request(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m
     }
     wg_sync();
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->pad0_[1], (u32)wd_now()); hb_beat(); } }      // (debug stamps: staged / evaluated / about to publish)
-    WAVES(w) eval_2Nx2N(w, depth, N, y0, x0, avm);
+    WAVES_ALL(w) eval_2Nx2N(w, depth, N, y0, x0, avm);
     wg_sync();
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->pad0_[2], (u32)wd_now()); hb_beat(); } }
     WAVES(w) LANES(l) {
@@ -938,6 +1036,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;

@@ -15,7 +15,7 @@
 #include "hevc_tables.h"
 #include "../../include/imcvt_hevc.h"
 
-__global__ __launch_bounds__(WG_THREADS, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
+__global__ __launch_bounds__(WG_THREADS_PIPE, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
                                                                  TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk) {
     KArgs A;
@@ -44,6 +44,7 @@ struct imcvt_hevc_ctx {
     int post16 = -1, post32 = -1;           // pool tuning: per mille of the 16x16 / 32x32 CUs offered to the helpers (IMCVT_POOL_POST16 / _POST32; < 0: from the launch shape)
     int lim16 = -1, lim32 = -1, prio = -1;  // pool tuning (IMCVT_POOL_LIM16 / _LIM32 / _PRIO; < 0: defaults from the launch shape)
     int last_mains = 0, last_help = 0;
+    int pipe = -1, pipe_wg = 0, last_pipe = 0;   // pipe wave (256-thread workgroups): < 0 whenever the launch fits pipe_wg workgroups (3 per CU), 0 never, 1 as -1 (forced on where it fits)
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
@@ -57,7 +58,7 @@ static bool have_device() {
     return true;
 }
 
-extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r3 (wg=192; a frame per workgroup, or main workgroups + a pool of helper workgroups when the batch leaves room; N = 16 / 32 transforms on the matrix cores)"; }
+extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r3 (wg=192, or 256 with a pipe wave when the launch leaves room; a frame per workgroup, or main workgroups + a pool of helper workgroups when the batch leaves room; N = 16 / 32 transforms on the matrix cores)"; }
 extern "C" int imcvt_hevc_padded(int v) { return ((v < 8192 ? v : 8192) + 31) / 32 * 32; }
 extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 32) * (h + 32) + 65536; }
 
@@ -84,8 +85,9 @@ static int pool_limit(int nmains, int nhelp, int kind) {
     const int v = kind == 0 ? per_shard / 2 : per_shard;
     return v > 1 ? v : 1;
 }
-static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp) {
-    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(WG_THREADS), 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
+// pipe: the workgroups carry a fourth wavefront (hevc_frame.h nxn_pipe) and its LDS slice; three such workgroups fit a CU
+static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0) {
+    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(pipe ? WG_THREADS_PIPE : WG_THREADS), pipe ? PIPE_LDS_BYTES : 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
                        (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
                        c->post16 >= 0 ? c->post16 : pool_split(nmains, nhelp, 0), c->post32 >= 0 ? c->post32 : pool_split(nmains, nhelp, 1),
                        c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1), c->d_fclk);
@@ -114,6 +116,8 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     if (const char *e = getenv("IMCVT_POOL_LIM16")) c->lim16 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_LIM32")) c->lim32 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_PRIO")) c->prio = atoi(e);
+    c->pipe_wg = c->max_wg / 4 * 3;                     // registers (4 x 168 per workgroup) and LDS (40.6 + 6.9 KB) admit 3 per CU
+    if (const char *e = getenv("IMCVT_HEVC_PIPE")) c->pipe = atoi(e);
     c->mail_cap = c->max_wg / 2 + 8;
     Tables *T = new Tables(); ColdTables *K = new ColdTables();
     imcvt::build_tables(*T, *K);
@@ -166,6 +170,8 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
 
 extern "C" void imcvt_hevc_set_frame_clock(imcvt_hevc_ctx *c, unsigned long long *d_buf) { if (c) c->d_fclk = d_buf; }
 extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
+extern "C" void imcvt_hevc_set_pipe(imcvt_hevc_ctx *c, int mode) { if (c) c->pipe = mode; }
+extern "C" int imcvt_hevc_last_pipe(imcvt_hevc_ctx *c) { return c ? c->last_pipe : IMCVT_ERR_ARG; }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) {
     if (!c) return IMCVT_ERR_ARG;
@@ -263,6 +269,10 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemsetAsync(c->d_counter + 6, 0, 2 * sizeof(int), stream));
     int nmains = 0, nhelp = 0;
     const int mode = pick_shape(c, n, &nmains, &nhelp);
+    // Pipe wave (256-thread workgroups, three per CU): used when the launch fits, with the same sixteenth of the slots left free
+    // as in imcvt_hevc_plan.  A pool that just misses the limit gives up helpers for it as long as 1.5 per main workgroup remain.
+    const int pipe_cap = c->pipe_wg - c->pipe_wg / 16;
+    if (c->pipe != 0 && mode > 1 && c->force_mains <= 0 && nmains + nhelp > pipe_cap && nmains + (3 * nmains + 1) / 2 <= pipe_cap) nhelp = pipe_cap - nmains;
     const int grid = nmains + nhelp;
     if (mode > 1) {
         HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nmains, stream));     // sequence numbers restart with every launch
@@ -270,8 +280,12 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     if (grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) { fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
     c->last_mains = nmains; c->last_help = nhelp;
+    // Launches that leave a quarter of the workgroup slots free are latency-bound (every frame waits for the serial chain of
+    // its 8x8 CUs): their workgroups get the pipe wave, which takes the NxN trial off that chain.  Fuller launches keep four
+    // 192-thread workgroups per CU.
+    c->last_pipe = (c->pipe != 0 && grid <= pipe_cap) ? 1 : 0;
     HIPCHK(hipEventRecord(c->ev0, stream));
-    launch(c, grid, stream, n, mode, nmains, nhelp);
+    launch(c, grid, stream, n, mode, nmains, nhelp, c->last_pipe);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;

@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan")
+           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -78,6 +78,10 @@ def load_library():
     lib.imcvt_hevc_version.argtypes = []
     lib.imcvt_hevc_set_team.restype = None
     lib.imcvt_hevc_set_team.argtypes = [C.c_void_p, C.c_int]
+    lib.imcvt_hevc_set_pipe.restype = None
+    lib.imcvt_hevc_set_pipe.argtypes = [C.c_void_p, C.c_int]
+    lib.imcvt_hevc_last_pipe.restype = C.c_int
+    lib.imcvt_hevc_last_pipe.argtypes = [C.c_void_p]
     lib.imcvt_hevc_last_team.restype = C.c_int
     lib.imcvt_hevc_last_team.argtypes = [C.c_void_p, _ip]
     lib.imcvt_hevc_batch_devices.restype = C.c_int
@@ -190,6 +194,14 @@ class DeviceEncoder:
     def set_team(self, team_size: int):
         """Helper workgroups: 0 = chosen per launch, 1 = none (a frame per workgroup), 2 / 3 = one / two per main workgroup (same results)."""
         self.lib.imcvt_hevc_set_team(self.ctx, int(team_size))
+
+    def set_pipe(self, mode: int):
+        """Pipe wave (256-thread workgroups, the NxN trial of the 8x8 CUs off the PU chain): < 0 / 1 = whenever the launch fits three workgroups per CU, 0 = never (same results)."""
+        self.lib.imcvt_hevc_set_pipe(self.ctx, int(mode))
+
+    def last_pipe(self) -> bool:
+        """True if the last launch ran with the pipe wave."""
+        return int(self.lib.imcvt_hevc_last_pipe(self.ctx)) == 1
 
     def last_team(self):
         """(1 / 2 / 3 = no / fewer than two / two helpers per main workgroup, main workgroups of a launch with helpers) of the last launch."""

@@ -101,6 +101,13 @@ int imcvt_hevc_encode_device(imcvt_hevc_ctx *ctx, int n, const imcvt_hevc_frame 
  * candidate sets for all of them), 1 = none, 2 / 3 = one / two helpers per main workgroup.
  * Results are identical for every setting.  Environment override at context creation: IMCVT_HEVC_TEAM. */
 void imcvt_hevc_set_team(imcvt_hevc_ctx *ctx, int team_size);
+/* Pipe wave: workgroups of 256 threads whose fourth wavefront prices the NxN candidate of every 8x8 CU ahead of time (all 35
+ * possible modes of the last PU), off the serial chain of the wave that walks the PUs — shorter frames when the device is not
+ * full (three such workgroups fit a compute unit instead of four).  mode < 0 (default) / 1: used whenever the launch fits three
+ * workgroups per compute unit; 0: never.  Results are identical.  Environment override at context creation: IMCVT_HEVC_PIPE. */
+void imcvt_hevc_set_pipe(imcvt_hevc_ctx *ctx, int mode);
+/* 1 if the last launch ran with the pipe wave, else 0. */
+int imcvt_hevc_last_pipe(imcvt_hevc_ctx *ctx);
 /* The choice itself, as a pure function (no device needed): launch shape for n_frames on a device that holds
  * max_workgroups resident workgroups of the encoder kernel (1024 on MI355X).  Returns 1 (a frame per workgroup,
  * *nmains workgroups, *nhelp = 0) or 2 (*nmains main workgroups + a pool of *nhelp helper workgroups). */

@@ -69,6 +69,19 @@ def hostemu_vec(built):
 
 
 @pytest.fixture(scope="session")
+def hostemu_pipe(built):
+    """Same, with 256-thread workgroups: the fourth wavefront is the pipe wave (hevc_frame.h nxn_pipe), which prices the NxN
+    candidate of every 8x8 CU for all 35 possible modes of the last PU while the PU wave is still working on it."""
+    return _hostemu_lib("libhostemu_pipe.so", ["-DEMU_DEFAULT_PIPE"])
+
+
+@pytest.fixture(scope="session")
+def hostemu_pipe_ovf(built):
+    """Pipe wave + every rare-path byte overflows the trial coders' rings: the pipe wave's safe-path repeat of its stream."""
+    return _hostemu_lib("libhostemu_pipe_ovf.so", ["-DEMU_DEFAULT_PIPE", "-DIMCVT_FORCE_OVF"])
+
+
+@pytest.fixture(scope="session")
 def hostemu_abn(built):
     """Same, with main workgroups that stop waiting for a helper's answer after three polls: exercises the path on which a late
     answer is abandoned, the CU evaluated by the main workgroup itself and the mailbox left alone until the answer has arrived."""

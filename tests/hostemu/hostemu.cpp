@@ -1,5 +1,5 @@
 // tests/hostemu/hostemu.cpp — TEST-ONLY harness: compiles the device encoder source (imcvt_amd/csrc/hevc_core.h,
-// hevc_frame.h) for the host.  Every lane of every 192-thread workgroup is a cooperative fiber with its own stack, so
+// hevc_frame.h) for the host.  Every lane of every 192-thread (256 with a pipe wave) workgroup is a cooperative fiber with its own stack, so
 // the kernel runs under real SIMT semantics: registers survive barriers, divergent lanes make independent progress,
 // wave_sync()/wg_sync() are true barriers and ballots/shuffles are collectives.  It exists so the bit-exactness of
 // the kernel LOGIC can be checked against the oracle on a machine without a GPU; it is not part of the product,
@@ -17,9 +17,15 @@ asm(".text\n.globl emu_ctx_switch\n.type emu_ctx_switch,@function\nemu_ctx_switc
     "  movq %rsp,(%rdi)\n  movq %rsi,%rsp\n"
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n");
 
-#define EMU_WG_THREADS 192
+#define EMU_WG_THREADS_MAX 256                              // 192, or 256 when the workgroups carry a pipe wave (hostemu_set_pipe)
+#ifdef EMU_DEFAULT_PIPE
+static int g_wg_threads = 256;
+#else
+static int g_wg_threads = 192;
+#endif
+#define EMU_WG_THREADS g_wg_threads
 #define EMU_MAX_WG 6                                        // main + helper workgroups of one emulated launch
-#define EMU_THREADS (EMU_WG_THREADS * EMU_MAX_WG)
+#define EMU_THREADS (EMU_WG_THREADS_MAX * EMU_MAX_WG)
 #define EMU_STACK (512 * 1024)
 struct EmuFiber {
     void *sp; char *stack; int done;
@@ -28,8 +34,8 @@ struct EmuFiber {
 static EmuFiber g_fib[EMU_THREADS];
 static void *g_main_sp;
 static int g_cur;                                           // running fiber (= blockIdx.x * 192 + threadIdx.x)
-static int g_nfib = EMU_WG_THREADS;                         // fibers of this run (192 per workgroup)
-static unsigned g_wave_gen[3 * EMU_MAX_WG], g_wave_arr[3 * EMU_MAX_WG], g_wg_gen[EMU_MAX_WG], g_wg_arr[EMU_MAX_WG];
+static int g_nfib = 192;                                    // fibers of this run (192 or 256 per workgroup)
+static unsigned g_wave_gen[4 * EMU_MAX_WG], g_wave_arr[4 * EMU_MAX_WG], g_wg_gen[EMU_MAX_WG], g_wg_arr[EMU_MAX_WG];
 static uint64_t g_xchg[EMU_THREADS];                        // collective exchange slots
 static void (*g_entry)(void);
 static unsigned g_yield_gen;                                // a yielding fiber is runnable again at once
@@ -49,7 +55,7 @@ static void emu_wave_sync() {
 }
 static void emu_wg_sync() {
     const int b = emu_block();
-    if (++g_wg_arr[b] == EMU_WG_THREADS) { g_wg_arr[b] = 0; g_wg_gen[b]++; }
+    if (++g_wg_arr[b] == (unsigned)EMU_WG_THREADS) { g_wg_arr[b] = 0; g_wg_gen[b]++; }
     else emu_wait(&g_wg_gen[b], g_wg_gen[b]);
 }
 static void emu_yield() {                                   // spin-wait on another workgroup's flag: let everyone else run
@@ -74,7 +80,7 @@ static int emu_shfl(int v, int src_lane) {                  // value of `v` held
 }
 // Matrix instructions (wave collectives): every lane deposits its operand registers, then computes the result registers
 // the hardware would hand it.  Layouts as verified on the device by tools/mfma_probe.hip.
-static uint32_t g_mx[3 * EMU_MAX_WG][64][8];                // per lane: a[0..3], b[0..3]
+static uint32_t g_mx[4 * EMU_MAX_WG][64][8];                // per lane: a[0..3], b[0..3]
 static long g_mfma_calls[2];                                // wave-level matrix instructions issued so far (32x32x32, 16x16x32)
 static int emu_sx8(uint32_t w, int k) { return (int)(int8_t)(w >> (8 * k)); }
 // v_mfma_i32_32x32x32_i8: lane l holds A[l%32][16*(l/32) .. +15], B[16*(l/32) .. +15][l%32]; acc r: D[8*(r/4) + 4*(l/32) + r%4][l%32]
@@ -109,6 +115,8 @@ static void emu_mfma16(const uint32_t *a, const uint32_t *b, int *acc) {
 }
 struct Shm;
 static Shm *g_shm_of[EMU_MAX_WG];                          // each emulated workgroup's LDS image
+static unsigned char *g_pipe_of[EMU_MAX_WG];               // ... and its dynamic part (the pipe wave's slice)
+static int emu_pipe_on() { return g_wg_threads > 192; }
 static long g_spins;
 static void emu_set_shm(int wg);                            // (defined below, next to the device source's LDS pointer)
 static void emu_trampoline() {
@@ -151,7 +159,7 @@ static void emu_run(void (*entry)(void)) {
 #include "../../imcvt_amd/csrc/hevc_frame.h"
 #include "../../imcvt_amd/csrc/hevc_tables.h"
 
-static void emu_set_shm(int wg) { g_shm_host = g_shm_of[wg]; }
+static void emu_set_shm(int wg) { g_shm_host = g_shm_of[wg]; g_pipe_host = g_pipe_of[wg]; }
 static KArgs g_args;
 static void emu_entry() { kernel_main(g_args, emu_block()); }
 
@@ -179,6 +187,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     Scratch sc[EMU_MAX_WG]; void *pool[EMU_MAX_WG];
     for (int b = 0; b < nwg; b++) {
         g_shm_of[b] = (Shm *)calloc(1, sizeof(Shm));
+        g_pipe_of[b] = (unsigned char *)aligned_alloc(16, PIPE_LDS_BYTES); memset(g_pipe_of[b], 0xA5, PIPE_LDS_BYTES);      // (LDS is not zeroed on the device either)
         pool[b] = calloc(1, scratch_bytes_per_wg());
         scratch_carve(sc[b], (u8 *)pool[b]);
     }
@@ -191,7 +200,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.post16 = 750; g_args.post32 = 1000; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0; g_args.quota = getenv("HOSTEMU_QUOTA") ? atoi(getenv("HOSTEMU_QUOTA")) : 1; g_args.fclk = nullptr;      // (quota 0: no workgroup starts as a main one — idle helpers take the roles)
     g_nfib = nwg * EMU_WG_THREADS; g_spins = 0;
     emu_run(emu_entry);
-    for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); }
+    for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); free(g_pipe_of[b]); }
     free(mail); free(pq); free(jobs); free(hdrs);
     return 0;
 }
@@ -207,8 +216,11 @@ extern "C" int hostemu_HEVCImageEncoderPool(int n, unsigned char *const *pbuffer
                                             int *ysz, int *xsz, int qpd6, int *out_len, int nmains, int nhelp) {
     return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, nmains, nhelp);
 }
+// 1: the emulated workgroups have 256 threads, the fourth wavefront being the pipe wave (hevc_frame.h nxn_pipe); 0: 192 threads
+extern "C" void hostemu_set_pipe(int on) { g_wg_threads = on ? 256 : 192; }
 extern "C" long hostemu_mfma_calls(int kind) { return g_mfma_calls[kind & 1]; }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
+extern "C" int hostemu_pipe_lds_bytes(void) { return (int)PIPE_LDS_BYTES; }
 
 // The device's RDOQ (rdoq_group, hevc_core.h) on a sz x sz block of transform coefficients, group by group, with the thresholds
 // the host derives for qpd6 (hevc_tables.h) staged as a frame stages them.  dst: signed levels; groups the weak-group test

@@ -248,6 +248,49 @@ def test_auto_team_choice_and_full_hd_team(amd):
     enc.close()
 
 
+@pytest.mark.parametrize("team", [1, 3])
+@pytest.mark.parametrize("pipe", [0, 1])
+def test_pipe_wave_on_and_off(amd, pipe, team):
+    """256-thread workgroups whose fourth wavefront prices the NxN candidate of the 8x8 CUs ahead of the PU wave (hevc_frame.h
+    nxn_pipe) against 192-thread ones, alone and as main workgroups of a pool: all small golden vectors, twice each."""
+    import torch
+    enc = amd.DeviceEncoder()
+    enc.set_pipe(pipe); enc.set_team(team)
+    batch = enc.make_batch([torch.from_numpy(np.ascontiguousarray(kat_input(e["input"]))).cuda() for e in SMALL], [e["qpd6"] for e in SMALL])
+    for rep in range(2):
+        enc.encode(batch)
+        got = enc.results(batch)
+        assert enc.last_pipe() == bool(pipe) and enc.last_team()[0] == team
+        bad = [kat_id(e) for e, (s, r) in zip(SMALL, got)
+               if len(s) != e["bytes"] or hashlib.sha256(s).hexdigest() != e["sha256"] or hashlib.sha256(r.tobytes()).hexdigest() != e["rcon_sha256"]]
+        assert not bad, (pipe, team, rep, bad)
+    enc.close()
+
+
+def test_pipe_wave_full_hd_frame_and_launches_too_large_for_it(amd):
+    """One 1080p frame with the pipe wave (the default for a launch that leaves room) has the reference's digest; a launch that
+    needs four workgroups per compute unit runs without it, same results as with it forced off."""
+    import torch
+    from oracle import synth
+    e = next(e for e in LARGE if (e["input"]["arg"], e["qpd6"]) == (2, 0))
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, 2)).cuda()], 0)
+    enc.encode(batch)
+    (s, r), = enc.results(batch)
+    assert enc.last_pipe() and enc.last_team()[0] == 3
+    assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
+    imgs = [torch.from_numpy(synth.syn(96, 64, i)).cuda() for i in range(800)]
+    big = enc.make_batch(imgs, 1)
+    enc.encode(big); a = enc.results(big)
+    assert not enc.last_pipe()
+    enc.set_pipe(1); enc.set_team(1)
+    sub = enc.make_batch(imgs[:300], 1)
+    enc.encode(sub); b = enc.results(sub)
+    assert enc.last_pipe()
+    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, b))
+    enc.close()
+
+
 def test_host_batch_uses_the_visible_devices(amd):
     """HEVCImageEncoderBatch fans frames out over min(n, devices) devices; one device on this box, results unchanged."""
     import torch

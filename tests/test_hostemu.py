@@ -72,6 +72,24 @@ def test_vector_transform_build_matches_golden(hostemu_vec, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+@pytest.mark.parametrize("e", PICK, ids=kat_id)
+def test_pipe_wave_matches_golden(hostemu_pipe, e):
+    # 256-thread workgroups: the NxN trial of every 8x8 CU runs on the pipe wave, 35 guesses of the last PU's mode ahead of the
+    # PU wave (hevc_frame.h nxn_pipe); the emulated wavefronts are concurrent fibers, so the flag hand-offs between them are real
+    stream, rcon = emu_encode(hostemu_pipe, kat_input(e["input"]), e["qpd6"])
+    assert len(stream) == e["bytes"]
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_pipe_wave_ring_overflow_path_matches_golden(hostemu_pipe_ovf, e):
+    # the lane that holds the NxN result repeats header + four PU segments on the safe path when its byte ring overflowed
+    stream, rcon = emu_encode(hostemu_pipe_ovf, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
 def _extreme_pictures():
     rng = np.random.default_rng(1)
     pics = {"bw_noise": rng.integers(0, 2, (32, 64), dtype=np.uint8) * 255, "noise": rng.integers(0, 256, (32, 64), dtype=np.uint8)}
@@ -182,6 +200,18 @@ def test_pool_modes_match_golden(hostemu, q, nmains, nhelp):
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
 
 
+@pytest.mark.parametrize("nmains,nhelp", [(1, 2), (2, 3), (1, 0), (3, 0)])
+@pytest.mark.parametrize("q", [0, 4])
+def test_pipe_wave_with_and_without_helpers(hostemu_pipe, q, nmains, nhelp):
+    """Pipe-wave workgroups as main workgroups of a pool (their helpers' fourth wavefront only keeps the barrier count) and as
+    plain frame-per-workgroup launches pulling several frames each: the reference's bytes."""
+    es = [e for e in OVF if e["qpd6"] == q]
+    res = emu_encode_pool(hostemu_pipe, [kat_input(e["input"]) for e in es], q, nmains, nhelp)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
 @pytest.mark.parametrize("nmains,nhelp", [(1, 1), (2, 2), (4, 1)])
 @pytest.mark.parametrize("q", [0, 3])
 def test_abandoned_answers_are_recomputed_by_the_main_workgroup(hostemu_abn, q, nmains, nhelp):
@@ -238,3 +268,6 @@ def _emu_big(lib, img, q):
 def test_lds_budget(hostemu):
     # two workgroups per CU need <= 80 KiB each (160 KiB LDS per CU)
     assert hostemu.hostemu_shm_bytes() <= 80 * 1024
+    # four 192-thread workgroups per CU, or three 256-thread ones with the pipe wave's dynamic slice
+    assert 4 * hostemu.hostemu_shm_bytes() <= 160 * 1024
+    assert 3 * (hostemu.hostemu_shm_bytes() + hostemu.hostemu_pipe_lds_bytes()) <= 160 * 1024
