@@ -366,7 +366,8 @@ def latency_view(enc, dev, qpd6):
         okd = (hashlib.sha256(b["outs"][0][:n].cpu().numpy().tobytes()).hexdigest() == e["sha256"]) if e else None
         if okd is False:
             raise SystemExit(f"latency_view {name}: stream differs from the reference digest")
-        out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(w * h / ms / 1e3, 3), "bytes": n, "sha256_equal_to_reference": okd}
+        out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(w * h / ms / 1e3, 3), "bytes": n, "sha256_equal_to_reference": okd,
+                     "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe()}
     return out
 
 

@@ -893,7 +893,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
             encode_ctu();
         }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
-    if (sc.prof && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(threadIdx.x >> 6) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);   // role 0's slice
+    if (sc.prof && threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(threadIdx.x >> 6) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);   // role 0's slice
 #endif
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) {
@@ -925,7 +925,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
     const int home_blk = home;
     stage_tables(gT);
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
-    if ((threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
+    if (threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
 #endif
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = (TeamMail *)0; F.pq = pq; F.seq[0] = 0; F.seq[1] = 0; F.frame = -1; m_add32(&pq->alive, 1u); } }
     wg_sync();
@@ -987,7 +987,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
         wg_sync();
     }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
-    if (sc.prof && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(role * NWAVES + (threadIdx.x >> 6)) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);
+    if (sc.prof && threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(role * NWAVES + (threadIdx.x >> 6)) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);
 #endif
     (void)role;
     return taken;

@@ -283,7 +283,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     // Launches that leave a quarter of the workgroup slots free are latency-bound (every frame waits for the serial chain of
     // its 8x8 CUs): their workgroups get the pipe wave, which takes the NxN trial off that chain.  Fuller launches keep four
     // 192-thread workgroups per CU.
-    c->last_pipe = (c->pipe != 0 && grid <= pipe_cap) ? 1 : 0;
+    c->last_pipe = (c->pipe != 0 && grid <= (c->force_mains > 0 ? c->pipe_wg : pipe_cap)) ? 1 : 0;      // (a forced shape may fill the last slot)
     HIPCHK(hipEventRecord(c->ev0, stream));
     launch(c, grid, stream, n, mode, nmains, nhelp, c->last_pipe);
     HIPCHK(hipGetLastError());

@@ -49,4 +49,4 @@ for sh in sys.argv[5:]:
     dig = hashlib.sha256(b"".join(s for s, _ in enc.results(batch))).hexdigest()[:16]
     if ref is None:
         ref = dig
-    print(f"{n} x {w}x{h} q{q} shape {sh:>18s} -> {enc.last_shape()}: kernel ms {[round(v, 1) for v in ms]} resident {resid}  {w * h * n / min(ms) / 1e3:7.2f} Mpx/s  digest {dig} {'same' if dig == ref else 'DIFFERENT'}", flush=True)
+    print(f"{n} x {w}x{h} q{q} shape {sh:>18s} -> {enc.last_shape()}{' + pipe wave' if enc.last_pipe() else ''}: kernel ms {[round(v, 1) for v in ms]} resident {resid}  {w * h * n / min(ms) / 1e3:7.2f} Mpx/s  digest {dig} {'same' if dig == ref else 'DIFFERENT'}", flush=True)
