@@ -64,8 +64,11 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD void drain_stores() {}
 #else
   #define HD __device__ __forceinline__
+  // Out-of-line device functions.  not_tail_called keeps LLVM's `tail` marker off their call sites; with the marker on any call site
+  // the AMDGPU backend does not apply its no-callee-saved-registers optimisation to an internal function, and the candidate-set
+  // functions (168 registers each, nothing live in their callers) then open with 67 scratch stores and close with 67 loads per call.
   #ifndef HDN
-  #define HDN __device__ __noinline__
+  #define HDN __device__ __noinline__ __attribute__((not_tail_called))
   #endif
   #define LANES(l) for (int l = (int)(threadIdx.x & 63u), l##_once = 1; l##_once; l##_once = 0)
   #define WAVES(w) for (int w = (int)(threadIdx.x >> 6), w##_once = (w < NWAVES); w##_once; w##_once = 0)      // the pipe wave sits these out
