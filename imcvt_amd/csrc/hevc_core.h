@@ -434,6 +434,7 @@ struct alignas(16) Shm {
     i32 next_frame;              // job index pulled from the queue
     i32 pipe_a, pipe_b;          // PU wave -> pipe wave: the winners of PUs 0..2 / of PU 3 are in place (cleared by the pipe wave)
     i32 nxn_lane;                // pipe wave: the lane that holds the NxN trial's result (= PU 3's mode)
+    i32 pu0_ready, pu0_taken;    // 8x8 CU: the PU wave's pass over PU 0 is complete / the four-TU wave has taken its copy (hevc_frame.h tu0_from_pu0)
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
 #endif

@@ -47,6 +47,41 @@ HD int nb_mode(const int uy, int ux) { return SM.mapmode[uy + 1][ux + 1]; }
 // upper modes of BOTH sets (modes are independent; a four-TU mode's TU chain stays inside one wave), writing tokens, SSE
 // and token counts straight into the owners' arrays; the owners then price all 35 of their candidates.
 struct P1Item { int own, shape, lo, hi; };
+// TU 0 of the four-TU shape of an 8x8 CU is the same 4x4 block, predicted from the same samples in the same 35 modes, as PU 0 of
+// the NxN chain (:1459-1466 with isub = 0 against :1497-1512 with isub = 0): same levels, same tokens (an all-zero block apart,
+// whose residual syntax only PU pricing codes, :1515), same reconstruction.  The PU wave runs that pass anyway and first; the
+// four-TU wave takes its results instead of repeating it: lane c appends candidate c's tokens to its own stream and keeps the
+// bottom row / right column of its reconstruction for TUs 1..3.
+#ifndef TU0_SHARE
+#define TU0_SHARE 1
+#endif
+HDN void tu0_from_pu0(int wave_, u16 *tok1_) {          // (out of line: inlined it costs eval_2Nx2N's passes registers)
+    const int wave = uni_i(wave_); u16 *const tok1 = uni_p(tok1_);
+    WaveMem &W = WM(wave);
+    const WaveMem &W2 = WM(2);
+    const u16 *tok2 = wave_tok(F.sc, 2);
+    while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause();
+    wave_sync();
+    LANES(l) {
+        if (l < NMODE) {
+            const int c = l, nz = W2.tnz[c], cnt = nz ? W2.tokn[c] - 7 : 1;
+            const u16 *src = tok2 + (size_t)c * TOK_CAP + 7;
+            LaneStream ls;
+            TokW w = ls_begin(ls, W, c, lane_row(W, l), tok1 + (size_t)c * TOK_CAP);
+            NOUNROLL
+            for (int i = 0; i < cnt; i++) {
+                tk_put(w, (int)(u16)g_ld16((const i16 *)(src + i)));
+                if (w.n >= LCAP - 8) ls_flush(ls, w);
+            }
+            ls_end(ls, w, W, c);
+            W.tnz[c] = (u8)nz;
+            W.sse[c] += W2.sse[c];
+            for (int i = 0; i < 4; i++) { SM.X.t3row[c][0][i] = W2.u.w2.rec4[c][12 + i]; SM.X.t3col[c][0][i] = W2.u.w2.rec4[c][4 * i + 3]; }
+        }
+    }
+    wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_taken, 1); }
+}
 #ifndef SPL32_0
 #define SPL32_0 23
 #define SPL32_1 24
@@ -102,6 +137,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
             } else {
                 const Avail ca = child_avail(av, k);
                 const int yk = y0 + (k >> 1) * h, xk = x0 + (k & 1) * h;
+                if (TU0_SHARE && N == 8 && k == 0) { tu0_from_pu0(wave, P.tok); continue; }
                 if (k == 0) border_from_tile(wave, h, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
                 else border_tu_split(N, y0, x0, k, av.l, av.bl, av.a, av.ar, P.c_lo, P.c_hi);
                 P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
@@ -163,6 +199,11 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     for (int k = 0; k < 4; k++) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
+        if (TU0_SHARE && k == 1) {                      // the four-TU wave has its copy of PU 0's pass (long ago: it takes it while this wave prices PU 0)
+            while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause();
+            wave_sync_lds();
+            LANES(l) { if (l == 0) { lds_st_i32(&SM.pu0_ready, 0); lds_st_i32(&SM.pu0_taken, 0); } }
+        }
         LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.tokn[l] = 7; blk_idle((u32a *)W.pend[l]); } }
         wave_sync_lds();
         long long pt = prof_now();
@@ -174,6 +215,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         wave_sync();
+        if (TU0_SHARE && k == 0) { LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); } }      // tokens in memory, SSE / reconstructions in this wave's slice: the four-TU wave's TU 0
         prof_add(PF_P1_16, pt); pt = prof_now();
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             const int on = l < NMODE, ll = on ? l : 0;
@@ -1036,7 +1078,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; } }      // (read after the barriers below)
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;
