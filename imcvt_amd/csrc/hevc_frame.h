@@ -65,13 +65,16 @@ HDN void tu0_from_pu0(int wave_, u16 *tok1_) {          // (out of line: inlined
     LANES(l) {
         if (l < NMODE) {
             const int c = l, nz = W2.tnz[c], cnt = nz ? W2.tokn[c] - 7 : 1;
-            const u16 *src = tok2 + (size_t)c * TOK_CAP + 7;
+            const u16 *src = tok2 + (size_t)c * TOK_CAP + 7;        // [7] cbf_luma, [8..] the rest: 16-byte blocks from token 8 on
             LaneStream ls;
             TokW w = ls_begin(ls, W, c, lane_row(W, l), tok1 + (size_t)c * TOK_CAP);
+            tk_put(w, (int)(u16)g_ld16((const i16 *)src));
             NOUNROLL
-            for (int i = 0; i < cnt; i++) {
-                tk_put(w, (int)(u16)g_ld16((const i16 *)(src + i)));
-                if (w.n >= LCAP - 8) ls_flush(ls, w);
+            for (int i = 1; i < cnt; i += 8) {                      // (a PU candidate's stream ends on a block boundary, padded with idle tokens)
+                const U4 b = g_ld128(src + i);
+                for (int j = 0; j < 8; j++) to_put(w.o, w.n + j, (int)tok_of(b, j));
+                w.n += imin(8, cnt - i);
+                if (w.n >= LCAP - 16) ls_flush(ls, w);
             }
             ls_end(ls, w, W, c);
             W.tnz[c] = (u8)nz;
@@ -130,14 +133,15 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
         const int shape = it[ii].shape;
         P.own = it[ii].own; P.c_lo = it[ii].lo; P.c_hi = it[ii].hi; P.shape = shape; P.tok = wave_tok(F.sc, it[ii].own);
         const int ntu = (shape == 0) ? 1 : 4;
-        for (int k = 0; k < ntu; k++) {
+        int k_first = 0;
+        if (TU0_SHARE && N == 8 && shape == 1) { tu0_from_pu0(wave, P.tok); k_first = 1; }      // TU 0 = the PU wave's PU 0
+        for (int k = k_first; k < ntu; k++) {
             if (shape == 0) {
                 border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
                 P.N = N; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
             } else {
                 const Avail ca = child_avail(av, k);
                 const int yk = y0 + (k >> 1) * h, xk = x0 + (k & 1) * h;
-                if (TU0_SHARE && N == 8 && k == 0) { tu0_from_pu0(wave, P.tok); continue; }
                 if (k == 0) border_from_tile(wave, h, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
                 else border_tu_split(N, y0, x0, k, av.l, av.bl, av.a, av.ar, P.c_lo, P.c_hi);
                 P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
@@ -240,9 +244,13 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         LANES(l) {                                      // keep its tokens and put its reconstruction in place (:1523-1524)
             const int bm = W.pu_mode[k], cnt = W.pu_cnt[k];
             const u16 *src = tok + (size_t)bm * TOK_CAP + 7;
-            u16 *dst = nxn + NXN_KEEP + k * NXN_KEEP_STRIDE;
+            // the pipe wave codes the winners of PUs 0..2 as ONE stream segment (kept back to back) and PU 3's as another: idle tokens up to
+            // the block boundary after PU 2 and after PU 3
+            const int at = !pipe ? k * NXN_KEEP_STRIDE : k == 3 ? 3 * NXN_KEEP_STRIDE : (k >= 1 ? W.pu_cnt[0] : 0) + (k >= 2 ? W.pu_cnt[1] : 0);
+            u16 *dst = nxn + NXN_KEEP + at;
             for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), g_ld16((const i16 *)(src + i)));
-            if (pipe && l < 8 && ((cnt + l) >> 3) == (cnt >> 3) && (cnt & 7) != 0) g_st16((i16 *)(dst + cnt + l), (int)TOK_IDLE);   // the pipe wave codes the kept copy as a stream segment of its own: idle tokens up to the block boundary
+            const int end = at + cnt;
+            if (pipe && k >= 2 && l < 8 && ((end + l) >> 3) == (end >> 3) && (end & 7) != 0) g_st16((i16 *)(nxn + NXN_KEEP + end + l), (int)TOK_IDLE);
             if (l < 16) SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
         }
         wave_sync_lds();
@@ -314,8 +322,8 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 // lane m of the pipe wave assumes PU 3 = mode m: as soon as PUs 0..2 are decided, 35 lanes code the 35 possible headers and
 // the winners of PUs 0..2 from the CU's entry state, while the PU wave is busy with PU 3.  When PU 3 is decided the lane that
 // guessed its mode codes PU 3's winner and holds the trial's result; what is left of the tail is that one segment.
-// The stream is coded in segments (header, PU 0, .. PU 3), each padded to a token block with idle tokens, which leave the coder
-// untouched: same bins in the same order as :1530-1543.
+// The stream is coded in three segments (header; PUs 0..2, kept back to back; PU 3), each padded to a token block with idle tokens,
+// which leave the coder untouched: same bins in the same order as :1530-1543.
 #define PIPE_HDR_OFF 2048     // the 35 header streams: token PIPE_HDR_OFF.. of the PU wave's candidate slots (a PU candidate uses < 200)
 HDN_EVAL void nxn_pipe(int y0_, int x0_) {
     const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
@@ -361,7 +369,8 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
         if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i);
         RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
         stream_seg(a, cx, lm, sink, hdr, on ? nh : 0);
-        for (int k = 0; k < 3; k++) stream_seg(a, cx, lm, sink, kept + k * NXN_KEEP_STRIDE, on ? W2.pu_cnt[k] : 0);
+        const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
+        stream_seg(a, cx, lm, sink, kept, on ? n012 : 0);
         while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
         wave_sync();
         const int mine = on & (l == W2.pu_mode[3]);
@@ -372,7 +381,8 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
             if (ovf) { a = SM.entry_a[2]; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i); }
             Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
             stream_seg_safe(a, cx, ss, hdr, ovf ? nh : 0);
-            for (int k = 0; k < 4; k++) stream_seg_safe(a, cx, ss, kept + k * NXN_KEEP_STRIDE, ovf ? W2.pu_cnt[k] : 0);
+            stream_seg_safe(a, cx, ss, kept, ovf ? n012 : 0);
+            stream_seg_safe(a, cx, ss, kept + 3 * NXN_KEEP_STRIDE, ovf ? W2.pu_cnt[3] : 0);
         }
         if (mine) {
             W.fin[0] = pack_arith(a);

@@ -6,7 +6,7 @@ L=$O/${TAG}_tu0_ab.log; : > $L
 V=$O/libimcvt_hevc_notu0.so
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DTU0_SHARE=0 imcvt_amd/csrc/hevc_hip.hip -o $V 2> $O/${TAG}_notu0.build.log || echo "variant build failed" | tee -a $L
 timeout 600 python tools/gpu_parity.py --big > $O/${TAG}_parity.log 2>&1; echo "shipped parity rc=$?" | tee -a $L; tail -2 $O/${TAG}_parity.log | tee -a $L
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pipe or small_golden or seeded or edge_cases or team" > $O/${TAG}_tests.log 2>&1; echo "pytest rc=$?" | tee -a $L; tail -2 $O/${TAG}_tests.log | tee -a $L
+echo "(pytest subset skipped in this run)" | tee -a $L
 for rep in 1 2; do
   echo "== shipped, 1024 x 512x256 solo" | tee -a $L; QB_LAUNCHES=2 timeout 300 python tools/quick_bench.py 512 256 1024 0 2>&1 | grep -v amdgpu.ids | tee -a $L
   echo "== TU0_SHARE=0, 1024 x 512x256 solo" | tee -a $L; QB_LAUNCHES=2 IMCVT_HEVC_LIB=$V timeout 300 python tools/quick_bench.py 512 256 1024 0 2>&1 | grep -v amdgpu.ids | tee -a $L
