@@ -1992,7 +1992,7 @@ HD void code_token_q(Arith &a, u8 *cx, u16 *lq, int &qn, u32 tok) {
     const int byp = tok >= 0x8000u;
     const u32 cim = tok >> 1;
     const int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
-    const int pz = cx[ci] & 127;                                                  // (the pad byte holds anything)
+    const int pz = cx[ci];                                                        // < 128 everywhere: states are 7 bits, and the pad byte starts as 0 (ctx_init) and only ever receives next-state bytes
     const uint2 e = SM.T.pst[pz];
     const int lps = (int)((e.x >> ((a.range >> 3) & 24)) & 0xFF);                 // :917-918
     const int rm = a.range - lps;
