@@ -143,7 +143,7 @@ def test_rare_paths_on_the_device(amd, flag, tmp_path):
     from conftest import ROOT
     so = str(tmp_path / "libimcvt_hevc_variant.so")
     src = os.path.join(ROOT, "imcvt_amd", "csrc", "hevc_hip.hip")
-    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-mllvm", "-disable-machine-licm",
                     flag, src, "-o", so], check=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity.py")], env=dict(os.environ, IMCVT_HEVC_LIB=so),
                        capture_output=True, text=True, timeout=900)
@@ -164,7 +164,7 @@ def test_results_do_not_depend_on_inlining(amd, flags, tmp_path):
     from conftest import ROOT
     so = str(tmp_path / "libimcvt_hevc_variant.so")
     src = os.path.join(ROOT, "imcvt_amd", "csrc", "hevc_hip.hip")
-    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-mllvm", "-disable-machine-licm",
                     *flags, src, "-o", so], check=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity.py")], env=dict(os.environ, IMCVT_HEVC_LIB=so),
                        capture_output=True, text=True, timeout=900)

@@ -5,7 +5,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 L=$O/${TAG}_ab.log; : > $L
 timeout 600 python tools/gpu_parity.py --big >> $L 2>&1; echo "parity rc=$?" >> $L
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value "$@" imcvt_amd/csrc/hevc_hip.hip -o $O/libimcvt_hevc_var.so 2> $O/${TAG}_var.build.log || echo "variant build failed" >> $L
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -disable-machine-licm "$@" imcvt_amd/csrc/hevc_hip.hip -o $O/libimcvt_hevc_var.so 2> $O/${TAG}_var.build.log || echo "variant build failed" >> $L
 for rep in 1 2; do
   echo "== shipped" >> $L; timeout 300 python tools/quick_bench.py 512 256 1024 0 >> $L 2>&1
   echo "== variant $*" >> $L; IMCVT_HEVC_LIB=$O/libimcvt_hevc_var.so timeout 300 python tools/quick_bench.py 512 256 1024 0 >> $L 2>&1

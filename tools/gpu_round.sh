@@ -11,6 +11,6 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/rocprof_${TAG} -o ${TAG} -- p
 cd $R
 DB=$(find $O/rocprof_${TAG} -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_trace_stats.txt && cat $O/${TAG}_kernel_trace_stats.txt
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DIMCVT_PROF imcvt_amd/csrc/hevc_hip.hip -o $O/libimcvt_hevc_prof.so 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -disable-machine-licm -DIMCVT_PROF imcvt_amd/csrc/hevc_hip.hip -o $O/libimcvt_hevc_prof.so 2>/dev/null
 ( IMCVT_HEVC_LIB=$O/libimcvt_hevc_prof.so timeout 300 python tools/prof_phases.py 512 256 1 0;  IMCVT_HEVC_LIB=$O/libimcvt_hevc_prof.so timeout 300 python tools/prof_phases.py 512 256 1024 0 ) > $O/${TAG}_phase_cycles.log 2>&1
 cat $O/${TAG}_phase_cycles.log

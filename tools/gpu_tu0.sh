@@ -4,7 +4,7 @@
 TAG=${1:-r03t2}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 L=$O/${TAG}_tu0_ab.log; : > $L
 V=$O/libimcvt_hevc_notu0.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DTU0_SHARE=0 imcvt_amd/csrc/hevc_hip.hip -o $V 2> $O/${TAG}_notu0.build.log || echo "variant build failed" | tee -a $L
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -disable-machine-licm -DTU0_SHARE=0 imcvt_amd/csrc/hevc_hip.hip -o $V 2> $O/${TAG}_notu0.build.log || echo "variant build failed" | tee -a $L
 timeout 600 python tools/gpu_parity.py --big > $O/${TAG}_parity.log 2>&1; echo "shipped parity rc=$?" | tee -a $L; tail -2 $O/${TAG}_parity.log | tee -a $L
 echo "(pytest subset skipped in this run)" | tee -a $L
 for rep in 1 2; do

@@ -6,7 +6,7 @@ L=$O/${TAG}_variants.log; : > $L
 n=0; libs=()
 for fl in "$@"; do
   so=$O/libimcvt_hevc_v$n.so
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $fl imcvt_amd/csrc/hevc_hip.hip -o $so 2> $O/${TAG}_v$n.build.log || echo "build failed: $fl" >> $L
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -disable-machine-licm $fl imcvt_amd/csrc/hevc_hip.hip -o $so 2> $O/${TAG}_v$n.build.log || echo "build failed: $fl" >> $L
   libs+=("$so"); n=$((n+1))
 done
 for rep in 1 2 3; do

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "imcvt_amd", "csrc", "hevc_hip.hip")
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
-    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-DIMCVT_MARK",
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-mllvm", "-disable-machine-licm", "-DIMCVT_MARK",
                     "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
 fn, inst, c = "?", collections.Counter(), collections.Counter()
