@@ -64,14 +64,16 @@ extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 3
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Balance of a launch with helpers.  Per CTU a main workgroup spends about 1.5 units on the 8x8 CUs (which it always walks itself)
+// Balance of a launch with helpers.  Per CTU a main workgroup spends about 1.35 units on the 8x8 CUs (which it always walks itself)
 // where the candidate sets of the four 16x16 CUs and of the 32x32 CU cost about 1 unit each (cycle counters of round 2 and 3,
-// DESIGN.md §4).  With h helpers per main workgroup the shares x (16x16) and y (32x32) that are handed over should make both
-// sides finish together: 1.5 + (1 - x) + (1 - y) = (x + y) / h.  32x32 requests go first (their answers are needed last).
+// DESIGN.md §4; 1.5 until TU 0 of the four-TU shape was shared — ten interleaved launch pairs of the bench shape at the end of
+// round 3, profiles/r03y5_split_ab.log: median 5.27 s with 56 % of the 16x16 CUs offered against 5.32 s with 63 %).  With h
+// helpers per main workgroup the shares x (16x16) and y (32x32) that are handed over should make both
+// sides finish together: 1.35 + (1 - x) + (1 - y) = (x + y) / h.  32x32 requests go first (their answers are needed last).
 // Returns the share of kind 0 (16x16) / 1 (32x32) per mille.
 static int pool_split(int nmains, int nhelp, int kind) {
     if (nmains < 1 || nhelp < 1) return 0;
-    const double h = (double)nhelp / nmains, total = 3.5 * h / (1.0 + h);     // x + y
+    const double h = (double)nhelp / nmains, total = 3.35 * h / (1.0 + h);    // x + y
     double y = total < 1.0 ? total : 1.0, x = total - y;
     if (x > 1.0) x = 1.0;
     const int v = (int)((kind == 0 ? x : y) * 1000.0 + 0.5);
