@@ -226,6 +226,18 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
     *nmains = m; *nhelp = h;
     return 2;
 }
+// Pipe wave (256-thread workgroups, three per CU instead of four), as a pure function of the shape imcvt_hevc_plan chose: launches
+// that leave a quarter of the workgroup slots free are latency-bound (every frame waits for the serial chain of its 8x8 CUs), so
+// their workgroups get the fourth wavefront that takes the NxN trial off that chain; fuller launches keep four 192-thread
+// workgroups per CU.  The same sixteenth of the slots stays free as in imcvt_hevc_plan; a pool that just misses the limit gives up
+// helpers for it as long as 1.5 per main workgroup remain (*nhelp is reduced); a forced shape may fill the last slot.
+// mode: what imcvt_hevc_plan returned.  Returns 1 if the launch runs with the pipe wave.
+extern "C" int imcvt_hevc_plan_pipe(int mode, int max_wg, int forced_shape, int *nmains, int *nhelp) {
+    if (!nmains || !nhelp || max_wg < 4) return 0;
+    const int pipe_wg = max_wg / 4 * 3, pipe_cap = pipe_wg - pipe_wg / 16;
+    if (mode > 1 && !forced_shape && *nmains + *nhelp > pipe_cap && *nmains + (3 * *nmains + 1) / 2 <= pipe_cap) *nhelp = pipe_cap - *nmains;
+    return *nmains + *nhelp <= (forced_shape ? pipe_wg : pipe_cap) ? 1 : 0;
+}
 static int pick_shape(const imcvt_hevc_ctx *c, int n, int *nmains, int *nhelp) {
     if (c->force_mains > 0 && c->force_help > 0 && c->force_mains + c->force_help <= c->max_wg) {
         *nmains = c->force_mains < n ? c->force_mains : n; *nhelp = c->force_help;
@@ -271,10 +283,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemsetAsync(c->d_counter + 6, 0, 2 * sizeof(int), stream));
     int nmains = 0, nhelp = 0;
     const int mode = pick_shape(c, n, &nmains, &nhelp);
-    // Pipe wave (256-thread workgroups, three per CU): used when the launch fits, with the same sixteenth of the slots left free
-    // as in imcvt_hevc_plan.  A pool that just misses the limit gives up helpers for it as long as 1.5 per main workgroup remain.
-    const int pipe_cap = c->pipe_wg - c->pipe_wg / 16;
-    if (c->pipe != 0 && mode > 1 && c->force_mains <= 0 && nmains + nhelp > pipe_cap && nmains + (3 * nmains + 1) / 2 <= pipe_cap) nhelp = pipe_cap - nmains;
+    const int use_pipe = c->pipe != 0 ? imcvt_hevc_plan_pipe(mode, c->max_wg, c->force_mains > 0, &nmains, &nhelp) : 0;
     const int grid = nmains + nhelp;
     if (mode > 1) {
         HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nmains, stream));     // sequence numbers restart with every launch
@@ -282,10 +291,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     if (grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) { fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
     c->last_mains = nmains; c->last_help = nhelp;
-    // Launches that leave a quarter of the workgroup slots free are latency-bound (every frame waits for the serial chain of
-    // its 8x8 CUs): their workgroups get the pipe wave, which takes the NxN trial off that chain.  Fuller launches keep four
-    // 192-thread workgroups per CU.
-    c->last_pipe = (c->pipe != 0 && grid <= (c->force_mains > 0 ? c->pipe_wg : pipe_cap)) ? 1 : 0;      // (a forced shape may fill the last slot)
+    c->last_pipe = use_pipe;
     HIPCHK(hipEventRecord(c->ev0, stream));
     launch(c, grid, stream, n, mode, nmains, nhelp, c->last_pipe);
     HIPCHK(hipGetLastError());

@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan")
+           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -78,6 +78,8 @@ def load_library():
     lib.imcvt_hevc_version.argtypes = []
     lib.imcvt_hevc_set_team.restype = None
     lib.imcvt_hevc_set_team.argtypes = [C.c_void_p, C.c_int]
+    lib.imcvt_hevc_plan_pipe.restype = C.c_int
+    lib.imcvt_hevc_plan_pipe.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.imcvt_hevc_set_pipe.restype = None
     lib.imcvt_hevc_set_pipe.argtypes = [C.c_void_p, C.c_int]
     lib.imcvt_hevc_last_pipe.restype = C.c_int

@@ -108,6 +108,11 @@ void imcvt_hevc_set_team(imcvt_hevc_ctx *ctx, int team_size);
 void imcvt_hevc_set_pipe(imcvt_hevc_ctx *ctx, int mode);
 /* 1 if the last launch ran with the pipe wave, else 0. */
 int imcvt_hevc_last_pipe(imcvt_hevc_ctx *ctx);
+/* That choice as a pure function (no device needed), applied to the shape imcvt_hevc_plan returned (mode = its return value; *nmains,
+ * *nhelp = its outputs): returns 1 if the launch runs 256-thread workgroups with the pipe wave — it does when it fits 15/16 of three
+ * workgroups per compute unit (max_workgroups * 3 / 4), and a pool that misses that by little gives up helpers for it (*nhelp is
+ * reduced, never below 1.5 per main workgroup).  forced_shape: the shape was set by imcvt_hevc_set_shape (it may fill the last slot). */
+int imcvt_hevc_plan_pipe(int mode, int max_workgroups, int forced_shape, int *nmains, int *nhelp);
 /* The choice itself, as a pure function (no device needed): launch shape for n_frames on a device that holds
  * max_workgroups resident workgroups of the encoder kernel (1024 on MI355X).  Returns 1 (a frame per workgroup,
  * *nmains workgroups, *nhelp = 0) or 2 (*nmains main workgroups + a pool of *nhelp helper workgroups). */

@@ -136,3 +136,23 @@ def test_launch_shape_policy(built):
     assert plan(2000, force=3) == (2, 341, 682) and plan(2000, force=2) == (2, 512, 512)
     assert plan(10, wg=16) == (2, 8, 7) and plan(11, wg=16) == (1, 11, 0) and plan(5, wg=16) == (2, 5, 10)
     assert plan(0) == (1, 0, 0)
+
+    # pipe wave (256-thread workgroups, three per CU): pure too — used when the planned launch fits 15/16 of 768 slots; a pool that just
+    # misses that gives up helpers for it, down to 1.5 per main workgroup
+    def pipe(n, wg=1024, forced=0):
+        mode, m, h = plan(n, wg)
+        mm, hh = C.c_int(m), C.c_int(h)
+        return lib.imcvt_hevc_plan_pipe(mode, wg, forced, C.byref(mm), C.byref(hh)), mm.value, hh.value
+
+    assert pipe(1) == (1, 1, 2) and pipe(64) == (1, 64, 128) and pipe(240) == (1, 240, 480)
+    assert pipe(256) == (1, 256, 464) and pipe(288) == (1, 288, 432)        # helpers cut to 720 - n
+    assert pipe(289) == (0, 289, 578) and pipe(512) == (0, 512, 448)        # (less than 1.5 helpers per main would be left: no pipe wave)
+    assert pipe(700) == (1, 700, 0) and pipe(720) == (1, 720, 0) and pipe(721) == (0, 721, 0)      # a frame per workgroup
+    assert pipe(5, wg=16) == (0, 5, 10) and pipe(3, wg=16) == (1, 3, 6)     # 12 slots of 256 threads, 11 usable... 9 workgroups fit
+    for n in range(1, 1400, 5):
+        mode, m, h = plan(n)
+        use, mm, hh = pipe(n)
+        assert mm == m and hh <= h and (hh == h or (use and mm + hh == 720 and 2 * hh >= 3 * mm))
+        assert use == (mm + hh <= 720)
+    m, h = C.c_int(512), C.c_int(256)
+    assert lib.imcvt_hevc_plan_pipe(2, 1024, 1, C.byref(m), C.byref(h)) == 1 and (m.value, h.value) == (512, 256)      # a forced shape may fill the last slot
