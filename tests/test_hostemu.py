@@ -250,7 +250,7 @@ def test_pool_mode_natural_image(hostemu):
 def test_sizes_beyond_8192_are_cropped_like_the_reference(hostemu):
     # :1580-1581 pads min(dim, 8192) while the source keeps its own stride (:1621): one CTU row / column of 257 CTUs' worth
     from oracle import oracle, synth
-    for h, w in ((3, 8200), (8200, 3)):
+    for h, w in ((3, 8200),):          # (the 8200 x 3 column runs on the GPU, tests/test_gpu_parity.py: in the emulation each orientation takes most of a minute)
         img = synth.noise(w, h, 5)
         stream, rcon = emu_encode(hostemu, img, 3) if max(h, w) <= 8192 else _emu_big(hostemu, img, 3)
         ws, wr, dims = oracle.cpu_encode(img, 3)
