@@ -22,7 +22,8 @@ compared with the CPU checker on a sample, or the line says "unverified".
 roofline: the HBM view the metric asks for — algorithmic bytes (W*H read + Wp*Hp reconstruction written + stream bytes
 written) per launch / HIP-event duration of the kernel on its launch stream.
 roofline_issue: the bound that binds (VALU issue).  cpu_baseline: the CPU checker on a bounded sample (N=1 only).
-latency_view: one 1080p frame and one 4K frame alone on the GPU (BASELINE configs 1 and 2), kernel ms (N=1 only).
+latency_view: one 1080p frame and one 4K frame alone on the GPU (BASELINE configs 1 and 2), kernel ms; the reference's P4 sample picture
+through writeHEVCImageFile (configs[0]), wall ms (N=1 only).  qpd6_4_view: the timed batch once more at qpd6 = 4 (N=1 only).
 host_abi_view: the reference-shaped host-pointer entry point over ALL the bench frames, PCIe copies included (N=1 only).
 solo_1000f: secondary throughput with the device full (1000 frames, a frame per workgroup), same kernel (N=1 only).
 jls_view: BASELINE config 5 (1920x1080 gray8 -> .jls, NEAR=0): one plane and 64 planes, kernel ms, reference digest (N=1 only).
@@ -48,30 +49,37 @@ def _gen(seed):
     return synth.syn(W, H, seed)
 
 
-def _cpu_strip(args):
-    """CPU baseline unit: one 1920x256 strip of syn() — same content class and CTU work as the bench frames."""
-    seed, q = args
+def _cpu_unit(args):
+    """CPU baseline unit: one syn(1920, rows, seed) picture through the CPU checker; returns its own seconds."""
+    seed, q, rows = args
     from imcvt_amd import synth
     from oracle import oracle              # cpu_baseline leg: the CPU checker is what is timed here
-    img = synth.syn(W, 256, seed)
+    img = synth.syn(W, rows, seed)
     t = time.perf_counter()
     oracle.cpu_encode(img, q)
     return time.perf_counter() - t
 
 
 def cpu_baseline(qpd6):
+    """The reference on this box's host cores, one process per core (`cores` whole frames of the bench workload).
+    A 1080p frame takes a core ~75 s, so `value` comes from cores x ONE whole syn(1920,1080,seed) frame; the round-1..3 sample
+    (cores x a 1920x256 strip, ~18 s) is kept beside it as `strips` — same content class, a quarter of a frame's context adaptation."""
     from multiprocessing import Pool
     from oracle import oracle
     cores = max(1, min(os.cpu_count() or 1, 32))
-    t0 = time.perf_counter()
-    pool = Pool(cores)
-    pool.map(_cpu_strip, [(s, qpd6) for s in range(cores)], chunksize=1)
-    wall = time.perf_counter() - t0
-    pool.close(); pool.join()       # let workers exit normally (a terminate() under rocprofv3 hangs in its signal handler)
-    px = cores * W * 256
-    return {"value": round(px / wall / 1e6, 4), "unit": "Mpixels/s", "cores": cores,
+    out = {}
+    for name, rows in (("strips", 256), ("frames", H)):
+        t0 = time.perf_counter()
+        pool = Pool(cores)
+        each = pool.map(_cpu_unit, [(s, qpd6, rows) for s in range(cores)], chunksize=1)
+        wall = time.perf_counter() - t0
+        pool.close(); pool.join()       # let workers exit normally (a terminate() under rocprofv3 hangs in its signal handler)
+        out[name] = {"mpx_s": round(cores * W * rows / wall / 1e6, 4), "wall_s": round(wall, 1), "per_core_mpx_s": round(W * rows / (sum(each) / len(each)) / 1e6, 4)}
+    return {"value": out["frames"]["mpx_s"], "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if oracle.have_ref() else "port",
-            "sample": f"{cores} x syn(1920,256,seed) strips (8 CTU rows each), one process per core, qpd6={qpd6}, {wall:.1f} s wall"}
+            "sample": f"{cores} whole syn(1920,1080,seed) frames (seeds 0..{cores - 1}), one process per core, qpd6={qpd6}, {out['frames']['wall_s']} s wall",
+            "per_core_mpx_s": out["frames"]["per_core_mpx_s"],
+            "strips": dict(out["strips"], sample=f"{cores} x syn(1920,256,seed) strips (8 CTU rows each), the sample of rounds 1-3")}
 
 
 def _free_port():
@@ -262,12 +270,15 @@ def main():
         if os.path.exists(ip):
             iv = json.load(open(ip))
             insts = iv["valu_wave_insts_per_ctu"] * ctus
-            peak = 256 * 4 * 2.4e9 / 2                                     # wave-instructions/s: 256 CUs x 4 SIMD-32, 2 cycles per wave64 VALU instruction
+            peak = 256 * 4 * 2.4e9 / 2                                     # wave-instructions/s: 256 CUs x 4 SIMDs, 2 cycles per wave64 VALU instruction (the packed-math rate)
+            peak4 = peak / 2                                               # plain 32-bit integer / select / shift instructions — all of this kernel — take 4 cycles per wave64
             line["roofline_issue"] = {"bound": "valu issue", "achieved": round(insts / k_avg / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-inst/s",
-                                      "frac": round(insts / k_avg / peak, 4), "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"],
-                                      "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": "instruction count per CTU from " + iv["source"] + "; time from this run"}
+                                      "frac": round(insts / k_avg / peak, 4), "peak_unpacked": round(peak4 / 1e9, 1), "frac_of_unpacked_peak": round(insts / k_avg / peak4, 4),
+                                      "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"], "lane_activity": iv.get("valu_lane_activity"),
+                                      "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": "instruction count per CTU and lane activity from " + iv["source"] + "; time from this run"}
         if world == 1 and not args.no_latency_view:
             line["latency_view"] = latency_view(enc, dev, args.qpd6)
+            line["qpd6_4_view"] = qpd6_view(enc, big, 4) if args.qpd6 != 4 else None
             line["solo_1000f"] = solo_view(enc, big, last, args.qpd6)
             line["host_abi_view"] = host_abi_view(big, last, args.qpd6)
             line["jls_view"] = jls_view(dev)
@@ -299,6 +310,27 @@ def solo_view(enc, big, digests, qpd6, n=1000):
         raise SystemExit("solo_1000f: streams differ from the timed batch's")
     return {"frames": n, "kernel_ms": round(ms, 1), "mpx_s": round(n * W * H / ms / 1e3, 3), "shape": list(enc.last_shape()),
             "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
+
+
+def qpd6_view(enc, big, q):
+    """The bench batch at the other end of the quantiser range (SURVEY section 8d asks for qpd6 = 0 and 4): same frames, same launch shape,
+    one warm launch and one timed; frame 0 against the reference's digest (tests/golden/hevc_kat.json holds syn(1920,1080,0) at qpd6 4)."""
+    import torch
+    F = big.shape[0]
+    if F < 1:
+        return None
+    b = enc.make_batch([big[i] for i in range(F)], q)
+    enc.encode(b); torch.cuda.synchronize()
+    enc.encode(b); torch.cuda.synchronize()
+    ms = enc.last_kernel_ms()
+    lens = b["lens"].cpu().tolist()
+    e = next((e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json")))
+              if e["input"] == {"kind": "syn", "w": W, "h": H, "arg": 0} and e["qpd6"] == q), None)
+    okd = (e["bytes"] == lens[0] and hashlib.sha256(b["outs"][0][:lens[0]].cpu().numpy().tobytes()).hexdigest() == e["sha256"]) if e else None
+    if okd is False:
+        raise SystemExit(f"qpd6_{q}_view: frame 0 differs from the reference digest")
+    return {"qpd6": q, "frames": F, "kernel_ms": round(ms, 1), "mpx_s": round(F * W * H / ms / 1e3, 3), "shape": list(enc.last_shape()),
+            "stream_bytes_per_frame": int(sum(lens) / F), "frame0_sha256_equal_to_reference": okd}
 
 
 def jls_view(dev):
@@ -368,6 +400,27 @@ def latency_view(enc, dev, qpd6):
             raise SystemExit(f"latency_view {name}: stream differs from the reference digest")
         out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(w * h / ms / 1e3, 3), "bytes": n, "sha256_equal_to_reference": okd,
                      "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe()}
+    # BASELINE configs[0]: the reference's own sample picture (image/P4.pnm, 300 x 263; its pixels are tests/golden/p4_gray.pgm) through the
+    # reference-shaped FILE entry point, writeHEVCImageFile (src/imageio_hevc.c:9): host buffers, PCIe, the launch and the file write included
+    import tempfile
+    import numpy as np
+    import imcvt_amd
+    data = open(os.path.join(ROOT, "tests", "golden", "p4_gray.pgm"), "rb").read().split(b"\n", 3)
+    pw, ph = map(int, data[1].split())
+    px = np.frombuffer(data[3], dtype=np.uint8, count=pw * ph).reshape(ph, pw)
+    want = open(os.path.join(ROOT, "tests", "golden", "p4_q0.h265"), "rb").read()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "p4.h265")
+        imcvt_amd.writeHEVCImageFile(path, px, False, ph, pw, 0)             # (first call: per-device context and slab)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); rc = imcvt_amd.writeHEVCImageFile(path, px, False, ph, pw, 0); ts.append(time.perf_counter() - t0)
+        got = open(path, "rb").read()
+    if rc != 0 or got != want:
+        raise SystemExit("latency_view p4: writeHEVCImageFile output differs from the reference's stream")
+    out["p4"] = {"what": "BASELINE configs[0]: the reference's 300x263 sample picture -> .h265 through writeHEVCImageFile (host buffers, file write), qpd6 0",
+                 "wall_ms": round(min(ts) * 1e3, 2), "mpx_s": round(pw * ph / min(ts) / 1e6, 3), "bytes": len(got), "bytes_equal_to_reference": True}
+    imcvt_amd.load_library().imcvt_hevc_shutdown()
     return out
 
 

@@ -58,6 +58,7 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_ld_i32(const i32 *p) { return *(const volatile i32 *)p; }
   HD void lds_st_i32(i32 *p, i32 v) { *(volatile i32 *)p = v; }
   HD void pipe_pause() { emu_yield(); }
+  HD void pipe_pause_long() { emu_yield(); }
   static int emu_pipe_on();
   HD int wg_has_pipe_wave() { return emu_pipe_on(); }
   HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
@@ -110,6 +111,9 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_ld_i32(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   HD void lds_st_i32(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   HD void pipe_pause() { __builtin_amdgcn_s_sleep(2); }
+  // the same wait in a launch that fills the device: the waiting wave shares its SIMD with waves that have work, and a poll every
+  // ~130 cycles costs them issue slots (the four-TU wave of an 8x8 CU waits ~16 k instruction-times for the PU wave: thousands of polls)
+  HD void pipe_pause_long() { __builtin_amdgcn_s_sleep(48); }
   HD int wg_has_pipe_wave() { return blockDim.x > (unsigned)WG_THREADS; }
 #endif
 
@@ -216,15 +220,19 @@ struct Tables {
     uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8        (:700-712)
     u32 posadd[4][3];      // sig_coeff ctx increment per in-group scan position, 2 bits each [pattern][type]  (:1115-1120)
     u64 c4tab[3];          // 4x4-TU sig_coeff ctx per scan position, 4 bits each [type]                  (:1092)
-    u32 ldelta[8];         // steps of the level rate model below level 8: (rate(l)-rate(l-1))/16 | (rate(l)-rate(l-2))/16 << 16  (:526-535)
+    u32 c4prev[3][4];      // [type]: per scan position n of a 4x4 TU (a byte each) the scan positions above n that share its sig_coeff context: nearest | next << 4 (0: none)
     u8  ang[36];           // intraPredAngle + 32                                                         (:282)
     u16 iang[36];          // |invAngle|                                                                  (:283)
 };
 // tables that stay in global memory (read once per frame)
 #define RQ_CLASSES 10
+#define PU_SIG_N 72
+#define PU_GT_N 136
 struct ColdTables {
     u8 ctx_init[5][CTX_STRIDE];            // initial context states per qpd6 (:726-784)
     i32 rthr[5][4][RQ_CLASSES];            // RDOQ decision thresholds per qpd6 and TU size (rdoq_group below); a frame stages its qpd6's 40 words into LDS
+    u8 pu_sig[5][PU_SIG_N];                // state hints of the 4x4 PU candidates (tokg_a_fast<0, true>), per qpd6: sig_coeff context f after no / one / two earlier bins: [8 f + idx]
+    u8 pu_gt[5][PU_GT_N];                  // greater-1 contexts: [j] the j-th flag while no level above 1 was seen; [8 + (1 << n) - 1 + pattern] context 0 after n earlier bins
 };
 HD int mat_off(int s) { return s == 0 ? 0 : s == 1 ? 16 : s == 2 ? 80 : 336; }
 
@@ -268,7 +276,8 @@ HD Arith unpack_arith(const FinState &f) {
 struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
 #define LSTRIDE_DW 33       // dwords per lane row of the lane-private token staging (LSTRIDE below)
 #define P1_RES_BYTES 2304   // 16 tiles of 8x8 + 4 or 4 tiles of 16x16 + 16 i16 (padded against LDS bank conflicts), 16-byte multiple
-#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
+#define NCODER (NMODE + 1)   // trial coders of a wave: the 35 candidates of its set and, on the four-TU wave of an 8x8 CU, the NxN trial as a 36th stream (hevc_frame.h eval_2Nx2N)
+#define W2_PAD (((NCODER * CTX_STRIDE + 15) & ~15) + ((NCODER * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
 struct alignas(16) WaveMem {
     Border  bsh;                 // border shared by all modes of a block
     i32 tokn[NMODE + 1];         // tokens written so far to each candidate's stream (slot NMODE: the NxN stream)
@@ -282,7 +291,7 @@ struct alignas(16) WaveMem {
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
         struct { i16 res[P1_RES_BYTES / 2]; i32 tmp[(7168 - P1_RES_BYTES) / 4]; } p1;                    // one pipeline pass: residual / dequantised tiles, stage outputs (tile strides: p1_run_t)
         u32 raw[1792];                                                                                // per-lane token staging (4x4 blocks, CU headers): lane l at raw + 33 l
-        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
+        struct { u8 cx[NCODER][CTX_STRIDE]; alignas(16) LaneMem lm[NCODER]; } p2;                        // trial coders: context copies, byte rings + lead queues
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
     } u;
 };
@@ -352,9 +361,10 @@ struct alignas(256) MailSlot {
 };
 struct TeamMail { MailSlot s[MAIL_SLOTS]; };
 // Request queues of a launch: the helper workgroups form ONE pool that serves the requests of every main workgroup.  A queue
-// is a ticket ring per request kind: a main workgroup takes ticket t = tail++ and publishes its index in ring[t]; a helper
-// claims ticket h = head++ (compare-and-swap while head < tail), waits for ring[h] and clears it.  A main workgroup has at most
-// one request of a kind outstanding, so a ring of POOL_QCAP entries never wraps onto a live entry.  The queue is cut into
+// is a ticket ring per request kind: a main workgroup takes ticket t = tail++ and publishes (t, its index) in ring[t]; a helper
+// claims ticket h = head++ (compare-and-swap while head < tail) and waits for ring[h] to name ticket h.  A main workgroup has at
+// most one request of a kind outstanding, so a ring of POOL_QCAP entries only wraps onto an entry whose claimer has been held up
+// for a whole lap — that claimer sees the later ticket in its slot and goes back to polling (hevc_frame.h ring_entry).  The queue is cut into
 // POOL_SHARDS shards on their own cache lines (main workgroup i posts to shard i mod POOL_SHARDS; a helper looks at its home
 // shard first and then at one other shard per poll), so that hundreds of polling workgroups do not meet on one line.
 #define POOL_SHARDS 16
@@ -375,7 +385,7 @@ struct TeamMail { MailSlot s[MAIL_SLOTS]; };
 struct alignas(256) PoolShard {
     u32 head[MAIL_SLOTS], tail[MAIL_SLOTS];      // tickets claimed / issued, per request kind
     u32 pad_[60];
-    u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> main workgroup index + 1 (0: not published yet)
+    u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> (ticket mod 2^20) << 12 | main workgroup index + 1 (0: nothing published yet)
 };
 struct alignas(256) PoolQ {
     u32 frames_done;                             // frames finished: helpers leave when all are (no request can follow)
@@ -435,12 +445,14 @@ struct alignas(16) Shm {
     i32 pipe_a, pipe_b;          // PU wave -> pipe wave: the winners of PUs 0..2 / of PU 3 are in place (cleared by the pipe wave)
     i32 nxn_lane;                // pipe wave: the lane that holds the NxN trial's result (= PU 3's mode)
     i32 pu0_ready, pu0_taken;    // 8x8 CU: the PU wave's pass over PU 0 is complete / the four-TU wave has taken its copy (hevc_frame.h tu0_from_pu0)
+    i32 nxn_ready, nxn_n;        // 8x8 CU without a pipe wave: the PU wave has assembled the NxN stream (nxn_n tokens) — the four-TU wave codes it beside its 35 candidates
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
 #endif
     FourTU X;
     alignas(4) u8 cx0[CTX_STRIDE];       // fresh context states of this frame's qpd6 (:1505)
     i32 rthr[4][RQ_CLASSES];             // RDOQ thresholds of this frame's qpd6
+    alignas(4) u8 pu_sig[PU_SIG_N]; alignas(4) u8 pu_gt[PU_GT_N];      // state hints of this frame's qpd6 (ColdTables)
     alignas(16) u8 wraw[NWAVES * sizeof(WaveMem)];   // wave slices (wave 2 runs full pipeline passes for the 16x16 / 32x32 CUs too)
 };
 
@@ -457,8 +469,10 @@ __shared__ Shm g_shm;
 #endif
 #define WM(w) (*(WaveMem *)(SM.wraw + (w) * sizeof(WaveMem)))
 // The pipe wave's slice (a WaveMem cut off after the trial coders' extent) is dynamic LDS: only 256-thread launches pay for it.
-#define PIPE_LDS_BYTES ((sizeof(WaveMem) - 7168 + 5120 + 15) & ~(size_t)15)
-static_assert(NMODE * LSTRIDE_DW * 4 <= 5120 && W2_PAD <= 5120, "the pipe wave's slice holds 35 token rows / 35 trial coders");
+#define PIPE_UNION_BYTES 5248
+#define PIPE_LDS_BYTES ((sizeof(WaveMem) - 7168 + PIPE_UNION_BYTES + 15) & ~(size_t)15)
+static_assert(NMODE * LSTRIDE_DW * 4 <= PIPE_UNION_BYTES && W2_PAD <= PIPE_UNION_BYTES, "the pipe wave's slice holds 35 token rows / the trial coders");
+static_assert(W2_PAD + NMODE * 16 <= 7168, "the PU candidates' reconstructions lie beside the trial coders in the pass buffer");
 #ifdef IMCVT_HOSTEMU
 static u8 *g_pipe_host;
 #define PM (*(WaveMem *)g_pipe_host)
@@ -880,6 +894,7 @@ struct P1Args {
     int q;
     int own;             // wave whose candidate set this is (its tokn / tnz / sse arrays and token streams); the executing wave lends lanes and its pass buffer
     int c_lo, c_hi;      // candidates (modes) handled by this call
+    int hint;            // 4x4 PU candidates (shape 3): the tokens carry state hints (tokg_a_fast<0, true>) — they are priced by code_token_r
 };
 
 // sign-extended byte kk of a packed word / i16 halves of a packed word
@@ -1061,8 +1076,12 @@ HD void fill_border_ref(BorderRef &br, const WaveMem &W, int per_mode, int c) {
 // ---------------------------------------------------------------------------------------------------
 // Bin tokens.  The syntax of a candidate (:1172-1339) is flattened, by the lanes that own its coefficient
 // groups, into a stream of 16-bit tokens in coding order:
-//     context-coded bin :  (context index << 1) | bin                       (< 182)
+//     context-coded bin :  context index << 8 | hint << 1 | bin             (< 0x5B00)
 //     bypass chunk      :  0x8000 | nbins << 8 | value   (1..8 bins, the reference's own chunking :898-910)
+// `hint` (7 bits) is the packed state the context is in when the bin is coded — filled in only where the generator can know it
+// (the PU candidates of an 8x8 CU, priced from fresh contexts: tokg_a_fast<0, true>; the NxN trial's pre-resolved segments), zero
+// elsewhere.  A coder that keeps context copies (code_token_q) ignores it; one that runs on resolved tokens (code_token_r) needs
+// nothing else.
 // Tokens do not depend on the coder or context STATE, so they are produced in parallel (one lane per 4x4
 // group) while the arithmetic coding itself — the only truly serial part — becomes a tight loop over a
 // linear stream (stream_run below), one lane per candidate.
@@ -1081,7 +1100,8 @@ HD void to_put_if(const TokOut &o, int k, int tok, int pred) {
 }
 struct TokW { TokOut o; int n; int wr; };       // wr == 0: count only
 HD void tk_put(TokW &w, int t) { if (w.wr) to_put(w.o, w.n, t); w.n++; }
-HD void tk_bin(TokW &w, int ci, int bin) { tk_put(w, (ci << 1) | bin); }
+#define TK(ci, bin) (((ci) << 8) | (bin))
+HD void tk_bin(TokW &w, int ci, int bin) { tk_put(w, TK(ci, bin)); }
 HD void tk_chunk(TokW &w, int v, int n) { tk_put(w, 0x8000 | (n << 8) | v); }
 HD void tk_bypass(TokW &w, int v, int len) {                                                // :898-910
     v &= (1 << len) - 1;
@@ -1151,16 +1171,19 @@ HD LastPos last_pos_prep(int s, int st, int y, int x) {
 }
 HD int last_pos_count(const LastPos &p) { return p.gx + (p.gx < p.gmax) + p.gy + (p.gy < p.gmax) + (p.nsuf > 0); }
 // emits tokens cnt.. ; S = log2(TU size) - 2 fixes the loop length.  PRIV as for tokg_a below.
-template <int S, bool PRIV>
+template <int S, bool PRIV, bool HINT = false>      // HINT: fresh contexts, each used once per TU (4x4: one context per prefix bin) — the state hint is the initial state
 HD int last_pos_emit(const TokOut &o, int cnt, const LastPos &p) {
     constexpr int gmax = 2 * (S + 2) - 1, shf = (S == 0) ? 0 : 1;
+    static_assert(!HINT || S == 0, "state hints exist for the 4x4 PU candidates only");
     for (int i = 0; i < gmax; i++) {
-        const int pr = i <= p.gx, tok = ((CX_LAST_X + p.cbase + (i >> shf)) << 1) | (i < p.gx);
+        const int ci = CX_LAST_X + p.cbase + (i >> shf);
+        const int pr = i <= p.gx, tok = TK(ci, i < p.gx) | (HINT ? SM.cx0[ci] << 1 : 0);
         if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr);
         cnt += pr;
     }
     for (int i = 0; i < gmax; i++) {
-        const int pr = i <= p.gy, tok = ((CX_LAST_Y + p.cbase + (i >> shf)) << 1) | (i < p.gy);
+        const int ci = CX_LAST_Y + p.cbase + (i >> shf);
+        const int pr = i <= p.gy, tok = TK(ci, i < p.gy) | (HINT ? SM.cx0[ci] << 1 : 0);
         if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr);
         cnt += pr;
     }
@@ -1228,7 +1251,7 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
     const Tables &T = SM.T;
     const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3, s = (cfg >> TG_S) & 3;
     B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
-    TK_EMIT(!dcg && !has_last, ((CX_CSBF + (pat != 0)) << 1) | (nzm != 0));
+    TK_EMIT(!dcg && !has_last, TK(CX_CSBF + (pat != 0), nzm != 0));
     if (nzm == 0 && !dcg) return cnt;
     {   // significance flags, scan positions nstart..0.  Context of position n: base + field n of a packed table (2-bit fields; 4-bit for 4x4 TUs)
         const int nstart = has_last ? hibit(nzm) : 15;
@@ -1240,7 +1263,7 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
             const int code = (n <= nstart) & !(has_last & (n == nstart)) & (dcg | (n != 0) | ((nzm >> (n + 1)) != 0));
             const int f4 = (int)(((n < 8 ? tlo : thi) >> (4 * (n & 7))) & 15), f2 = (int)((tlo >> (2 * n)) & 3);
             const int ci = (dcg && n == 0) ? 0 : base + (s == 0 ? f4 : f2);
-            TK_EMIT(code, ((CX_SIG + ci) << 1) | (int)((nzm >> n) & 1));
+            TK_EMIT(code, TK(CX_SIG + ci, (int)((nzm >> n) & 1)));
         }
     }
     if (nzm == 0) return cnt;
@@ -1252,14 +1275,14 @@ HD int tokg_a(const TokOut &o, int cnt, const Lv16 &L, u32 nzm, int cfg, TgB &B)
         const int v = L.v[n], mg = iabs(v), isnz = v != 0;
         signs = isnz ? ((signs << 1) | (v < 0)) : signs;
         const int act = isnz & (seen < 8), big = mg > 1;
-        TK_EMIT(act, ((CX_GT1 + 4 * set + c1) << 1) | big);
+        TK_EMIT(act, TK(CX_GT1 + 4 * set + c1, big));
         const int ab = act & big, an = act & !big;
         esc |= ab & (g2 >= 0);
         g2 = (ab & (g2 < 0)) ? (mg > 2) : g2;
         c1 = ab ? 0 : ((an & (c1 > 0) & (c1 < 3)) ? c1 + 1 : c1);
         seen += isnz;
     }
-    TK_EMIT(g2 >= 0, ((CX_GT2 + set) << 1) | (g2 > 0));
+    TK_EMIT(g2 >= 0, TK(CX_GT2 + set, g2 > 0));
     esc |= (g2 > 0);
     {   // sign bins open the group's bypass run: full chunks leave at once, the rest waits for the remaining-level bins
         int nb = nnz;
@@ -1283,12 +1306,21 @@ HD u32 mc_of(const Lv16 &L) { u32 P = 0; for (int n = 0; n < 16; n++) P |= (u32)
 // running predicate: the significance flags of scan positions top..0 are consecutive, the greater-1 flags belong to the first
 // min(nnz, 8) set bits of the non-zero mask, walked with clz; contexts of the latter are min(1 + j, 3) until a level above 1
 // was seen and 0 afterwards (:1218-1227).  P = the group's magnitude codes (scan_levels).
-template <int S>
+// HINT (4x4 PU candidates, priced from fresh contexts: S == 0, one DC group that holds the last position): every context-coded token
+// also carries the state its context is in when the bin is coded.  From fresh contexts that state is a function of the bins coded
+// earlier in THIS group on the same context, read from per-frame tables (Shm::pu_sig, pu_gt; built on the host, hevc_tables.h):
+//   significance flags: a context serves at most three scan positions of a 4x4 TU (:1092) — the (at most two) coded positions above
+//                       n that share its context are listed in T.c4prev, their flags index the table;
+//   greater-1 flags   : contexts 1, 2, 3, 3, ... until a level above 1 was seen (every earlier bin on context 3 was a 0), context 0
+//                       afterwards (any earlier bins: indexed by their count and pattern);
+//   greater-2 flag    : first use.
+template <int S, bool HINT = false>
 HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB &B) {
+    static_assert(!HINT || S == 0, "state hints exist for the 4x4 PU candidates only");
     const Tables &T = SM.T;
     const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3;
     B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
-    tb[cnt] = (u16)(((CX_CSBF + (pat != 0)) << 1) | (nzm != 0));
+    tb[cnt] = (u16)TK(CX_CSBF + (pat != 0), nzm != 0);
     cnt += (!dcg && !has_last);
     if (nzm == 0 && !dcg) return cnt;
     {   // significance flags of scan positions top..0 (the last significant position itself is not coded; position 0 is inferred
@@ -1297,14 +1329,23 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
         u32 tlo, thi = 0; int base;
         if (S == 0) { const u64 t = T.c4tab[st]; tlo = (u32)t; thi = (u32)(t >> 32); base = 0; }
         else { tlo = T.posadd[pat][st]; base = 9 + (S >= 2 ? 12 : 0) + ((S == 1 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); }
+        u32 pv[4] = { 0, 0, 0, 0 };
+        if (HINT) for (int i = 0; i < 4; i++) pv[i] = T.c4prev[st][i];
         u16 *const lo = tb + cnt, *const hi = lo + top;
         UNROLL_FULL
         for (int n = 15; n >= 0; n--) {
             const int f = S == 0 ? (int)(((n < 8 ? tlo : thi) >> (4 * (n & 7))) & 15) : (int)((tlo >> (2 * n)) & 3);
             const int ci = (n == 0 && dcg) ? 0 : base + f;
+            int hint = 0;
+            if (HINT) {
+                const int pp = (int)((pv[n >> 2] >> (8 * (n & 3))) & 255), p1 = pp & 15, p2 = pp >> 4;      // coded earlier on the same context: p1 (nearest), p2 > p1; 0: none
+                const int k1 = (p1 != 0) & (p1 <= top), k2 = (p2 != 0) & (p2 <= top);
+                const int b1 = (int)((nzm >> p1) & 1), b2 = (int)((nzm >> p2) & 1);
+                hint = SM.pu_sig[8 * f + (k2 ? 3 + 2 * b2 + b1 : k1 ? 1 + b1 : 0)];
+            }
             u16 *p = hi - n;
             p = p < lo ? lo : p;
-            *p = (u16)(((CX_SIG + ci) << 1) | (int)((nzm >> n) & 1));
+            *p = (u16)(TK(CX_SIG + ci, (int)((nzm >> n) & 1)) | hint << 1);
         }
         cnt += top + 1 - ((top >= 0) & !(dcg | ((nzm >> 1) != 0)));
     }
@@ -1314,16 +1355,18 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
     const int set = (dcg ? 0 : 2) + ((cfg & TG_C1Z) != 0);
     u32 rem = nzs;
     {   // greater-1 flags of the first 8 non-zero levels
-        const int K = (CX_GT1 + 4 * set) << 1;
+        const int K = TK(CX_GT1 + 4 * set, 0);
         u16 *const g0 = tb + cnt, *const gend = g0 + m8;
-        int seenbig = 0;
+        int seenbig = 0, hidx = 8;                          // hidx: 8 + (1 << bins coded on context 0 so far) - 1 + their pattern
         UNROLL_FULL
         for (int j = 0; j < 8; j++) {
             const int p2 = 31 - clz_nz(rem | 1u);
             const int bigj = (int)((bigs >> p2) & 1u);
             u16 *p = g0 + j;
             p = p > gend ? gend : p;
-            *p = (u16)(K + (seenbig ? 0 : 2 * (j < 2 ? j + 1 : 3)) + bigj);
+            int hint = 0;
+            if (HINT) { hint = SM.pu_gt[seenbig ? hidx : j]; hidx = seenbig ? 2 * hidx - 7 + bigj : hidx; }      // (8 + m) -> 8 + 2 m + 1 + bin
+            *p = (u16)(K + ((seenbig ? 0 : (j < 2 ? j + 1 : 3)) << 8) + (hint << 1) + bigj);
             seenbig |= bigj;
             rem &= (1u << p2) - 1u;
         }
@@ -1332,7 +1375,7 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
     const u32 big8 = bigs & (nzs ^ rem);                  // levels above 1 among the first 8 non-zero ones
     const int anybig = big8 != 0, fb = 31 - clz_nz(big8 | 1u);
     const int g2 = (int)((g2s >> fb) & 1u) & anybig;     // greater-2 flag of the first of them (:1232-1238)
-    tb[cnt] = (u16)(((CX_GT2 + set) << 1) | g2);
+    tb[cnt] = (u16)(TK(CX_GT2 + set, g2) | (HINT ? SM.cx0[CX_GT2 + set] << 1 : 0));
     cnt += anybig;
     int signs = 0;
     UNROLL_FULL
@@ -1512,10 +1555,12 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
                 if (nzm != 0) {
                     const int in = T.incg[st][hibit(nzm)];
-                    w.n = last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, in >> 2, in & 3));
+                    const LastPos lp = last_pos_prep(0, st, in >> 2, in & 3);
+                    w.n = P.hint ? last_pos_emit<0, true, true>(w.o, w.n, lp) : last_pos_emit<0, true>(w.o, w.n, lp);      // PU candidates: tokens with state hints (priced by code_token_r)
                     ls_flush(ls, w);                        // <= 7 tokens stay staged: each part below then fits the row
                     TgB B;
-                    w.n = tokg_a_fast<0>(w.o.tb, w.n, L, nzm, mcode, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
+                    const int cfg4 = TG_DC | TG_LAST | st << TG_ST;
+                    w.n = (P.hint ? tokg_a_fast<0, true>(w.o.tb, w.n, L, nzm, mcode, cfg4, B) : tokg_a_fast<0>(w.o.tb, w.n, L, nzm, mcode, cfg4, B)) & 0xFFFF;
                     if (B.esc) {
                         ls_flush(ls, w);
                         w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B);
@@ -1523,7 +1568,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                         w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B);
                     }
                     w.n = tokg_end<true, true>(w.o, w.n, B);
-                } else if (P.shape == 3) w.n = last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));   // PU pricing codes the residual syntax of an all-zero block (:1515)
+                } else if (P.shape == 3) w.n = P.hint ? last_pos_emit<0, true, true>(w.o, w.n, last_pos_prep(0, st, 0, 0)) : last_pos_emit<0, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));   // PU pricing codes the residual syntax of an all-zero block (:1515)
                 ls_end(ls, w, W, c);
                 W.tnz[c] = (u8)(nzm != 0);
             }
@@ -1796,7 +1841,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 int cg = 0;
                 if (talk) {
                     TokOut o; o.tb = row; o.pos = 0; o.cap = ROWCAP; o.glob = 0;
-                    if (seg == 0) { to_put(o, 0, (cbf_ctx << 1) | 0); cg = 1; }
+                    if (seg == 0) { to_put(o, 0, TK(cbf_ctx, 0)); cg = 1; }
                     else { TgB B; const int ra = tokg_a_fast<s>(row, 0, L, nzm, mcode, cfg, B); cg = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, ra & 0xFFFF, L, B), B); }
                 }
                 MARK("group_tokens");
@@ -1817,7 +1862,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                     if (fits) {
                         if (lead) {                                         // header tokens: staged in the slot's header row, like the group rows
                             TokOut ho; ho.tb = (u16 *)((u32a *)&W.pend[0][0] + sl * HDRSTRIDE_S(s)); ho.pos = 0; ho.cap = HDRCAP_S(s); ho.glob = 0;
-                            to_put(ho, 0, (cbf_ctx << 1) | 1);
+                            to_put(ho, 0, TK(cbf_ctx, 1));
                             last_pos_emit<s, true>(ho, 1, lp);
                             row_to_stream(ho.tb, P.tok + (size_t)c * TOK_CAP, tokn0 + off, hdr);
                         }
@@ -1950,7 +1995,7 @@ HD void p1_run(int wave, const P1Args &P) {
 HDN void p1_run_cold(int wave_, const P1Args P_) {
     P1Args P;
     P.N = uni_i(P_.N); P.y0 = uni_i(P_.y0); P.x0 = uni_i(P_.x0); P.k = uni_i(P_.k); P.per_mode_border = uni_i(P_.per_mode_border); P.out_kind = uni_i(P_.out_kind);
-    P.only_mode = uni_i(P_.only_mode); P.shape = uni_i(P_.shape); P.tok = uni_p(P_.tok); P.q = uni_i(P_.q); P.own = uni_i(P_.own); P.c_lo = uni_i(P_.c_lo); P.c_hi = uni_i(P_.c_hi);
+    P.only_mode = uni_i(P_.only_mode); P.shape = uni_i(P_.shape); P.tok = uni_p(P_.tok); P.q = uni_i(P_.q); P.own = uni_i(P_.own); P.c_lo = uni_i(P_.c_lo); P.c_hi = uni_i(P_.c_hi); P.hint = 0;
     p1_run(uni_i(wave_), P);
 }     // the winner's reconstruction: once per CU, kept out of line
 
@@ -1968,7 +2013,7 @@ HD void code_token(Arith &a, u8 *cx, S &sink, u32 tok) {
         a.low = (a.low << nb_) + mul24(a.range, (int)(tok & 255u));                 // range <= 510, value <= 255
         a.nbits -= nb_;
     } else {                                                                        // context-coded bin, :913-932
-        const int ci = (int)(tok >> 1), bin = (int)(tok & 1u);
+        const int ci = (int)(tok >> 8), bin = (int)(tok & 1u);
         const int pz = cx[ci];
         const uint2 e = SM.T.pst[pz];
         const int lps = (int)((e.x >> (((a.range >> 6) & 3) * 8)) & 0xFF);
@@ -1990,7 +2035,7 @@ HD void code_token(Arith &a, u8 *cx, S &sink, u32 tok) {
 #define CX_PAD (CTX_STRIDE - 1)
 HD void code_token_q(Arith &a, u8 *cx, u16 *lq, int &qn, u32 tok) {
     const int byp = tok >= 0x8000u;
-    const u32 cim = tok >> 1;
+    const u32 cim = tok >> 8;
     const int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
     const int pz = cx[ci];                                                        // < 128 everywhere: states are 7 bits, and the pad byte starts as 0 (ctx_init) and only ever receives next-state bytes
     const uint2 e = SM.T.pst[pz];
@@ -2011,6 +2056,28 @@ HD void code_token_q(Arith &a, u8 *cx, u16 *lq, int &qn, u32 tok) {
     a.nbits += need ? 8 : 0;
     a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
 }
+// The same on RESOLVED tokens (context-coded tokens that carry the state their context is in, see "Bin tokens"): no context
+// copy is read or written; `lw` = the four LPS ranges of the token's state (T.pst[(tok >> 1) & 127].x), whose address depends on
+// the token alone — the caller loads the words of a whole token block ahead of its steps, so nothing on the step's dependent
+// chain waits for LDS.
+HD void code_token_r(Arith &a, u16 *lq, int &qn, u32 tok, u32 lw) {
+    const int byp = tok >= 0x8000u;
+    const int lps = (int)((lw >> ((a.range >> 3) & 24)) & 0xFF);                    // :917-918
+    const int rm = a.range - lps;
+    const int is_lps = (int)(tok ^ (tok >> 1)) & 1;                                // bin ^ MPS of the hinted state
+    const int r2 = is_lps ? lps : rm;
+    const int sh = clz_nz((u32)r2) - 23;
+    const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+    const int add = (is_lps & !byp) ? rm : 0;
+    a.low = ((a.low + add) << nb_) + mul24(a.range, byp ? (int)(tok & 255u) : 0);
+    a.range = byp ? a.range : (r2 << sh);
+    a.nbits -= nb_;
+    const int need = a.nbits < 12;
+    lq[qn] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
+    qn += need;
+    a.nbits += need ? 8 : 0;
+    a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
+}
 template <class S>
 HD void lead_step(Arith &a, S &sink, int lead) {                                  // :863-878
     const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
@@ -2027,7 +2094,9 @@ HD u32 tok_of(const U4 &b, int j) { const u32 w = (j < 2) ? b.x : (j < 4) ? b.y 
 // the token loads (one 16-byte block per lane per 8 steps, issued one block ahead) and the byte flushes are wave-synchronous.
 // Returns non-zero if the lane's ring overflowed (the result is then void, see RingSink).
 // (stream_seg: one segment of a stream on a sink that outlives it — the pipe wave codes a CU's stream in pieces as they become known)
-HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) {
+// RES: the tokens are resolved (code_token_r); cx is not used
+template <bool RES>
+HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) {
     // token blocks are loaded unconditionally (index clamped to the stream's last block; p is always a valid address),
     // so the loop carries no conditional load and the only wait for a block is where it is first used, one round later
     const int last_blk = imax((n - 1) >> 3, 0);
@@ -2054,9 +2123,17 @@ HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, 
             MARK("p2_ring_sync");
             prof_add(PF_T_NDRAIN, tp0);
             const long long tp1 = prof_now();
+            if constexpr (RES) {
+                u32 lw[8];
+                UNROLL_FULL
+                for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
+                UNROLL_FULL
+                for (int j = 0; j < 8; j++) code_token_r(a, lm->lq, qn, tok_of(cur, j), lw[j]);
+            } else {
             UNROLL_FULL
             for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
                 code_token_q(a, cx, lm->lq, qn, tok_of(cur, j));
+            }
             MARK("p2_eight_tokens");
             prof_add(PF_T_NTOK, tp1); prof_cnt(PF_BORDER, 1);
             const long long tp2 = prof_now();
@@ -2086,9 +2163,11 @@ HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, 
 #endif
     }
 }
+HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) { stream_seg_t<false>(a, cx, lm, sink, p, n); }
+template <bool RES = false>
 HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) {
     RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
-    stream_seg(a, cx, lm, sink, p, n);
+    stream_seg_t<RES>(a, cx, lm, sink, p, n);
     const long long tx3 = prof_now();
     ring_finish(sink, a.cnt);
     prof_add(PF_X3, tx3);
@@ -2119,6 +2198,19 @@ HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, LaneMem *lm, u8 *gbuf, con
     const int ovf = stream_run(a, cx, lm, gbuf, p, on ? n : 0);
     if (WAVE_ANY(ovf)) {                                    // practically never: redo the overflowed lanes without the ring
         if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i); }
+        stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
+    }
+}
+// One trial on resolved tokens (the 4x4 PU candidates: fresh contexts, state hints in the tokens): no context copy at all.  The
+// safe path (ring overflow) is the ordinary coder on a copy of the fresh contexts — the tokens carry their context indices too.
+HD void run_trial_r(Arith &a, const u8 *cx_fresh, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n, int on) {
+    const Arith a0 = a;
+#ifdef IMCVT_TOKSTAT
+    if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
+#endif
+    const int ovf = stream_run<true>(a, cx, lm, gbuf, p, on ? n : 0);
+    if (WAVE_ANY(ovf)) {
+        if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_fresh + i); }
         stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
     }
 }

@@ -55,12 +55,15 @@ struct P1Item { int own, shape, lo, hi; };
 #ifndef TU0_SHARE
 #define TU0_SHARE 1
 #endif
+#ifndef PU_HINTS
+#define PU_HINTS 1        // launches with a pipe wave: the PU candidates of an 8x8 CU carry state hints and are priced without context copies
+#endif
 HDN void tu0_from_pu0(int wave_, u16 *tok1_) {          // (out of line: inlined it costs eval_2Nx2N's passes registers)
     const int wave = uni_i(wave_); u16 *const tok1 = uni_p(tok1_);
     WaveMem &W = WM(wave);
     const WaveMem &W2 = WM(2);
     const u16 *tok2 = wave_tok(F.sc, 2);
-    while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause();
+    if (F.pipe) { while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause(); } else { while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause_long(); }
     wave_sync();
     LANES(l) {
         if (l < NMODE) {
@@ -127,7 +130,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     else if (wave < 2) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = split_mode(N, wave); }
     else { nit = 2; for (int i = 0; i < 2; i++) { it[i].own = i; it[i].shape = i; it[i].lo = split_mode(N, i); it[i].hi = NMODE; } }
     P1Args P;
-    P.q = q; P.only_mode = -1;
+    P.q = q; P.only_mode = -1; P.hint = 0;
     long long pt = prof_now();
     for (int ii = 0; ii < nit; ii++) {
         const int shape = it[ii].shape;
@@ -159,17 +162,35 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 #ifndef IMCVT_HOSTEMU
     if (big) { if (F.prio_base) SETPRIO(3); else SETPRIO(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
 #endif
+    // The four-TU wave of an 8x8 CU also codes the NxN trial (:1530-1543), as a 36th stream beside its 35 candidates: same entry state
+    // (the CU's), about the same length — a lane that would idle instead of a whole wave pass with ONE live lane on the PU wave (9 % of
+    // all vector instructions of a full device).  Launches with a pipe wave price the NxN CU there (nxn_pipe).
+    const int host = !big && wave == 1 && !F.pipe;
+    int nxn_n = 0;
+    if (host) {
+        while (lds_ld_i32(&SM.nxn_ready) == 0) pipe_pause_long();      // (only launches without a pipe wave come here: throughput shapes)
+        wave_sync();                                    // (the PU wave drained its token stores before it raised the flag)
+        nxn_n = SM.nxn_n;
+    }
     LANES(l) {
-        const int on = l < NMODE, ll = on ? l : 0;
+        const int on = l < NMODE + host, ll = on ? l : 0, guest = host && l == NMODE;
         Arith a = SM.entry_a[depth];
         const int len0 = arith_len(a);
-        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], &W.u.p2.lm[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP, W.tokn[ll], on);
-        if (on) {
+        const u16 *stream = guest ? wave_tok(F.sc, 2) + (size_t)NMODE * TOK_CAP : tok + (size_t)ll * TOK_CAP;
+        u8 *gbuf = guest ? ubytes + (size_t)(2 * NMODE) * TRIAL_BYTES : ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES;      // the NxN trial's bytes: the PU wave's block, lane 0
+        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], &W.u.p2.lm[ll], gbuf, stream, guest ? nxn_n : W.tokn[ll], on);
+        if (on && !guest) {
             W.fin[l] = pack_arith(a);
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
 #ifdef IMCVT_TOKSTAT
             fprintf(stderr, "TS %d %d %d %d %d %d %d %d\n", N, wave, l, W.tokn[l], W.cost[l], W.sse[l], arith_len(a) - len0, (N > 8) ? SM.split_cost[depth] : -1);
 #endif
+        }
+        if (guest) {
+            WaveMem &W2 = WM(2);
+            W2.fin[0] = pack_arith(a);
+            W2.nxn_cost = rd_cost(rw, W2.pu_sse[0] + W2.pu_sse[1] + W2.pu_sse[2] + W2.pu_sse[3], arith_len(a) - len0);
+            lds_st_i32(&SM.nxn_ready, 0);               // (the PU wave raises it again only after the workgroup barrier that ends this CU)
         }
     }
     wave_sync();
@@ -196,6 +217,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     WaveMem &W = WM(wave);
     const int q = F.job.q;
     const int pipe = F.pipe;                            // a pipe wave prices the NxN CU (nxn_pipe below): this wave only walks the PU chain
+    const int hint = PU_HINTS && pipe;                  // latency-bound launches: PU candidates are priced on resolved tokens (fewer instructions on the PU chain, more in its passes)
     u16 *tok = wave_tok(F.sc, wave);
     u16 *nxn = tok + (size_t)NMODE * TOK_CAP;
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
@@ -204,7 +226,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
         if (TU0_SHARE && k == 1) {                      // the four-TU wave has its copy of PU 0's pass (long ago: it takes it while this wave prices PU 0)
-            while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause();
+            if (pipe) { while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause(); } else { while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause_long(); }
             wave_sync_lds();
             LANES(l) { if (l == 0) { lds_st_i32(&SM.pu0_ready, 0); lds_st_i32(&SM.pu0_taken, 0); } }
         }
@@ -215,7 +237,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         prof_add(PF_P1_32, pt); pt = prof_now();            // (NxN chain, IMCVT_PROF builds: p1_32 = borders, p1_16 = store drain before pricing, p1_8 = pick + keep,
         P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
-        P.own = wave; P.c_lo = 0; P.c_hi = NMODE;
+        P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = hint;
         p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         wave_sync();
@@ -224,7 +246,9 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             const int on = l < NMODE, ll = on ? l : 0;
             Arith a; arith_reset(a);
-            run_trial(a, SM.cx0, W.u.p2.cx[ll], &W.u.p2.lm[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP + 8, W.tokn[ll] - 8, on);
+            u8 *gb = ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES; const u16 *ts = tok + (size_t)ll * TOK_CAP + 8;
+            if (hint) run_trial_r(a, SM.cx0, W.u.p2.cx[ll], &W.u.p2.lm[ll], gb, ts, W.tokn[ll] - 8, on);      // (tokens with state hints: p1_run_4)
+            else run_trial(a, SM.cx0, W.u.p2.cx[ll], &W.u.p2.lm[ll], gb, ts, W.tokn[ll] - 8, on);
             if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
 #ifdef IMCVT_TOKSTAT
             if (on) fprintf(stderr, "TS %d %d %d %d %d %d %d %d\n", 4, wave, l, W.tokn[l] - 8, W.cost[l], W.sse[l], arith_len(a), -1);
@@ -296,20 +320,11 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             pos += cnt;
         }
         if (l < 8 && ((pos + l) >> 3) == (pos >> 3) && (pos & 7) != 0) g_st16((i16 *)(nxn + pos + l), (int)TOK_IDLE);   // idle tokens up to the block boundary
-        wave_sync();
+        wave_sync();                                    // the stream is in memory
         prof_add(PF_P2_32, ptn);
-        const long long ptt = prof_now();
-        const int on = l == 0;
-        Arith a = SM.entry_a[2];
-        const int len0 = arith_len(a);
-        run_trial(a, SM.entry_cx[2], W.u.p2.cx[0], &W.u.p2.lm[0], ubytes + (size_t)(wave * NMODE) * TRIAL_BYTES, nxn, pos, on);
-        if (on) {
-            W.fin[0] = pack_arith(a);
-            W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);
-        }
-        prof_add(PF_P2_16, ptt);
+        if (l == 0) { SM.nxn_n = pos; lds_st_i32(&SM.nxn_ready, 1); }      // the four-TU wave codes it beside its 35 candidates (eval_2Nx2N) and leaves the result in this wave's fin[0] / nxn_cost
     }
-    wave_sync();
+    wave_sync_lds();
     prof_add(PF_P2_NXN, ptn);
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(2); else SETPRIO(0);
@@ -468,14 +483,18 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     const int kind = SM.win_kind, mode = SM.win_mode;
     if (kind != 0) {
         const int pk = (kind == 3) && F.pipe;             // the NxN trial ran on the pipe wave: its result sits in that wave's slice, lane nxn_lane
+        // where the winning trial left its results — ww / wl: bytes (Scratch.bytes block and lane); WW.fin[fl]: final coder state; CW.u.p2.cx[cl]: contexts.
+        // Without a pipe wave the NxN trial is the four-TU wave's 36th coder (eval_2Nx2N): bytes and state in the PU wave's places, contexts in ITS row.
         const int ww = pk ? PIPE_WAVE : (kind == 3) ? 2 : kind - 1, wl = pk ? SM.nxn_lane : (kind == 3) ? 0 : mode, fl = pk ? 0 : wl;
         const WaveMem &WW = pk ? PM : WM(ww);
+        const WaveMem &CW = (kind == 3 && !pk) ? WM(1) : WW;
+        const int cl = (kind == 3 && !pk) ? NMODE : wl;
         const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WW.fin[fl].w2 >> 16);
         const u8 *src = lane_bytes(F.sc, ww, wl);
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
             for (int i = tid; i < cnt1 - cnt0; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(src + i));
-            if (tid < CTX_STRIDE) SM.cx[tid] = WW.u.p2.cx[wl][tid];
+            if (tid < CTX_STRIDE) SM.cx[tid] = CW.u.p2.cx[cl][tid];
             if (tid == 64) SM.live = unpack_arith(WW.fin[fl]);
             if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445, :1549-1553)
                 const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
@@ -583,11 +602,16 @@ HD void team_publish(i32 *flag, i32 v) {
     WAVES(w) LANES(l) { if (w == 0 && l == 0) m_st32(flag, (u32)v); }
 }
 // the same for a request: the mail words are visible to the helper that claims the ticket and finds this workgroup's index in it
+// A ring entry names its ticket: (ticket mod 2^20) << 12 | main workgroup index + 1.  A claimer waits for ITS ticket's entry; an entry of a
+// later lap (the claimer was held up for a whole lap of the ring while other workgroups kept posting and being served) tells it that
+// its ticket is gone — the owner has long stopped waiting (ABANDON_TICKS) — and it goes back to polling instead of waiting for a
+// value that will never come.
+HD u32 ring_entry(u32 ticket, int main_id) { return (ticket & 0xFFFFFu) << 12 | ((u32)main_id + 1u); }
 HD void pool_push(int slot) {
     drain_stores();
     wg_sync();
     WAVES(w) LANES(l) {
-        if (w == 0 && l == 0) { PoolShard *q = &F.pq->sh[F.main_id % POOL_SHARDS]; const u32 t = m_add32(&q->tail[slot], 1u); m_st32(&q->ring[slot][t % POOL_QCAP], (u32)F.main_id + 1u); }
+        if (w == 0 && l == 0) { PoolShard *q = &F.pq->sh[F.main_id % POOL_SHARDS]; const u32 t = m_add32(&q->tail[slot], 1u); m_st32(&q->ring[slot][t % POOL_QCAP], ring_entry(t, F.main_id)); }
     }
 }
 // await: returns once flag == v; mail loads issued afterwards see what the publisher stored before publishing
@@ -906,7 +930,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
         NOUNROLL
         for (int i = tid; i < (int)(sizeof(Tables) / 4); i += WG_THREADS) dst[i] = src[i];
         for (int i = tid; i < job.hdr_len; i += WG_THREADS) g_st8(job.out + i, g_ld8(hdr + i));
-        if (tid == 0) { F.job = job; F.sc = sc; F.out_pos = job.hdr_len; F.trace_n = 0; F.ctu_y = 0; F.ctu_x = 0; F.pace_mine = 0; F.pace_inc = 65536 / ((job.hp / 32) * (job.wp / 32)); }
+        if (tid == 0) { F.job = job; F.sc = sc; F.out_pos = job.hdr_len; F.trace_n = 0; F.ctu_y = 0; F.ctu_x = 0; F.pace_inc = 65536 / ((job.hp / 32) * (job.wp / 32)); }      // (pace_mine runs on over this workgroup's frames, like the launch's progress sum)
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
         if (l < PF_N) SM.prof[w][l] = 0;
 #endif
@@ -916,6 +940,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
         const int tid = w * 64 + l;
         if (tid < CTX_STRIDE) { const u8 v = g_ld8(&gK->ctx_init[job.q][tid]); SM.cx[tid] = v; SM.cx0[tid] = v; }
         if (tid >= 128 && tid < 128 + 4 * RQ_CLASSES) (&SM.rthr[0][0])[tid - 128] = (i32)g_ld32(&gK->rthr[job.q][0][0] + (tid - 128));
+        for (int i = tid; i < (PU_SIG_N + PU_GT_N) / 4; i += WG_THREADS) { if (i < PU_SIG_N / 4) *(u32a *)&SM.pu_sig[4 * i] = g_ld32(&gK->pu_sig[job.q][4 * i]); else *(u32a *)&SM.pu_gt[4 * (i - PU_SIG_N / 4)] = g_ld32(&gK->pu_gt[job.q][4 * (i - PU_SIG_N / 4)]); }
         if (tid == 64) arith_reset(SM.live);
     }
     wg_sync();
@@ -932,7 +957,8 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
                         // share of its frame it has finished with the average over all of them, and one that lags more than a CTU and
                         // a half runs at raised wave priority until it has caught up to within half a CTU (priority outranks age).
                         if ((cy | cx) != 0) { F.pace_mine += F.pace_inc; m_add32(&F.pq->progress, (u32)F.pace_inc); }
-                        const int avg = (int)(m_ld32(&F.pq->progress) / (u32)F.pace_n), lag = avg - F.pace_mine;
+                        const u32 running = m_ld32(&F.pq->mains_taken);                  // main workgroups that have actually started (<= the planned number)
+                        const int avg = (int)(m_ld32(&F.pq->progress) / (running ? running : 1u)), lag = avg - F.pace_mine;
                         if (lag * 2 > 3 * F.pace_inc) F.prio_base = 2; else if (lag * 2 < F.pace_inc) F.prio_base = F.pace_base;
                     }
                 }
@@ -1019,11 +1045,19 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
                     mail_idle_pause(round++);
                 }
                 if (pick >= 0) {                            // the ticket's owner publishes its index right after taking the ticket
-                    u32 *e = &pq->sh[shard].ring[pick][ticket % POOL_QCAP]; u32 v;
+                    const u32 *e = &pq->sh[shard].ring[pick][ticket % POOL_QCAP]; u32 v; int got = 0;
                     const unsigned long long t0 = wd_now();
-                    for (int n = 0; (v = m_ld32(e)) == 0u; n++) { if (wd_poll(pq, t0, n, 2, shard, (int)ticket)) break; mail_poll_pause(); }
-                    if (v == 0u) pick = -1;                 // (watchdog)
-                    else { m_st32(e, 0u); id = (int)v - 1; }
+                    for (int n = 0; ; n++) {
+                        v = m_ld32(e);
+                        const u32 lap = ((v >> 12) - ticket) & 0xFFFFFu;                  // 0: this ticket's entry (or nothing published in a fresh ring: v == 0)
+                        if (v != 0u && lap == 0u) { got = 1; break; }
+                        if (v != 0u && lap < 0x80000u) break;                              // a later lap's entry: the ticket is gone
+                        if ((n & 15) == 15 && m_ld32(&pq->frames_done) == (u32)njobs) { pick = -1; break; }      // nothing can be outstanding any more
+                        if (wd_poll(pq, t0, n, 2, shard, (int)ticket)) { pick = -1; break; }
+                        mail_poll_pause();
+                    }
+                    if (got) id = (int)(v & 0xFFFu) - 1;
+                    else if (pick >= 0) pick = -3;          // poll again
                 }
                 F.hb_last = wd_now();
                 SM.red[1] = pick; SM.red[2] = id;
@@ -1032,6 +1066,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
         wg_sync();
         prof_add(PF_CTUIO, tidle);                          // (booked as "idle": waiting for a request)
         const int slot = SM.red[1], id = SM.red[2];
+        if (slot == -3) continue;
         if (slot < 0) { taken = slot == -2 ? id : -1; break; }
         WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&mail[id].s[slot].req_flag, 0x10000u | (u32)home_blk); m_st32(&mail[id].s[slot].pad0_[0], (u32)wd_now()); } }      // (debug: who took the request, when)
         serve_request(gK, jobs, &mail[id].s[slot]);
@@ -1088,7 +1123,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; SM.nxn_ready = 0; SM.nxn_n = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;
@@ -1128,7 +1163,7 @@ HD void kernel_main(const KArgs &A, int block) {
     // arbitration of the SIMDs it shares with them (measured: 320 teams 5.75 s -> 4.95 s, 256 teams 4.78 s -> 4.31 s)
     if (pool && A.prio >= 2) SETPRIO(2);
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.prio_base = (pool && A.prio >= 2) ? 2 : 0; F.pace_base = F.prio_base; F.pace_n = nm; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.prio_base = (pool && A.prio >= 2) ? 2 : 0; F.pace_base = F.prio_base; F.pace_n = nm; F.pace_mine = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.mail = pool ? A.mail + team : (TeamMail *)0; F.pq = A.pq; F.main_id = team; F.lim[SLOT_16] = A.lim16; F.lim[SLOT_32] = A.lim32; F.post_pm[SLOT_16] = A.post16; F.post_pm[SLOT_32] = A.post32; F.post_acc[SLOT_16] = 500; F.post_acc[SLOT_32] = 500; F.posted[0] = 0; F.posted[1] = 0; F.stale[0] = 0; F.stale[1] = 0; F.gaveup = 0; F.seq[0] = 0; F.seq[1] = 0; F.aborted = 0; } }
     // (this barrier is load-bearing: without it hipcc threads the `thread 0` branch above into the one inside the loop, and the
     // other lanes of wave 0 then reach the loop's first barrier BEFORE thread 0 has stored next_frame — seen as a memory fault)

@@ -8,7 +8,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "hevc_frame.h"
@@ -45,6 +48,9 @@ struct imcvt_hevc_ctx {
     int lim16 = -1, lim32 = -1, prio = -1;  // pool tuning (IMCVT_POOL_LIM16 / _LIM32 / _PRIO; < 0: defaults from the launch shape)
     int last_mains = 0, last_help = 0;
     int pipe = -1, pipe_wg = 0, last_pipe = 0;   // pipe wave (256-thread workgroups): < 0 whenever the launch fits pipe_wg workgroups (3 per CU), 0 never, 1 as -1 (forced on where it fits)
+    int occ_wg = 0, occ_pipe = 0;           // workgroups per compute unit the HIP occupancy API reports for 192- / 256-thread workgroups of this kernel
+    int census_wg = 0, census_pipe = 0;     // workgroups of a max_wg / pipe_wg launch that were resident at once when the context was created (0: not measured)
+    int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
@@ -95,6 +101,14 @@ static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, i
                        c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1), c->d_fclk);
 }
 
+// residency census: `grid` workgroups that count themselves, wait ~1 ms and record how many had started by then (kernel_main, team_size < 0)
+static int census(imcvt_hevc_ctx *c, int grid, int pipe) {
+    if (grid < 1 || hipMemset(c->d_counter, 0, 8 * sizeof(int)) != hipSuccess) return 0;
+    launch(c, grid, 0, 0, -1, 0, 0, pipe);
+    int v[2] = { 0, 0 };
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return v[1];
+}
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     if (!have_device()) return nullptr;
     imcvt_hevc_ctx *c = new imcvt_hevc_ctx();
@@ -111,14 +125,20 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
         } else (void)hipGetLastError();
     }
     c->cus = prop.multiProcessorCount;
-    c->max_wg = max_workgroups > 0 ? max_workgroups : 4 * prop.multiProcessorCount;   // LDS (40.6 KB) and registers (168) admit 4 per CU
+    // How many workgroups of a launch can be resident at once is what every pool shape is planned against (main workgroups wait for
+    // helpers, helpers poll): it comes from the occupancy API for the actual block sizes and dynamic LDS — 4 per compute unit for
+    // 192 threads (40.9 KB of LDS, 168 registers), 3 for 256 threads with the pipe wave's slice — and is checked against a census
+    // launch below (the API has been seen one block high for some register counts).
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_wg, hevc_encode_frames, WG_THREADS, 0) != hipSuccess || c->occ_wg < 1) { (void)hipGetLastError(); c->occ_wg = 4; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_pipe, hevc_encode_frames, WG_THREADS_PIPE, PIPE_LDS_BYTES) != hipSuccess || c->occ_pipe < 1) { (void)hipGetLastError(); c->occ_pipe = 3; }
+    c->max_wg = max_workgroups > 0 ? max_workgroups : c->occ_wg * prop.multiProcessorCount;
     if (const char *e = getenv("IMCVT_HEVC_TEAM")) imcvt_hevc_set_team(c, atoi(e));      // clamped to 0..3 like the API call
     if (const char *e = getenv("IMCVT_POOL_POST16")) c->post16 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_POST32")) c->post32 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_LIM16")) c->lim16 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_LIM32")) c->lim32 = atoi(e);
     if (const char *e = getenv("IMCVT_POOL_PRIO")) c->prio = atoi(e);
-    c->pipe_wg = c->max_wg / 4 * 3;                     // registers (4 x 168 per workgroup) and LDS (40.6 + 6.9 KB) admit 3 per CU
+    c->pipe_wg = max_workgroups > 0 ? (int)((long long)c->max_wg * c->occ_pipe / c->occ_wg) : c->occ_pipe * prop.multiProcessorCount;     // registers (4 x 168 per workgroup) and LDS (40.9 + 6.9 KB) admit 3 per CU
     if (const char *e = getenv("IMCVT_HEVC_PIPE")) c->pipe = atoi(e);
     c->mail_cap = c->max_wg / 2 + 8;
     Tables *T = new Tables(); ColdTables *K = new ColdTables();
@@ -153,6 +173,13 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
             ok = ok && hipDeviceSynchronize() == hipSuccess;
         }
         if (!ok) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
+        // census: a launch of max_wg (pipe_wg) workgroups that only count themselves — what is resident at once is what the plans may use
+        if (max_workgroups <= 0 && !getenv("IMCVT_HEVC_NO_CENSUS")) {
+            c->census_wg = census(c, c->max_wg, 0); c->census_pipe = census(c, c->pipe_wg, 1);
+            if (c->census_wg > 0 && c->census_wg < c->max_wg) { fprintf(stderr, "imcvt_hevc: %d of %d workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_wg, c->max_wg, c->occ_wg, c->census_wg); c->max_wg = c->census_wg; }
+            if (c->census_pipe > 0 && c->census_pipe < c->pipe_wg) { fprintf(stderr, "imcvt_hevc: %d of %d pipe-wave workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_pipe, c->pipe_wg, c->occ_pipe, c->census_pipe); c->pipe_wg = c->census_pipe; }
+            if (c->pipe_wg > c->max_wg) c->pipe_wg = c->max_wg;
+        }
     }
     return c;
 }
@@ -232,22 +259,32 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
 // workgroups per CU.  The same sixteenth of the slots stays free as in imcvt_hevc_plan; a pool that just misses the limit gives up
 // helpers for it as long as 1.5 per main workgroup remain (*nhelp is reduced); a forced shape may fill the last slot.
 // mode: what imcvt_hevc_plan returned.  Returns 1 if the launch runs with the pipe wave.
-extern "C" int imcvt_hevc_plan_pipe(int mode, int max_wg, int forced_shape, int *nmains, int *nhelp) {
-    if (!nmains || !nhelp || max_wg < 4) return 0;
-    const int pipe_wg = max_wg / 4 * 3, pipe_cap = pipe_wg - pipe_wg / 16;
+static int plan_pipe_wg(int mode, int max_wg, int pipe_wg, int forced_shape, int *nmains, int *nhelp) {      // pipe_wg: resident 256-thread workgroups (occupancy API x compute units)
+    if (!nmains || !nhelp || max_wg < 4 || pipe_wg < 3) return 0;
+    const int pipe_cap = pipe_wg - pipe_wg / 16;
     if (mode > 1 && !forced_shape && *nmains + *nhelp > pipe_cap && *nmains + (3 * *nmains + 1) / 2 <= pipe_cap) *nhelp = pipe_cap - *nmains;
     return *nmains + *nhelp <= (forced_shape ? pipe_wg : pipe_cap) ? 1 : 0;
 }
-static int pick_shape(const imcvt_hevc_ctx *c, int n, int *nmains, int *nhelp) {
-    if (c->force_mains > 0 && c->force_help > 0 && c->force_mains + c->force_help <= c->max_wg) {
-        *nmains = c->force_mains < n ? c->force_mains : n; *nhelp = c->force_help;
+extern "C" int imcvt_hevc_plan_pipe(int mode, int max_wg, int forced_shape, int *nmains, int *nhelp) { return plan_pipe_wg(mode, max_wg, max_wg / 4 * 3, forced_shape, nmains, nhelp); }
+// *forced: the shape is imcvt_hevc_set_shape's.  A forced shape the context cannot hold (workgroups, mailboxes, queue capacity) is an
+// argument error — returns 0 — before anything is written anywhere.
+static int pick_shape(const imcvt_hevc_ctx *c, int n, int *nmains, int *nhelp, int *forced) {
+    *forced = 0;
+    if (c->force_mains > 0 && c->force_help > 0) {
+        const int m = c->force_mains < n ? c->force_mains : n;
+        if (m + c->force_help > c->max_wg || m > c->mail_cap || 2 * m > POOL_SHARDS * POOL_QCAP) { *nmains = m; *nhelp = c->force_help; return 0; }
+        *nmains = m; *nhelp = c->force_help; *forced = 1;
         return 2;
     }
     return imcvt_hevc_plan(n, c->max_wg, c->force_team, nmains, nhelp);
 }
 extern "C" void imcvt_hevc_set_pool_tuning(imcvt_hevc_ctx *c, int lim16, int lim32, int prio) { if (c) { c->lim16 = lim16; c->lim32 = lim32; c->prio = prio; } }
 extern "C" void imcvt_hevc_set_pool_split(imcvt_hevc_ctx *c, int post16, int post32) { if (c) { c->post16 = post16; c->post32 = post32; } }
-extern "C" void imcvt_hevc_set_shape(imcvt_hevc_ctx *c, int nmains, int nhelp) { if (c) { c->force_mains = nmains > 0 ? nmains : 0; c->force_help = nhelp > 0 ? nhelp : 0; } }
+extern "C" void imcvt_hevc_set_shape(imcvt_hevc_ctx *c, int nmains, int nhelp) {
+    if (!c) return;
+    const int ok = nmains > 0 && nhelp > 0;               // both or neither: anything else returns to the automatic choice
+    c->force_mains = ok ? nmains : 0; c->force_help = ok ? nhelp : 0;
+}
 
 extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_hevc_frame *frames, void *stream_) {
     if (!c || n < 0 || (n > 0 && !frames)) return IMCVT_ERR_ARG;
@@ -256,7 +293,24 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     hipStream_t stream = (hipStream_t)stream_;
     // One launch in flight per context: job table, frame counter, mailboxes and per-workgroup scratch belong to the launch
     // that is running, whatever stream it was put on.
-    if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
+    if (c->timed) {
+        HIPCHK(hipEventSynchronize(c->ev1));
+        if (c->last_help > 0 && !c->pending_err) {       // the launch this one replaces: keep its verdict for whoever asks next (the queues are about to be zeroed)
+            u32 ab = 0;
+            if (hipMemcpy(&ab, &c->d_pq->abort, sizeof ab, hipMemcpyDeviceToHost) == hipSuccess && ab != 0u) {
+                c->pending_err = IMCVT_ERR_WATCHDOG;
+                fprintf(stderr, "imcvt_hevc: the previous launch of this context (%d + %d workgroups) was abandoned by the device watchdog - its results are invalid\n", c->last_mains, c->last_help);
+            }
+        }
+    }
+    int nmains = 0, nhelp = 0, forced = 0;
+    const int mode = pick_shape(c, n, &nmains, &nhelp, &forced);
+    const int use_pipe = (mode > 0 && c->pipe != 0) ? plan_pipe_wg(mode, c->max_wg, c->pipe_wg, forced, &nmains, &nhelp) : 0;
+    const int grid = nmains + nhelp;
+    if (mode <= 0 || grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) {
+        fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap);
+        return IMCVT_ERR_ARG;
+    }
     if (n > c->jobs_cap) {
         hipFree(c->d_jobs); hipFree(c->d_hdrs);
         if (c->h_jobs) hipHostFree(c->h_jobs);
@@ -281,15 +335,10 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     HIPCHK(hipMemsetAsync(c->d_counter, 0, 4 * sizeof(int), stream));
     HIPCHK(hipMemsetAsync(c->d_counter + 4, 0xFF, 2 * sizeof(int), stream));      // earliest start: a minimum
     HIPCHK(hipMemsetAsync(c->d_counter + 6, 0, 2 * sizeof(int), stream));
-    int nmains = 0, nhelp = 0;
-    const int mode = pick_shape(c, n, &nmains, &nhelp);
-    const int use_pipe = c->pipe != 0 ? imcvt_hevc_plan_pipe(mode, c->max_wg, c->force_mains > 0, &nmains, &nhelp) : 0;
-    const int grid = nmains + nhelp;
     if (mode > 1) {
-        HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nmains, stream));     // sequence numbers restart with every launch
+        HIPCHK(hipMemsetAsync(c->d_mail, 0, sizeof(TeamMail) * nmains, stream));     // sequence numbers restart with every launch (nmains <= mail_cap: checked above)
         HIPCHK(hipMemsetAsync(c->d_pq, 0, sizeof(PoolQ), stream));
     }
-    if (grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) { fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap); return IMCVT_ERR_ARG; }
     c->last_mains = nmains; c->last_help = nhelp;
     c->last_pipe = use_pipe;
     HIPCHK(hipEventRecord(c->ev0, stream));
@@ -317,12 +366,31 @@ extern "C" int imcvt_hevc_debug_census(imcvt_hevc_ctx *c, int grid) {
     if (!c || grid < 1) return IMCVT_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (c->timed) HIPCHK(hipEventSynchronize(c->ev1));
-    HIPCHK(hipMemset(c->d_counter, 0, 8 * sizeof(int)));
-    launch(c, grid, 0, 0, -1, 0, 0);
-    HIPCHK(hipDeviceSynchronize());
-    int v[2] = { 0, 0 };
-    HIPCHK(hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost));
-    return v[1];
+    return census(c, grid, 0);
+}
+extern "C" int imcvt_hevc_residency(imcvt_hevc_ctx *c, int *max_wg, int *pipe_wg, int *occ_per_cu, int *occ_pipe_per_cu, int *census_wg, int *census_pipe) {
+    if (!c) return IMCVT_ERR_ARG;
+    if (max_wg) *max_wg = c->max_wg;
+    if (pipe_wg) *pipe_wg = c->pipe_wg;
+    if (occ_per_cu) *occ_per_cu = c->occ_wg;
+    if (occ_pipe_per_cu) *occ_pipe_per_cu = c->occ_pipe;
+    if (census_wg) *census_wg = c->census_wg;
+    if (census_pipe) *census_pipe = c->census_pipe;
+    return c->cus;
+}
+// Test aid: a co-tenant.  `grid` workgroups of 256 threads that hold `lds_bytes` of LDS each and spin for about `ms` milliseconds on
+// `stream` — what another kernel on the same device does to this library's launches (tests/test_gpu_parity.py).
+__global__ void imcvt_filler(int ticks100) {
+    extern __shared__ int filler_lds[];
+    if (threadIdx.x == 0) { filler_lds[0] = ticks100; const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < (unsigned long long)filler_lds[0]) __builtin_amdgcn_s_sleep(64); }
+    __syncthreads();
+}
+extern "C" int imcvt_hevc_debug_filler(int grid, int lds_bytes, int ms, void *stream) {
+    if (grid < 1 || lds_bytes < 4 || lds_bytes > 160 * 1024 || ms < 0) return IMCVT_ERR_ARG;
+    if (lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)imcvt_filler, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(imcvt_filler, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, ms * 100000);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // Waits for the context's last launch and reports how it ended: 0, or IMCVT_ERR_WATCHDOG when a wait between workgroups gave up
@@ -332,10 +400,11 @@ extern "C" int imcvt_hevc_last_status(imcvt_hevc_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     if (!c->timed) return 0;
     HIPCHK(hipEventSynchronize(c->ev1));
-    if (c->last_help <= 0) return 0;
+    const int earlier = c->pending_err; c->pending_err = 0;      // an earlier launch nobody asked about (imcvt_hevc_encode_device latched it)
+    if (c->last_help <= 0) return earlier;
     u32 v[16] = { 0 };
     HIPCHK(hipMemcpy(v, &c->d_pq->abort, sizeof v, hipMemcpyDeviceToHost));
-    if (v[0] == 0) return 0;
+    if (v[0] == 0) return earlier;
     fprintf(stderr, "imcvt_hevc: device watchdog: a %s gave up after %.0f s (slot/shard %u, seq/ticket %u, main workgroup %u, frame %d; launch %d + %d workgroups) — results invalid\n",
             v[1] == 1 ? "main workgroup waiting for a helper's answer" : "helper waiting for a ticket's owner", (double)WD_TICKS / 1e8, v[2], v[3], v[4], (int)v[5], c->last_mains, c->last_help);
     if (v[1] == 1) fprintf(stderr, "  when it gave up: its shard's queue of that kind had head %u tail %u; request flag %#x (0x1xxxx: taken by the helper with that home shard)\n", v[6], v[7], v[8]);
@@ -437,10 +506,9 @@ extern "C" void imcvt_hevc_shutdown(void) {
     g_devs.clear();
 }
 
-extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
-                                     unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len) {
-    if (n < 0 || (n > 0 && (!pbuffers || !imgs || !rcons || !ysz || !xsz || !qpd6 || !out_len))) return IMCVT_ERR_ARG;
-    for (int i = 0; i < n; i++) if (qpd6[i] < 0 || qpd6[i] > 4 || ysz[i] < 1 || xsz[i] < 1 || !pbuffers[i] || !imgs[i] || !rcons[i]) return IMCVT_ERR_ARG;
+// One merged batch on the devices (called by one thread at a time: the submission queue's leader, below).
+static int encode_batch_on_devices(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
+                                   unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len) {
     if (!have_device()) return IMCVT_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> guard(g_lock);
     int prev_dev = 0;
@@ -449,8 +517,12 @@ extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, cons
         int nd = 0;
         HIPCHK(hipGetDeviceCount(&nd));
         if (const char *e = getenv("IMCVT_HEVC_DEVICES")) { const int lim = atoi(e); if (lim >= 1 && lim < nd) nd = lim; }
-        g_devs.resize(nd);
-        for (int i = 0; i < nd; i++) g_devs[i].dev = i;
+        // Test seam: IMCVT_HEVC_FAKE_DEVICES=k runs the fan-out below with k LOGICAL devices that all sit on physical device 0, each with its
+        // own context, stream and slab — the i mod D split, the per-device slabs and the collection order on a box with one GPU.
+        int fake = 0;
+        if (const char *e = getenv("IMCVT_HEVC_FAKE_DEVICES")) { fake = atoi(e); if (fake < 1 || fake > 64) fake = 0; }
+        g_devs.resize(fake ? fake : nd);
+        for (int i = 0; i < (int)g_devs.size(); i++) g_devs[i].dev = fake ? 0 : i;
     }
     if (n == 0) return 0;
     // a device joins when it gets at least one frame; with one frame the caller's current device does the work
@@ -507,6 +579,77 @@ extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, cons
     g_last_devices = D;
     (void)hipSetDevice(prev_dev);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Submission queue.  The reference's entry point is re-entrant (src/HEVCe/HEVCe.c:1569 has no mutable globals): N threads may call
+// it at once.  Here one frame alone occupies a handful of workgroups for seconds, so concurrent callers must not queue up behind
+// each other: calls that arrive while a batch is being formed (a short window) or while the previous one runs are merged into ONE
+// device batch.  The first caller to find no leader becomes the leader: it waits the window, takes everything submitted so far,
+// runs it as one batch, hands every caller its results and gives the leadership up; a caller that is still waiting takes it over.
+// ---------------------------------------------------------------------------------------------------
+typedef int (*batch_backend_t)(int, unsigned char *const *, const unsigned char *const *, unsigned char *const *, int *, int *, const int *, int *);
+struct Submission {
+    int n; unsigned char *const *pbuffers; const unsigned char *const *imgs; unsigned char *const *rcons; int *ysz, *xsz; const int *qpd6; int *out_len;
+    int rc = 0; bool done = false;
+};
+static std::mutex g_qmu;
+static std::condition_variable g_qcv;
+static std::vector<Submission *> g_pending;
+static bool g_leader = false;
+static batch_backend_t g_backend = encode_batch_on_devices;
+static long g_q_calls = 0, g_q_batches = 0, g_q_max_batch = 0;
+static int coalesce_window_us() {
+    static int us = -1;
+    if (us < 0) { const char *e = getenv("IMCVT_HEVC_COALESCE_US"); us = e ? atoi(e) : 300; if (us < 0) us = 0; if (us > 1000000) us = 1000000; }
+    return us;
+}
+// Test aids: a stand-in for the device batch (NULL: the real one) so that the queue's logic runs without a GPU; its counters.
+extern "C" void imcvt_hevc_debug_set_backend(void *fn) { std::lock_guard<std::mutex> g(g_qmu); g_backend = fn ? (batch_backend_t)fn : encode_batch_on_devices; }
+extern "C" void imcvt_hevc_coalesce_stats(long *calls, long *batches, long *max_batch, int reset) {
+    std::lock_guard<std::mutex> g(g_qmu);
+    if (calls) *calls = g_q_calls;
+    if (batches) *batches = g_q_batches;
+    if (max_batch) *max_batch = g_q_max_batch;
+    if (reset) { g_q_calls = 0; g_q_batches = 0; g_q_max_batch = 0; }
+}
+static void lead_one_round(std::unique_lock<std::mutex> &lk) {       // called with the queue locked and g_leader == true; returns the same way
+    const int win = coalesce_window_us();
+    if (win > 0) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(win)); lk.lock(); }
+    std::vector<Submission *> take; take.swap(g_pending);
+    const batch_backend_t backend = g_backend;
+    lk.unlock();
+    size_t total = 0;
+    for (const Submission *u : take) total += (size_t)u->n;
+    std::vector<unsigned char *> pb(total), rc_(total); std::vector<const unsigned char *> im(total);
+    std::vector<int> ys(total), xs(total), q(total), len(total, 0);
+    size_t k = 0;
+    for (const Submission *u : take) for (int i = 0; i < u->n; i++, k++) { pb[k] = u->pbuffers[i]; im[k] = u->imgs[i]; rc_[k] = u->rcons[i]; ys[k] = u->ysz[i]; xs[k] = u->xsz[i]; q[k] = u->qpd6[i]; }
+    const int rc = total ? backend((int)total, pb.data(), im.data(), rc_.data(), ys.data(), xs.data(), q.data(), len.data()) : 0;
+    k = 0;
+    for (Submission *u : take) { for (int i = 0; i < u->n; i++, k++) if (rc == 0) { u->ysz[i] = ys[k]; u->xsz[i] = xs[k]; u->out_len[i] = len[k]; } u->rc = rc; }
+    lk.lock();
+    g_q_batches++; if ((long)total > g_q_max_batch) g_q_max_batch = (long)total;
+    for (Submission *u : take) u->done = true;
+}
+extern "C" int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
+                                     unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len) {
+    if (n < 0 || (n > 0 && (!pbuffers || !imgs || !rcons || !ysz || !xsz || !qpd6 || !out_len))) return IMCVT_ERR_ARG;
+    for (int i = 0; i < n; i++) if (qpd6[i] < 0 || qpd6[i] > 4 || ysz[i] < 1 || xsz[i] < 1 || !pbuffers[i] || !imgs[i] || !rcons[i]) return IMCVT_ERR_ARG;
+    Submission me; me.n = n; me.pbuffers = pbuffers; me.imgs = imgs; me.rcons = rcons; me.ysz = ysz; me.xsz = xsz; me.qpd6 = qpd6; me.out_len = out_len;
+    std::unique_lock<std::mutex> lk(g_qmu);
+    if (g_backend == encode_batch_on_devices && n > 0) { lk.unlock(); if (!have_device()) return IMCVT_ERR_NO_DEVICE; lk.lock(); }
+    g_q_calls++;
+    g_pending.push_back(&me);
+    while (!me.done) {
+        if (!g_leader) {
+            g_leader = true;
+            lead_one_round(lk);
+            g_leader = false;
+            g_qcv.notify_all();                         // results are out; whoever still waits takes the next round
+        } else g_qcv.wait(lk);
+    }
+    return me.rc;
 }
 
 extern "C" int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,

@@ -5,6 +5,8 @@
 //   * CABAC probability tables (reference :700-714) from H.265 rangeTabLps / transIdxLps.
 #pragma once
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "hevc_core.h"
 
 namespace imcvt {
@@ -120,8 +122,13 @@ inline void build_tables(Tables &T, ColdTables &K) {
     }
     static const u8 c4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };     // reference :1092
     for (int t = 0; t < 3; t++) { u64 w = 0; for (int k = 0; k < 16; k++) w |= (u64)c4[T.incg[t][k]] << (4 * k); T.c4tab[t] = w; }
-    { const u32 lr[8] = { 0, 70000, 90000, 92000, 157536, 190304, 92000 + (4u << 15), 92000 + (6u << 15) };       // reference :526-535
-      for (int l = 0; l < 8; l++) T.ldelta[l] = (lr[l] - lr[l > 0 ? l - 1 : 0]) / 16 | (lr[l] - lr[l > 1 ? l - 2 : 0]) / 16 << 16; }
+    // scan positions above n that share n's sig_coeff context in a 4x4 TU (tokg_a_fast<0, true>); position 15 is never coded as a flag
+    for (int t = 0; t < 3; t++) for (int k = 0; k < 16; k++) {
+        int prev[3] = { 0, 0, 0 }, np = 0;
+        for (int m = k + 1; m < 15; m++) if (c4[T.incg[t][m]] == c4[T.incg[t][k]]) { if (np < 3) prev[np] = m; np++; }
+        if (np > 2) { fprintf(stderr, "imcvt_hevc: a sig_coeff context of a 4x4 TU serves more than three positions\n"); abort(); }
+        T.c4prev[t][k >> 2] |= (u32)(prev[0] | prev[1] << 4) << (8 * (k & 3));
+    }
     for (int q = 0; q < 5; q++) {
         const int qp = q * 6 + 4;
         for (int i = 0; i < NCTX; i++) {
@@ -132,6 +139,23 @@ inline void build_tables(Tables &T, ColdTables &K) {
         }
     }
     for (int m = 0; m < 35; m++) { T.ang[m] = (u8)(kAng[m] + 32); T.iang[m] = kInvAng[m]; }
+    // state hints of the 4x4 PU candidates: what a FRESH context's state is after the bins coded on it earlier in the same TU
+    for (int q = 0; q < 5; q++) {
+        auto next = [&](int p, int bin) { return (int)(((bin ^ p) & 1) ? (T.pst[p].y & 0xFF) : ((T.pst[p].y >> 8) & 0xFF)); };
+        for (int f = 0; f < 9; f++) {
+            const int p0 = K.ctx_init[q][CX_SIG + f];
+            K.pu_sig[q][8 * f] = (u8)p0;
+            for (int b1 = 0; b1 < 2; b1++) K.pu_sig[q][8 * f + 1 + b1] = (u8)next(p0, b1);
+            for (int b2 = 0; b2 < 2; b2++) for (int b1 = 0; b1 < 2; b1++) K.pu_sig[q][8 * f + 3 + 2 * b2 + b1] = (u8)next(next(p0, b2), b1);      // b2 is coded first
+        }
+        K.pu_gt[q][0] = K.ctx_init[q][CX_GT1 + 1]; K.pu_gt[q][1] = K.ctx_init[q][CX_GT1 + 2];
+        { int p = K.ctx_init[q][CX_GT1 + 3]; for (int k = 0; k < 6; k++) { K.pu_gt[q][2 + k] = (u8)p; p = next(p, 0); } }
+        for (int n = 0; n <= 6; n++) for (int pat = 0; pat < (1 << n); pat++) {
+            int p = K.ctx_init[q][CX_GT1 + 0];
+            for (int i = n - 1; i >= 0; i--) p = next(p, (pat >> i) & 1);               // the first bin is the pattern's top bit
+            K.pu_gt[q][8 + (1 << n) - 1 + pat] = (u8)p;
+        }
+    }
     // RDOQ thresholds (rdoq_group, hevc_core.h): for one level of every class, the largest remainder (in units of 2^14) at which the
     // reference's loop still prefers l0 - 1; "never" (below every remainder) where it does not occur.
     for (int q = 0; q < 5; q++) for (int s = 0; s < 4; s++) {

@@ -26,7 +26,8 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe")
+           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
+           "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -110,8 +111,25 @@ def load_library():
     lib.imcvt_hevc_set_pool_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.imcvt_hevc_shutdown.restype = None
     lib.imcvt_hevc_shutdown.argtypes = []
+    if hasattr(lib, "imcvt_hevc_residency"):             # (absent only from older builds loaded through IMCVT_HEVC_LIB for A/B runs)
+        lib.imcvt_hevc_residency.restype = C.c_int
+        lib.imcvt_hevc_residency.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip, _ip, _ip]
+        lib.imcvt_hevc_debug_filler.restype = C.c_int
+        lib.imcvt_hevc_debug_filler.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.imcvt_hevc_debug_set_backend.restype = None
+        lib.imcvt_hevc_debug_set_backend.argtypes = [C.c_void_p]
+        lib.imcvt_hevc_coalesce_stats.restype = None
+        lib.imcvt_hevc_coalesce_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]
     _lib = lib
     return lib
+
+
+def coalesce_stats(reset=False):
+    """(calls submitted, device batches run, frames in the largest batch) of the host-pointer entry points' submission queue."""
+    lib = load_library()
+    a, b, c = C.c_long(0), C.c_long(0), C.c_long(0)
+    lib.imcvt_hevc_coalesce_stats(C.byref(a), C.byref(b), C.byref(c), int(reset))
+    return a.value, b.value, c.value
 
 
 def _check(rc, what):
@@ -221,6 +239,12 @@ class DeviceEncoder:
     def set_pool_split(self, post16: int = -1, post32: int = -1):
         """Debug / tuning: per mille of the 16x16 / 32x32 CUs offered to the helpers (< 0: from the launch shape)."""
         self.lib.imcvt_hevc_set_pool_split(self.ctx, int(post16), int(post32))
+
+    def residency(self):
+        """What the context plans its launches against: dict(cus, max_wg, pipe_wg, occ_per_cu, occ_pipe_per_cu, census_wg, census_pipe)."""
+        v = [C.c_int(0) for _ in range(6)]
+        cus = int(self.lib.imcvt_hevc_residency(self.ctx, *[C.byref(x) for x in v]))
+        return dict(zip(("max_wg", "pipe_wg", "occ_per_cu", "occ_pipe_per_cu", "census_wg", "census_pipe"), (x.value for x in v)), cus=cus)
 
     def last_resident(self):
         """Most workgroups of the last launch that ran at the same time."""

@@ -36,7 +36,8 @@ extern "C" {
  *   ysz,xsz   in : true size; out: size padded to a multiple of 32 (capped at 8192, :1580-1581)
  *   qpd6      0..4 (not validated by the reference; this library returns IMCVT_ERR_ARG outside 0..4)
  * Returns the stream length in bytes (>0), or a negative IMCVT_ERR_* (the reference's caller treats
- * <=0 as failure, src/imageio_hevc.c:38).  Thread-safe (internally serialised). */
+ * <=0 as failure, src/imageio_hevc.c:38).  Re-entrant like the reference's (which has no mutable globals): calls from several
+ * threads at once are merged into one device batch (see HEVCImageEncoderBatch) instead of running one after the other. */
 int HEVCImageEncoder(unsigned char *pbuffer, const unsigned char *img, unsigned char *img_rcon,
                      int *ysz, int *xsz, const int qpd6);
 
@@ -55,8 +56,12 @@ int writeHEVCImageFile(const char *p_filename, const uint8_t *p_buf, int is_rgb,
  * stays on the caller's current device), are encoded concurrently and copied back; results do not depend on
  * D.  ysz[i]/xsz[i] are updated to the padded sizes, out_len[i] receives each stream length.  Device memory
  * and contexts are created on first use and reused by later calls (imcvt_hevc_shutdown releases them).
- * Environment: IMCVT_HEVC_DEVICES=k limits the fan-out to the first k devices.
- * Returns 0, or a negative IMCVT_ERR_*.  Thread-safe (internally serialised).   */
+ * Environment: IMCVT_HEVC_DEVICES=k limits the fan-out to the first k devices; IMCVT_HEVC_FAKE_DEVICES=k (test seam) runs the
+ * fan-out with k logical devices that all sit on physical device 0, each with its own context, stream and slab.
+ * Concurrent callers: calls that arrive within a short window (IMCVT_HEVC_COALESCE_US, default 300 us) or while the previous
+ * batch is running are merged into ONE device batch — the first caller waits the window, takes everything submitted so far,
+ * runs it and hands every caller its results; 16 threads with a frame each cost about one frame's time, not sixteen.
+ * Returns 0, or a negative IMCVT_ERR_*.   */
 int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
                           unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len);
 
@@ -122,8 +127,10 @@ int imcvt_hevc_plan(int n_frames, int max_workgroups, int force_team, int *nmain
 int imcvt_hevc_last_team(imcvt_hevc_ctx *ctx, int *nteams);
 /* The same in full: returns 1 (no helpers) or 2 (pool), *nmains and *nhelp the workgroups of each kind. */
 int imcvt_hevc_last_shape(imcvt_hevc_ctx *ctx, int *nmains, int *nhelp);
-/* Debug / tuning aid: the next launches use exactly nmains main and nhelp helper workgroups (both > 0 and together within the
- * context's workgroups; fewer mains when there are fewer frames); (0, 0) returns to imcvt_hevc_set_team's choice. */
+/* Debug / tuning aid: the next launches use exactly nmains main and nhelp helper workgroups (fewer mains when there are fewer
+ * frames); anything but two positive numbers returns to imcvt_hevc_set_team's choice.  A shape the context cannot hold (more
+ * workgroups than are resident at once, more main workgroups than mailboxes) makes imcvt_hevc_encode_device return
+ * IMCVT_ERR_ARG before it touches any memory. */
 void imcvt_hevc_set_shape(imcvt_hevc_ctx *ctx, int nmains, int nhelp);
 /* Debug / tuning aid for launches with helpers: a main workgroup posts a 16x16 / 32x32 request only while fewer than lim16 / lim32
  * requests of that kind wait unclaimed in its queue shard (otherwise it evaluates the CU itself); prio >= 2 raises the wave
@@ -166,6 +173,22 @@ int imcvt_hevc_debug_census(imcvt_hevc_ctx *ctx, int grid);
 
 /* Debug aid: what the HIP occupancy API reports for the encoder kernel on the current device. */
 int imcvt_hevc_debug_occupancy(int *blocks_per_cu, int *cus, int *lds_per_block, int *lds_per_cu);
+
+/* What the context plans its launches against: returns the device's compute units; *max_wg / *pipe_wg = workgroups of 192 / 256
+ * threads (the latter with the pipe wave's dynamic LDS) that a launch may count on being resident at once — the HIP occupancy
+ * API's blocks per compute unit (*occ_per_cu, *occ_pipe_per_cu) x compute units, lowered to what a census launch at context
+ * creation found resident (*census_wg, *census_pipe; 0: not measured, e.g. with an explicit max_workgroups).  Any pointer may be NULL. */
+int imcvt_hevc_residency(imcvt_hevc_ctx *ctx, int *max_wg, int *pipe_wg, int *occ_per_cu, int *occ_pipe_per_cu, int *census_wg, int *census_pipe);
+
+/* Test aid: a co-tenant kernel — `grid` workgroups of 256 threads holding lds_bytes of LDS each that spin for about `ms` ms on
+ * `stream` (a hipStream_t): what another kernel on the device does to this library's launches. */
+int imcvt_hevc_debug_filler(int grid, int lds_bytes, int ms, void *stream);
+
+/* Test aids for the submission queue of the host-pointer entry points: a stand-in for the device batch (a function with
+ * HEVCImageEncoderBatch's signature; NULL restores the real one) so that the queue's logic can be exercised without a GPU, and
+ * its counters (calls submitted, device batches run, frames in the largest batch). */
+void imcvt_hevc_debug_set_backend(void *fn);
+void imcvt_hevc_coalesce_stats(long *calls, long *batches, long *max_batch, int reset);
 
 /* Library / build information, e.g. "imcvt_hevc gfx950 r3 ...". */
 const char *imcvt_hevc_version(void);

@@ -387,3 +387,124 @@ def test_teams_fill_exactly_the_workgroups_they_are_given(amd):
         ws, wr, _ = oracle.cpu_encode(a, 1)
         assert s == ws and (r == wr).all()
     enc.close()
+
+
+def test_residency_is_planned_from_the_occupancy_api_and_a_census(amd):
+    """Every pool shape is planned against the workgroups that are resident at once: that number comes from the HIP occupancy API for
+    the real block sizes and dynamic LDS (192 threads; 256 threads + the pipe wave's slice) and is confirmed by a census launch when
+    the context is created — no hard-coded '4 per compute unit'."""
+    enc = amd.DeviceEncoder()
+    r = enc.residency()
+    assert r["cus"] >= 1 and r["occ_per_cu"] >= 1 and r["occ_pipe_per_cu"] >= 1
+    assert r["max_wg"] <= r["occ_per_cu"] * r["cus"] and r["pipe_wg"] <= r["occ_pipe_per_cu"] * r["cus"]
+    assert r["census_wg"] == r["max_wg"] and r["census_pipe"] == r["pipe_wg"], r      # what was measured is what is planned with
+    lib = amd.load_library()
+    assert lib.imcvt_hevc_debug_census(enc.ctx, r["max_wg"]) == r["max_wg"]
+    enc.close()
+
+
+def test_forced_shape_beyond_the_context_is_an_error_before_anything_is_written(amd):
+    """imcvt_hevc_set_shape(max_wg - 1, 1) asks for more main workgroups than there are mailboxes: IMCVT_ERR_ARG, and nothing was
+    zeroed past the mailbox array on the way (the context keeps working, results unchanged)."""
+    import torch
+    from oracle import oracle, synth
+    enc = amd.DeviceEncoder()
+    r = enc.residency()
+    imgs = [synth.syn(48 + i, 40, i) for i in range(r["max_wg"])]           # enough frames that the forced main count is not clipped to the batch
+    batch = enc.make_batch([torch.from_numpy(a).cuda() for a in imgs], 1)
+    enc.encode(batch); ref = enc.results(batch)
+    for shape in ((r["max_wg"] - 1, 1), (r["max_wg"], r["max_wg"])):
+        enc.set_shape(*shape)
+        with pytest.raises(RuntimeError, match="bad argument"):
+            enc.encode(batch)
+    enc.set_shape(7, 0)                                  # half a shape is no shape: back to the automatic choice
+    enc.encode(batch); got = enc.results(batch)
+    assert all(a[0] == b[0] and (a[1] == b[1]).all() for a, b in zip(got, ref))
+    for i in (0, 1, len(imgs) - 1):
+        ws, wr, _ = oracle.cpu_encode(imgs[i], 1)
+        assert got[i][0] == ws and (got[i][1] == wr).all()
+    enc.close()
+
+
+def test_sixteen_threads_share_one_device_batch(amd):
+    """The reference's HEVCImageEncoder is re-entrant; here 16 host threads calling it at once are merged into one device batch
+    (submission queue, hevc_hip.hip) instead of waiting for each other: byte-identical outputs, a handful of batches, and about one
+    call's time rather than sixteen."""
+    import threading, time
+    from oracle import synth
+    imgs = [synth.syn(512, 256, s) for s in range(16)]
+    amd.HEVCImageEncoder(imgs[0], 0)                     # contexts exist, code is loaded
+    t0 = time.time(); one = amd.HEVCImageEncoder(imgs[0], 0); t_one = time.time() - t0
+    amd.hevc.coalesce_stats(reset=True)
+    out = {}
+    th = [threading.Thread(target=lambda i=i: out.__setitem__(i, amd.HEVCImageEncoder(imgs[i], 0))) for i in range(16)]
+    t0 = time.time()
+    for t in th: t.start()
+    for t in th: t.join()
+    t_all = time.time() - t0
+    calls, batches, biggest = amd.hevc.coalesce_stats()
+    assert calls == 16 and batches <= 4 and biggest >= 8, (calls, batches, biggest)
+    assert out[0][0] == one[0]
+    for i in range(16):
+        s, r, d = amd.HEVCImageEncoderBatch([imgs[i]], 0)[0]
+        assert out[i][0] == s and (out[i][1] == r).all() and out[i][2] == d, i
+    assert t_all < 4 * t_one, (t_one, t_all)             # serialised it would be 16 x
+
+
+def test_host_fan_out_over_four_logical_devices(amd):
+    """HEVCImageEncoderBatch's device fan-out (frame i -> device i mod D, per-device context / stream / slab, collection in frame
+    order) with D = 4 on a box with one GPU: IMCVT_HEVC_FAKE_DEVICES maps four logical devices onto device 0.  Same bytes as D = 1."""
+    from oracle import synth
+    lib = amd.load_library()
+    imgs = [synth.syn(64 + 8 * (s % 5), 48 + 4 * (s % 3), s) for s in range(11)]
+    qs = [s % 5 for s in range(11)]
+    a = amd.HEVCImageEncoderBatch(imgs, qs)
+    assert lib.imcvt_hevc_batch_devices() == 1
+    lib.imcvt_hevc_shutdown()
+    os.environ["IMCVT_HEVC_FAKE_DEVICES"] = "4"
+    try:
+        b = amd.HEVCImageEncoderBatch(imgs, qs)
+        assert lib.imcvt_hevc_batch_devices() == 4
+        c = amd.HEVCImageEncoderBatch(imgs[:3], qs[:3])   # fewer frames than devices: D = 3
+        assert lib.imcvt_hevc_batch_devices() == 3
+        one = amd.HEVCImageEncoder(imgs[5], qs[5])
+    finally:
+        del os.environ["IMCVT_HEVC_FAKE_DEVICES"]
+        lib.imcvt_hevc_shutdown()
+    for i in range(11):
+        assert a[i][0] == b[i][0] and (a[i][1] == b[i][1]).all() and a[i][2] == b[i][2], i
+    assert all(a[i][0] == c[i][0] for i in range(3)) and one[0] == a[5][0]
+    assert amd.HEVCImageEncoderBatch(imgs[:2], qs[:2])[1][0] == a[1][0] and lib.imcvt_hevc_batch_devices() == 1
+
+
+def test_pool_launch_beside_a_co_tenant_kernel(amd):
+    """A pool launch planned for the whole device (512 main + 448 helper workgroups) while another kernel holds compute units: fewer
+    of its workgroups are resident than planned.  Nothing in the pool depends on a workgroup that is not running (roles by placement,
+    requests only once a helper reported in, late answers abandoned) — ten launches, identical results, no watchdog, no outlier."""
+    import torch
+    from oracle import synth
+    lib = amd.load_library()
+    enc = amd.DeviceEncoder()
+    r = enc.residency()
+    if r["max_wg"] < 1024:
+        pytest.skip("planned for a device that holds 1024 workgroups")
+    uniq = [torch.from_numpy(synth.syn(160, 96, s)).cuda() for s in range(32)]
+    batch = enc.make_batch([uniq[i % 32] for i in range(512)], 0)
+    enc.set_shape(512, 448)
+    enc.encode(batch); ref = enc.results(batch); base_ms = enc.last_kernel_ms()
+    side = torch.cuda.Stream()
+    ms = []
+    for rep in range(10):
+        # 96 co-tenant workgroups of 256 threads that hold 100 KB of LDS each: 96 compute units take at most one encoder workgroup instead of four
+        assert lib.imcvt_hevc_debug_filler(96, 100 * 1024, 400, side.cuda_stream) == 0
+        enc.encode(batch); got = enc.results(batch)
+        ms.append(enc.last_kernel_ms())
+        assert enc.last_shape() == (512, 448)
+        assert all(a[0] == b[0] and (a[1] == b[1]).all() for a, b in zip(got, ref)), rep
+        side.synchronize()
+    assert max(ms) < 6 * base_ms + 50, (base_ms, ms)
+    from conftest import ROOT
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "cotenant_test.log"), "w").write(f"512+448 workgroups, 512 x 160x96 q0: alone {base_ms:.1f} ms; beside 96 co-tenant workgroups (100 KB LDS each, 400 ms): {[round(v, 1) for v in ms]} ms; resident {enc.last_resident()}\n")
+    enc.close()

@@ -156,3 +156,56 @@ def test_launch_shape_policy(built):
         assert use == (mm + hh <= 720)
     m, h = C.c_int(512), C.c_int(256)
     assert lib.imcvt_hevc_plan_pipe(2, 1024, 1, C.byref(m), C.byref(h)) == 1 and (m.value, h.value) == (512, 256)      # a forced shape may fill the last slot
+
+
+def test_submission_queue_merges_concurrent_callers(built):
+    """The reference's HEVCImageEncoder is re-entrant (src/HEVCe/HEVCe.c:1569, no mutable globals).  Here concurrent calls are merged
+    into one device batch by a submission queue (hevc_hip.hip): exercised without a GPU through a stand-in for the device batch that
+    records what it is handed.  16 threads with a frame each -> far fewer batches than calls, every caller gets ITS result back, and
+    a call that arrives while a batch runs joins the next one."""
+    import threading, time
+    import imcvt_amd
+    lib = imcvt_amd.load_library()
+    u8p = C.POINTER(C.c_ubyte); ip = C.POINTER(C.c_int)
+    seen = []
+
+    @C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(u8p), C.POINTER(u8p), ip, ip, ip, ip)
+    def backend(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len):
+        seen.append(n)
+        time.sleep(0.05)                                   # "the kernel runs": later callers pile up meanwhile
+        for i in range(n):
+            tag = imgs[i][0]                               # the caller's first pixel
+            pbuffers[i][0] = tag; rcons[i][0] = tag ^ 0xFF
+            out_len[i] = 100 + tag + qpd6[i]; ysz[i] = ysz[i] + 1000; xsz[i] = xsz[i] + 2000
+        return 0
+
+    lib.imcvt_hevc_debug_set_backend(C.cast(backend, C.c_void_p))
+    try:
+        imcvt_amd.hevc.coalesce_stats(reset=True)
+        results = {}
+
+        def call(t):
+            img = np.full(64, t, np.uint8); out = np.zeros(16, np.uint8); rc = np.zeros(16, np.uint8)
+            ys, xs = C.c_int(8), C.c_int(8)
+            n = lib.HEVCImageEncoder(out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), rc.ctypes.data_as(u8p), C.byref(ys), C.byref(xs), t % 5)
+            results[t] = (n, int(out[0]), int(rc[0]), ys.value, xs.value)
+
+        th = [threading.Thread(target=call, args=(t,)) for t in range(16)]
+        for t in th: t.start()
+        for t in th: t.join()
+        for t in range(16):
+            assert results[t] == (100 + t + t % 5, t, t ^ 0xFF, 1008, 2008), (t, results[t])
+        calls, batches, biggest = imcvt_amd.hevc.coalesce_stats()
+        assert calls == 16 and sum(seen) == 16 and batches == len(seen)
+        assert batches <= 4 and biggest >= 8, (seen, batches, biggest)      # one or two rounds in practice: the first few callers, then everyone who arrived meanwhile
+        # an error of the batch reaches every caller of that batch; bad arguments never reach the queue
+        assert lib.HEVCImageEncoder(None, None, None, None, None, 0) == -3
+        assert imcvt_amd.hevc.coalesce_stats()[0] == 16
+        # a multi-frame call is one submission
+        imgs = [np.full(64, 40 + i, np.uint8) for i in range(3)]; outs = [np.zeros(16, np.uint8) for _ in range(3)]; rcs = [np.zeros(16, np.uint8) for _ in range(3)]
+        P = u8p * 3
+        ys = (C.c_int * 3)(8, 8, 8); xs = (C.c_int * 3)(8, 8, 8); qv = (C.c_int * 3)(0, 1, 2); lens = (C.c_int * 3)()
+        assert lib.HEVCImageEncoderBatch(3, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]), P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, qv, lens) == 0
+        assert list(lens) == [140, 142, 144] and seen[-1] == 3
+    finally:
+        lib.imcvt_hevc_debug_set_backend(None)
