@@ -58,7 +58,6 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_ld_i32(const i32 *p) { return *(const volatile i32 *)p; }
   HD void lds_st_i32(i32 *p, i32 v) { *(volatile i32 *)p = v; }
   HD void pipe_pause() { emu_yield(); }
-  HD void pipe_pause_long() { emu_yield(); }
   static int emu_pipe_on();
   HD int wg_has_pipe_wave() { return emu_pipe_on(); }
   HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
@@ -111,9 +110,6 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_ld_i32(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   HD void lds_st_i32(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   HD void pipe_pause() { __builtin_amdgcn_s_sleep(2); }
-  // the same wait in a launch that fills the device: the waiting wave shares its SIMD with waves that have work, and a poll every
-  // ~130 cycles costs them issue slots (the four-TU wave of an 8x8 CU waits ~16 k instruction-times for the PU wave: thousands of polls)
-  HD void pipe_pause_long() { __builtin_amdgcn_s_sleep(48); }
   HD int wg_has_pipe_wave() { return blockDim.x > (unsigned)WG_THREADS; }
 #endif
 
@@ -276,8 +272,7 @@ HD Arith unpack_arith(const FinState &f) {
 struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
 #define LSTRIDE_DW 33       // dwords per lane row of the lane-private token staging (LSTRIDE below)
 #define P1_RES_BYTES 2304   // 16 tiles of 8x8 + 4 or 4 tiles of 16x16 + 16 i16 (padded against LDS bank conflicts), 16-byte multiple
-#define NCODER (NMODE + 1)   // trial coders of a wave: the 35 candidates of its set and, on the four-TU wave of an 8x8 CU, the NxN trial as a 36th stream (hevc_frame.h eval_2Nx2N)
-#define W2_PAD (((NCODER * CTX_STRIDE + 15) & ~15) + ((NCODER * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
+#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
 struct alignas(16) WaveMem {
     Border  bsh;                 // border shared by all modes of a block
     i32 tokn[NMODE + 1];         // tokens written so far to each candidate's stream (slot NMODE: the NxN stream)
@@ -291,7 +286,7 @@ struct alignas(16) WaveMem {
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
         struct { i16 res[P1_RES_BYTES / 2]; i32 tmp[(7168 - P1_RES_BYTES) / 4]; } p1;                    // one pipeline pass: residual / dequantised tiles, stage outputs (tile strides: p1_run_t)
         u32 raw[1792];                                                                                // per-lane token staging (4x4 blocks, CU headers): lane l at raw + 33 l
-        struct { u8 cx[NCODER][CTX_STRIDE]; alignas(16) LaneMem lm[NCODER]; } p2;                        // trial coders: context copies, byte rings + lead queues
+        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
     } u;
 };
@@ -445,7 +440,6 @@ struct alignas(16) Shm {
     i32 pipe_a, pipe_b;          // PU wave -> pipe wave: the winners of PUs 0..2 / of PU 3 are in place (cleared by the pipe wave)
     i32 nxn_lane;                // pipe wave: the lane that holds the NxN trial's result (= PU 3's mode)
     i32 pu0_ready, pu0_taken;    // 8x8 CU: the PU wave's pass over PU 0 is complete / the four-TU wave has taken its copy (hevc_frame.h tu0_from_pu0)
-    i32 nxn_ready, nxn_n;        // 8x8 CU without a pipe wave: the PU wave has assembled the NxN stream (nxn_n tokens) — the four-TU wave codes it beside its 35 candidates
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
 #endif
@@ -469,7 +463,7 @@ __shared__ Shm g_shm;
 #endif
 #define WM(w) (*(WaveMem *)(SM.wraw + (w) * sizeof(WaveMem)))
 // The pipe wave's slice (a WaveMem cut off after the trial coders' extent) is dynamic LDS: only 256-thread launches pay for it.
-#define PIPE_UNION_BYTES 5248
+#define PIPE_UNION_BYTES 5120
 #define PIPE_LDS_BYTES ((sizeof(WaveMem) - 7168 + PIPE_UNION_BYTES + 15) & ~(size_t)15)
 static_assert(NMODE * LSTRIDE_DW * 4 <= PIPE_UNION_BYTES && W2_PAD <= PIPE_UNION_BYTES, "the pipe wave's slice holds 35 token rows / the trial coders");
 static_assert(W2_PAD + NMODE * 16 <= 7168, "the PU candidates' reconstructions lie beside the trial coders in the pass buffer");

@@ -63,7 +63,7 @@ HDN void tu0_from_pu0(int wave_, u16 *tok1_) {          // (out of line: inlined
     WaveMem &W = WM(wave);
     const WaveMem &W2 = WM(2);
     const u16 *tok2 = wave_tok(F.sc, 2);
-    if (F.pipe) { while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause(); } else { while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause_long(); }
+    while (lds_ld_i32(&SM.pu0_ready) == 0) pipe_pause();
     wave_sync();
     LANES(l) {
         if (l < NMODE) {
@@ -162,35 +162,17 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 #ifndef IMCVT_HOSTEMU
     if (big) { if (F.prio_base) SETPRIO(3); else SETPRIO(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
 #endif
-    // The four-TU wave of an 8x8 CU also codes the NxN trial (:1530-1543), as a 36th stream beside its 35 candidates: same entry state
-    // (the CU's), about the same length — a lane that would idle instead of a whole wave pass with ONE live lane on the PU wave (9 % of
-    // all vector instructions of a full device).  Launches with a pipe wave price the NxN CU there (nxn_pipe).
-    const int host = !big && wave == 1 && !F.pipe;
-    int nxn_n = 0;
-    if (host) {
-        while (lds_ld_i32(&SM.nxn_ready) == 0) pipe_pause_long();      // (only launches without a pipe wave come here: throughput shapes)
-        wave_sync();                                    // (the PU wave drained its token stores before it raised the flag)
-        nxn_n = SM.nxn_n;
-    }
     LANES(l) {
-        const int on = l < NMODE + host, ll = on ? l : 0, guest = host && l == NMODE;
+        const int on = l < NMODE, ll = on ? l : 0;
         Arith a = SM.entry_a[depth];
         const int len0 = arith_len(a);
-        const u16 *stream = guest ? wave_tok(F.sc, 2) + (size_t)NMODE * TOK_CAP : tok + (size_t)ll * TOK_CAP;
-        u8 *gbuf = guest ? ubytes + (size_t)(2 * NMODE) * TRIAL_BYTES : ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES;      // the NxN trial's bytes: the PU wave's block, lane 0
-        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], &W.u.p2.lm[ll], gbuf, stream, guest ? nxn_n : W.tokn[ll], on);
-        if (on && !guest) {
+        run_trial(a, SM.entry_cx[depth], W.u.p2.cx[ll], &W.u.p2.lm[ll], ubytes + (size_t)(wave * NMODE + ll) * TRIAL_BYTES, tok + (size_t)ll * TOK_CAP, W.tokn[ll], on);
+        if (on) {
             W.fin[l] = pack_arith(a);
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
 #ifdef IMCVT_TOKSTAT
             fprintf(stderr, "TS %d %d %d %d %d %d %d %d\n", N, wave, l, W.tokn[l], W.cost[l], W.sse[l], arith_len(a) - len0, (N > 8) ? SM.split_cost[depth] : -1);
 #endif
-        }
-        if (guest) {
-            WaveMem &W2 = WM(2);
-            W2.fin[0] = pack_arith(a);
-            W2.nxn_cost = rd_cost(rw, W2.pu_sse[0] + W2.pu_sse[1] + W2.pu_sse[2] + W2.pu_sse[3], arith_len(a) - len0);
-            lds_st_i32(&SM.nxn_ready, 0);               // (the PU wave raises it again only after the workgroup barrier that ends this CU)
         }
     }
     wave_sync();
@@ -226,7 +208,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
         if (TU0_SHARE && k == 1) {                      // the four-TU wave has its copy of PU 0's pass (long ago: it takes it while this wave prices PU 0)
-            if (pipe) { while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause(); } else { while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause_long(); }
+            while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause();
             wave_sync_lds();
             LANES(l) { if (l == 0) { lds_st_i32(&SM.pu0_ready, 0); lds_st_i32(&SM.pu0_taken, 0); } }
         }
@@ -322,9 +304,18 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         if (l < 8 && ((pos + l) >> 3) == (pos >> 3) && (pos & 7) != 0) g_st16((i16 *)(nxn + pos + l), (int)TOK_IDLE);   // idle tokens up to the block boundary
         wave_sync();                                    // the stream is in memory
         prof_add(PF_P2_32, ptn);
-        if (l == 0) { SM.nxn_n = pos; lds_st_i32(&SM.nxn_ready, 1); }      // the four-TU wave codes it beside its 35 candidates (eval_2Nx2N) and leaves the result in this wave's fin[0] / nxn_cost
+        const long long ptt = prof_now();
+        const int on = l == 0;
+        Arith a = SM.entry_a[2];
+        const int len0 = arith_len(a);
+        run_trial(a, SM.entry_cx[2], W.u.p2.cx[0], &W.u.p2.lm[0], ubytes + (size_t)(wave * NMODE) * TRIAL_BYTES, nxn, pos, on);
+        if (on) {
+            W.fin[0] = pack_arith(a);
+            W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);
+        }
+        prof_add(PF_P2_16, ptt);
     }
-    wave_sync_lds();
+    wave_sync();
     prof_add(PF_P2_NXN, ptn);
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(2); else SETPRIO(0);
@@ -483,18 +474,14 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     const int kind = SM.win_kind, mode = SM.win_mode;
     if (kind != 0) {
         const int pk = (kind == 3) && F.pipe;             // the NxN trial ran on the pipe wave: its result sits in that wave's slice, lane nxn_lane
-        // where the winning trial left its results — ww / wl: bytes (Scratch.bytes block and lane); WW.fin[fl]: final coder state; CW.u.p2.cx[cl]: contexts.
-        // Without a pipe wave the NxN trial is the four-TU wave's 36th coder (eval_2Nx2N): bytes and state in the PU wave's places, contexts in ITS row.
         const int ww = pk ? PIPE_WAVE : (kind == 3) ? 2 : kind - 1, wl = pk ? SM.nxn_lane : (kind == 3) ? 0 : mode, fl = pk ? 0 : wl;
         const WaveMem &WW = pk ? PM : WM(ww);
-        const WaveMem &CW = (kind == 3 && !pk) ? WM(1) : WW;
-        const int cl = (kind == 3 && !pk) ? NMODE : wl;
         const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WW.fin[fl].w2 >> 16);
         const u8 *src = lane_bytes(F.sc, ww, wl);
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
             for (int i = tid; i < cnt1 - cnt0; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(src + i));
-            if (tid < CTX_STRIDE) SM.cx[tid] = CW.u.p2.cx[cl][tid];
+            if (tid < CTX_STRIDE) SM.cx[tid] = WW.u.p2.cx[wl][tid];
             if (tid == 64) SM.live = unpack_arith(WW.fin[fl]);
             if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445, :1549-1553)
                 const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
@@ -1123,7 +1110,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; SM.nxn_ready = 0; SM.nxn_n = 0; } }      // (read after the barriers below)
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;

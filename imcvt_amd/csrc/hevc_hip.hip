@@ -166,19 +166,26 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     // ROCr sizes the private-segment ring from the dispatches it has seen: the first full-grid launches of a process run
     // with fewer resident waves (measured: 1.6x the steady kernel time, twice).  Three empty full-grid launches (no frames:
     // every workgroup leaves at once) bring the ring to size before real work arrives.
-    if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
-        for (int i = 0; i < 3 && ok; i++) {
-            ok = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;
-            if (ok) launch(c, c->max_wg, 0, 0, 1, 0, 0);
-            ok = ok && hipDeviceSynchronize() == hipSuccess;
+    auto prewarm = [&]() {
+        bool good = true;
+        for (int i = 0; i < 3 && good; i++) {
+            good = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;
+            if (good) launch(c, c->max_wg, 0, 0, 1, 0, 0);
+            good = good && hipDeviceSynchronize() == hipSuccess;
         }
-        if (!ok) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
+        return good;
+    };
+    if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
+        if (!prewarm()) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
         // census: a launch of max_wg (pipe_wg) workgroups that only count themselves — what is resident at once is what the plans may use
         if (max_workgroups <= 0 && !getenv("IMCVT_HEVC_NO_CENSUS")) {
-            c->census_wg = census(c, c->max_wg, 0); c->census_pipe = census(c, c->pipe_wg, 1);
+            c->census_pipe = census(c, c->pipe_wg, 1); c->census_wg = census(c, c->max_wg, 0);
             if (c->census_wg > 0 && c->census_wg < c->max_wg) { fprintf(stderr, "imcvt_hevc: %d of %d workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_wg, c->max_wg, c->occ_wg, c->census_wg); c->max_wg = c->census_wg; }
             if (c->census_pipe > 0 && c->census_pipe < c->pipe_wg) { fprintf(stderr, "imcvt_hevc: %d of %d pipe-wave workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_pipe, c->pipe_wg, c->occ_pipe, c->census_pipe); c->pipe_wg = c->census_pipe; }
             if (c->pipe_wg > c->max_wg) c->pipe_wg = c->max_wg;
+            // (the 256-thread census launch left the SECOND full 192-thread launch after it with ~940 of 1000 workgroups resident,
+            // profiles/r04c_census_probe.log: the last launches the runtime sees before real work are full 192-thread ones again)
+            if (!prewarm()) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
         }
     }
     return c;
