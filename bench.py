@@ -357,6 +357,20 @@ def jls_view(dev):
     from oracle import oracle                                  # (checker leg, like cpu_baseline)
     t = time.perf_counter(); oracle.jls_cpu_encode(img, 0); cs = time.perf_counter() - t
     out["cpu_1core"] = {"seconds": round(cs, 3), "mpx_s": round(W * H / cs / 1e6, 2), "kind": "reference" if oracle.jls_have_ref() else "port"}
+    # near-lossless (NEAR = 2): the neighbourhood of a pixel is made of RECONSTRUCTED samples, which depend on the coded errors and
+    # through them on the adaptive context state in raster order (src/imageio_jls.c:325,361) — one plane is one serial chain, walked by
+    # one lane; the device's answer is many planes at once.  Both ends, with the CPU checker's one-core time for the same plane.
+    for name, n in (("near2_1_plane", 1), ("near2_64_planes", 64)):
+        d = jls.DevicePlanes([torch.from_numpy(img).to(dev) for _ in range(n)], 2)
+        d.encode(); torch.cuda.synchronize(); ms = d.last_kernel_ms()
+        res = d.results()
+        if name == "near2_1_plane":
+            t = time.perf_counter(); want = oracle.jls_cpu_encode(img, 2); cs2 = time.perf_counter() - t
+        if res[0] != want or res[-1] != want:
+            raise SystemExit(f"jls_view {name}: stream differs from the CPU checker")
+        out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(n * W * H / ms / 1e3, 2), "bytes_per_plane": len(res[0]), "bytes_equal_to_cpu_checker": True,
+                     "path": "planes spread over the device" if d.last_path() == 1 else "one walker per plane"}
+    out["near2_cpu_1core"] = {"seconds": round(cs2, 3), "mpx_s": round(W * H / cs2 / 1e6, 2)}
     return out
 
 

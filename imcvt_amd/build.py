@@ -27,11 +27,36 @@ def _run_to(cmd, out):
 KERNEL_FLAGS = ["-mllvm", "-disable-machine-licm"]
 
 
+def _source_hash(deps, flags) -> str:
+    """sha256 over the sources a library is built from and the flags it is built with."""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for d in deps:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _stamp(out: str) -> str:
+    return out + ".srchash"          # travels with the library (git-ignored like it)
+
+
+def _is_current(out, deps, flags) -> bool:
+    """The library exists and was built from exactly these sources with exactly these flags (content, not modification times:
+    a prebuilt library that travelled to another machine is rebuilt there only if what it was built from differs)."""
+    try:
+        return os.path.exists(out) and open(_stamp(out)).read().strip() == _source_hash(deps, flags)
+    except OSError:
+        return False
+
+
+def _write_stamp(out, deps, flags):
+    with open(_stamp(out), "w") as f:
+        f.write(_source_hash(deps, flags) + "\n")
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    return os.path.getmtime(os.path.abspath(__file__)) > t or any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)      # (this file holds the compiler flags)
+    return not _is_current(OUT, DEPS, KERNEL_FLAGS)
 
 
 JLS_OUT = os.path.join(CSRC, "libimcvt_jls.so")   # JPEG-LS (BASELINE config 5)
@@ -39,10 +64,11 @@ JLS_DEPS = ["jls_hip.hip", "jls_core.h", "jls_par.h", os.path.join("..", "..", "
 
 
 def build_jls(force: bool = False) -> str:
-    if force or not os.path.exists(JLS_OUT) or any(os.path.getmtime(os.path.join(CSRC, d)) > os.path.getmtime(JLS_OUT) for d in JLS_DEPS):
+    if force or not _is_current(JLS_OUT, JLS_DEPS, []):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run_to([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                  os.path.join(CSRC, "jls_hip.hip")], JLS_OUT)
+        _write_stamp(JLS_OUT, JLS_DEPS, [])
     return JLS_OUT
 
 
@@ -75,6 +101,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     _run_to(cmd, OUT)
+    _write_stamp(OUT, DEPS, KERNEL_FLAGS)
     build_host(force=True)
     return OUT
 
