@@ -1,8 +1,8 @@
 #!/bin/bash
-# Final measurement pass of round 3 on one box: counters on the bench workload (-> profiles/pmc_*.json, which bench.py reads), the bench line,
+# Final measurement pass of a round on one box: counters on the bench workload (-> profiles/pmc_*.json, which bench.py reads), the bench line,
 # the same command under rocprofv3 --kernel-trace --stats, JPEG-LS timings, scale prediction.   usage: tools/gpu_final.sh TAG   (on the GPU box: gpurun -- tools/gpu_final.sh r03z)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out; TAG=${1:-r03zx}
+O=gpurun_out; TAG=${1:-r04z}
 bash tools/gpu_pmc.sh ${TAG} 1920 1080 512 0 > $O/${TAG}_pmc.log 2>&1; tail -3 $O/${TAG}_pmc.log
 python tools/pmc_issue.py $O/${TAG}_pmc_sq.txt 512 1920 1080 0 "the bench's launch shape: 512 main + 448 helper workgroups" > $O/${TAG}_pmc_issue.json; cat $O/${TAG}_pmc_issue.json
 cp $O/${TAG}_pmc_issue.json profiles/pmc_issue.json; cp $O/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
