@@ -190,7 +190,7 @@ int imcvt_hevc_debug_filler(int grid, int lds_bytes, int ms, void *stream);
 void imcvt_hevc_debug_set_backend(void *fn);
 void imcvt_hevc_coalesce_stats(long *calls, long *batches, long *max_batch, int reset);
 
-/* Library / build information, e.g. "imcvt_hevc gfx950 r3 ...". */
+/* Library / build information, e.g. "imcvt_hevc gfx950 r4 ...". */
 const char *imcvt_hevc_version(void);
 
 #ifdef __cplusplus
