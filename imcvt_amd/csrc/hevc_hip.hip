@@ -620,9 +620,15 @@ extern "C" void imcvt_hevc_coalesce_stats(long *calls, long *batches, long *max_
     if (max_batch) *max_batch = g_q_max_batch;
     if (reset) { g_q_calls = 0; g_q_batches = 0; g_q_max_batch = 0; }
 }
+static std::chrono::steady_clock::time_point g_last_crowd;           // when callers were last seen arriving together
 static void lead_one_round(std::unique_lock<std::mutex> &lk) {       // called with the queue locked and g_leader == true; returns the same way
+    // The window is only worth its 300 us when callers do arrive together: a second submission is already waiting, or a round of the
+    // last 100 ms carried more than one.  A lone caller (the reference's serial file loop) goes straight through.
     const int win = coalesce_window_us();
-    if (win > 0) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(win)); lk.lock(); }
+    const auto now = std::chrono::steady_clock::now();
+    const bool crowd = g_pending.size() > 1 || (g_last_crowd.time_since_epoch().count() != 0 && now - g_last_crowd < std::chrono::milliseconds(100));
+    if (win > 0 && crowd) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(win)); lk.lock(); }
+    if (g_pending.size() > 1) g_last_crowd = std::chrono::steady_clock::now();
     std::vector<Submission *> take; take.swap(g_pending);
     const batch_backend_t backend = g_backend;
     lk.unlock();

@@ -59,8 +59,9 @@ int writeHEVCImageFile(const char *p_filename, const uint8_t *p_buf, int is_rgb,
  * Environment: IMCVT_HEVC_DEVICES=k limits the fan-out to the first k devices; IMCVT_HEVC_FAKE_DEVICES=k (test seam) runs the
  * fan-out with k logical devices that all sit on physical device 0, each with its own context, stream and slab.
  * Concurrent callers: calls that arrive within a short window (IMCVT_HEVC_COALESCE_US, default 300 us) or while the previous
- * batch is running are merged into ONE device batch — the first caller waits the window, takes everything submitted so far,
- * runs it and hands every caller its results; 16 threads with a frame each cost about one frame's time, not sixteen.
+ * batch is running are merged into ONE device batch — the first caller waits the window (only when callers have been seen
+ * arriving together in the last 100 ms: a lone caller is not delayed), takes everything submitted so far, runs it and hands
+ * every caller its results; 16 threads with a frame each cost about one or two frames' time, not sixteen.
  * Returns 0, or a negative IMCVT_ERR_*.   */
 int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs,
                           unsigned char *const *rcons, int *ysz, int *xsz, const int *qpd6, int *out_len);
