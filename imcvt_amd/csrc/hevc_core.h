@@ -2208,3 +2208,56 @@ HD void run_trial_r(Arith &a, const u8 *cx_fresh, u8 *cx, LaneMem *lm, u8 *gbuf,
         stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// One stream coded on WAVE-UNIFORM values (the NxN trial of an 8x8 CU in launches without a pipe wave: one stream, nobody to
+// share a wavefront with).  As lane code it is a whole pass of 72 vector instructions per token with one live lane — 9 % of the
+// vector instructions of a full device — on the wave every other wave of the workgroup is waiting for.  Here every lane carries
+// the same coder state and every loaded value is declared uniform (readfirstlane), so the arithmetic, the branches (plain
+// code_token / carry_out: no need for the branch-free form) and the byte-level logic run on the SCALAR unit, which the other
+// wavefronts of the SIMD are not queueing for; the vector pipe sees the loads, their readfirstlanes and the stores of lane 0.
+// Same bins, same order, same arithmetic as :858-932.
+// ---------------------------------------------------------------------------------------------------
+#ifdef IMCVT_HOSTEMU
+#define UNI(x) (x)
+#define UNI_RUN(l) ((l) == 0)        // (the emulation's lanes are fibers that do not run in lock-step: one of them walks the stream)
+#define UNI_STORE(l) 1
+#else
+#define UNI(x) ((int)__builtin_amdgcn_readfirstlane((int)(x)))
+#define UNI_RUN(l) 1
+#define UNI_STORE(l) ((l) == 0)
+#endif
+struct UniSink { u8 *base; u32 off; int st; };            // as Sink; st: this lane performs the stores
+HD void sink_put(UniSink &s, int i, int v) { if (s.st) g_st8(s.base + (u32)(s.off + (u32)i), v); }
+HD int sink_room(UniSink &, int) { return 1; }
+HD void code_token_uni(Arith &a, u8 *cx, UniSink &sink, u32 tok) {
+    if (tok & 0x8000u) {                                                            // bypass chunk, :898-910
+        const int nb_ = (int)((tok >> 8) & 15u);
+        a.low = (a.low << nb_) + a.range * (int)(tok & 255u);
+        a.nbits -= nb_;
+    } else {                                                                        // context-coded bin, :913-932
+        const int ci = (int)(tok >> 8), bin = (int)(tok & 1u);
+        const int pz = UNI(cx[ci]);
+        const int ex = UNI(SM.T.pst[pz].x), ey = UNI(SM.T.pst[pz].y);
+        const int lps = (int)(((u32)ex >> (((a.range >> 6) & 3) * 8)) & 0xFF);
+        const int rm = a.range - lps;
+        const int is_lps = (bin ^ pz) & 1;
+        const int sh = is_lps ? imin(6, clz32((u32)lps) - 23) : (rm < 256);
+        if (sink.st) cx[ci] = (u8)(is_lps ? ey : ey >> 8);
+        a.low = (a.low + (is_lps ? rm : 0)) << sh;
+        a.range = (is_lps ? lps : rm) << sh;
+        a.nbits -= sh;
+    }
+    carry_out(a, sink);
+}
+// p: 16-byte aligned, padded to a token block with idle tokens.  Wave collective; every lane ends with the same coder state.
+HD void stream_run_uni(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n, int lane) {
+    UniSink sink; sink.base = gbuf; sink.off = (u32)(0 - a.cnt); sink.st = UNI_STORE(lane);
+    NOUNROLL
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        const U4 b = g_ld128(p + k0);
+        const u32 w[4] = { (u32)UNI(b.x), (u32)UNI(b.y), (u32)UNI(b.z), (u32)UNI(b.w) };
+        for (int j = 0; j < 8; j++) code_token_uni(a, cx, sink, (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu));
+    }
+}
+

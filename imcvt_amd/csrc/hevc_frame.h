@@ -55,6 +55,9 @@ struct P1Item { int own, shape, lo, hi; };
 #ifndef TU0_SHARE
 #define TU0_SHARE 1
 #endif
+#ifndef NXN_UNI
+#define NXN_UNI 1         // launches without a pipe wave: the NxN trial of an 8x8 CU runs on wave-uniform values, i.e. on the scalar unit (hevc_core.h stream_run_uni)
+#endif
 #ifndef PU_HINTS
 #define PU_HINTS 1        // launches with a pipe wave: the PU candidates of an 8x8 CU carry state hints and are priced without context copies
 #endif
@@ -305,6 +308,22 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         wave_sync();                                    // the stream is in memory
         prof_add(PF_P2_32, ptn);
         const long long ptt = prof_now();
+#if NXN_UNI
+        // the trial on wave-uniform values (stream_run_uni): the scalar unit walks the stream, lane 0 stores
+        if (l < CTX_STRIDE / 4) *(u32a *)(W.u.p2.cx[0] + 4 * l) = *(const u32a *)(SM.entry_cx[2] + 4 * l);
+        wave_sync_lds();
+        if (UNI_RUN(l)) {
+            Arith a;
+            a.range = UNI(SM.entry_a[2].range); a.low = UNI(SM.entry_a[2].low); a.nbits = UNI(SM.entry_a[2].nbits); a.nbytes = UNI(SM.entry_a[2].nbytes);
+            a.bufbyte = UNI(SM.entry_a[2].bufbyte); a.zeros = UNI(SM.entry_a[2].zeros); a.cnt = UNI(SM.entry_a[2].cnt);
+            const int len0 = arith_len(a);
+            stream_run_uni(a, W.u.p2.cx[0], ubytes + (size_t)(wave * NMODE) * TRIAL_BYTES, nxn, UNI(pos), l);
+            if (l == 0) {
+                W.fin[0] = pack_arith(a);
+                W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);
+            }
+        }
+#else
         const int on = l == 0;
         Arith a = SM.entry_a[2];
         const int len0 = arith_len(a);
@@ -313,6 +332,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             W.fin[0] = pack_arith(a);
             W.nxn_cost = rd_cost(rw, W.pu_sse[0] + W.pu_sse[1] + W.pu_sse[2] + W.pu_sse[3], arith_len(a) - len0);
         }
+#endif
         prof_add(PF_P2_16, ptt);
     }
     wave_sync();
