@@ -634,13 +634,18 @@ static void lead_one_round(std::unique_lock<std::mutex> &lk) {       // called w
     lk.unlock();
     size_t total = 0;
     for (const Submission *u : take) total += (size_t)u->n;
-    std::vector<unsigned char *> pb(total), rc_(total); std::vector<const unsigned char *> im(total);
-    std::vector<int> ys(total), xs(total), q(total), len(total, 0);
-    size_t k = 0;
-    for (const Submission *u : take) for (int i = 0; i < u->n; i++, k++) { pb[k] = u->pbuffers[i]; im[k] = u->imgs[i]; rc_[k] = u->rcons[i]; ys[k] = u->ysz[i]; xs[k] = u->xsz[i]; q[k] = u->qpd6[i]; }
-    const int rc = total ? backend((int)total, pb.data(), im.data(), rc_.data(), ys.data(), xs.data(), q.data(), len.data()) : 0;
-    k = 0;
-    for (Submission *u : take) { for (int i = 0; i < u->n; i++, k++) if (rc == 0) { u->ysz[i] = ys[k]; u->xsz[i] = xs[k]; u->out_len[i] = len[k]; } u->rc = rc; }
+    try {                                               // (whatever happens in here, every caller of this round is released with a return code)
+        std::vector<unsigned char *> pb(total), rc_(total); std::vector<const unsigned char *> im(total);
+        std::vector<int> ys(total), xs(total), q(total), len(total, 0);
+        size_t k = 0;
+        for (const Submission *u : take) for (int i = 0; i < u->n; i++, k++) { pb[k] = u->pbuffers[i]; im[k] = u->imgs[i]; rc_[k] = u->rcons[i]; ys[k] = u->ysz[i]; xs[k] = u->xsz[i]; q[k] = u->qpd6[i]; }
+        const int rc = total ? backend((int)total, pb.data(), im.data(), rc_.data(), ys.data(), xs.data(), q.data(), len.data()) : 0;
+        k = 0;
+        for (Submission *u : take) { for (int i = 0; i < u->n; i++, k++) if (rc == 0) { u->ysz[i] = ys[k]; u->xsz[i] = xs[k]; u->out_len[i] = len[k]; } u->rc = rc; }
+    } catch (...) {
+        fprintf(stderr, "imcvt_hevc: out of host memory while merging %zu frames of %zu callers\n", total, take.size());
+        for (Submission *u : take) u->rc = IMCVT_ERR_HIP;
+    }
     lk.lock();
     g_q_batches++; if ((long)total > g_q_max_batch) g_q_max_batch = (long)total;
     for (Submission *u : take) u->done = true;
