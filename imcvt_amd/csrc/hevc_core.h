@@ -268,6 +268,9 @@ HD Arith unpack_arith(const FinState &f) {
 #ifndef RING_BYTES
 #define RING_BYTES 32      // per-lane byte ring of the trial coders (RingSink)
 #endif
+#ifndef DRAIN_REGS
+#define DRAIN_REGS 1
+#endif
 #define LEADQ 10           // per-lane queue of byte leads: at most one per token of an 8-token block, plus the slot the idle write lands in
 struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
 #define LSTRIDE_DW 33       // dwords per lane row of the lane-private token staging (LSTRIDE below)
@@ -2131,10 +2134,20 @@ HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p
             MARK("p2_eight_tokens");
             prof_add(PF_T_NTOK, tp1); prof_cnt(PF_BORDER, 1);
             const long long tp2 = prof_now();
+#if DRAIN_REGS
+            u32 lqw[4];                                     // the block's (at most 8) queued leads, read once: the loop below then has no LDS read to wait for
+            for (int d = 0; d < 4; d++) lqw[d] = *(const u32a *)&lm->lq[2 * d];
+            UNROLL_FULL
+            for (int i = 0; i < 8; i++) {
+                if (!WAVE_ANY(i < qn)) break;
+                const int act = i < qn;
+                const int lead = (int)((i & 1) ? lqw[i >> 1] >> 16 : lqw[i >> 1] & 0xFFFFu);
+#else
             NOUNROLL
             for (int i = 0; WAVE_ANY(i < qn); i++) {        // the bytes this block pushed out of `low` (:863-878): the common case is
                 const int act = i < qn;                     // straight-line (one byte buffered, no 0xFF run, no emulation prevention)
                 const int lead = (int)lm->lq[i];
+#endif
                 const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
                 const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
                 u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : (u8 *)&lm->lq[LEADQ - 1];
