@@ -1172,15 +1172,17 @@ template <int S, bool PRIV, bool HINT = false>      // HINT: fresh contexts, eac
 HD int last_pos_emit(const TokOut &o, int cnt, const LastPos &p) {
     constexpr int gmax = 2 * (S + 2) - 1, shf = (S == 0) ? 0 : 1;
     static_assert(!HINT || S == 0, "state hints exist for the 4x4 PU candidates only");
+    int hx[gmax], hy[gmax];                              // (HINT: the table reads before the first store, see tokg_a_fast)
+    for (int i = 0; i < gmax; i++) { hx[i] = HINT ? SM.cx0[CX_LAST_X + p.cbase + (i >> shf)] : 0; hy[i] = HINT ? SM.cx0[CX_LAST_Y + p.cbase + (i >> shf)] : 0; }
     for (int i = 0; i < gmax; i++) {
         const int ci = CX_LAST_X + p.cbase + (i >> shf);
-        const int pr = i <= p.gx, tok = TK(ci, i < p.gx) | (HINT ? SM.cx0[ci] << 1 : 0);
+        const int pr = i <= p.gx, tok = TK(ci, i < p.gx) | hx[i] << 1;
         if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr);
         cnt += pr;
     }
     for (int i = 0; i < gmax; i++) {
         const int ci = CX_LAST_Y + p.cbase + (i >> shf);
-        const int pr = i <= p.gy, tok = TK(ci, i < p.gy) | (HINT ? SM.cx0[ci] << 1 : 0);
+        const int pr = i <= p.gy, tok = TK(ci, i < p.gy) | hy[i] << 1;
         if (PRIV) to_put(o, cnt, tok); else to_put_if(o, cnt, tok, pr);
         cnt += pr;
     }
@@ -1317,6 +1319,7 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
     const Tables &T = SM.T;
     const int dcg = (cfg & TG_DC) != 0, has_last = (cfg & TG_LAST) != 0, pat = (cfg >> TG_PAT) & 3, st = (cfg >> TG_ST) & 3;
     B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
+    const int gt2_hint = HINT ? SM.cx0[CX_GT2] : 0;      // (HINT: one DC group, greater-1 context set 0)
     tb[cnt] = (u16)TK(CX_CSBF + (pat != 0), nzm != 0);
     cnt += (!dcg && !has_last);
     if (nzm == 0 && !dcg) return cnt;
@@ -1326,23 +1329,31 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
         u32 tlo, thi = 0; int base;
         if (S == 0) { const u64 t = T.c4tab[st]; tlo = (u32)t; thi = (u32)(t >> 32); base = 0; }
         else { tlo = T.posadd[pat][st]; base = 9 + (S >= 2 ? 12 : 0) + ((S == 1 && st != 0) ? 6 : 0) + (dcg ? 0 : 3); }
-        u32 pv[4] = { 0, 0, 0, 0 };
-        if (HINT) for (int i = 0; i < 4; i++) pv[i] = T.c4prev[st][i];
+        // (all table reads of the hints come before the first token store: the compiler cannot move an LDS read above an LDS write it
+        // cannot tell apart, and a read per token between the stores would be a wait per token)
+        int hints[16];
+        if (HINT) {
+            u32 pv[4];
+            for (int i = 0; i < 4; i++) pv[i] = T.c4prev[st][i];
+            const u32 coded = nzm & ((2u << (top & 31)) - 1u) & (top >= 0 ? 0xFFFFu : 0u);      // the flags that are coded at all: positions 0 .. top
+            const u32 inrange = (top >= 0) ? ((2u << top) - 1u) : 0u;
+            UNROLL_FULL
+            for (int n = 15; n >= 0; n--) {
+                const int f = (int)(((n < 8 ? tlo : thi) >> (4 * (n & 7))) & 15);
+                const int pp = (int)((pv[n >> 2] >> (8 * (n & 3))) & 255), p1 = pp & 15, p2 = pp >> 4;      // coded earlier on the same context: p1 (nearest), p2 > p1; 0: none
+                const int k1 = (int)((inrange >> p1) & 1u) & (p1 != 0), k2 = (int)((inrange >> p2) & 1u) & (p2 != 0);
+                const int b1 = (int)((coded >> p1) & 1u) & k1, b2 = (int)((coded >> p2) & 1u) & k2;
+                hints[n] = SM.pu_sig[8 * f + k1 + b1 + 2 * (k2 + b2)];                               // 0 | 1 + b1 | 3 + 2 b2 + b1
+            }
+        }
         u16 *const lo = tb + cnt, *const hi = lo + top;
         UNROLL_FULL
         for (int n = 15; n >= 0; n--) {
             const int f = S == 0 ? (int)(((n < 8 ? tlo : thi) >> (4 * (n & 7))) & 15) : (int)((tlo >> (2 * n)) & 3);
             const int ci = (n == 0 && dcg) ? 0 : base + f;
-            int hint = 0;
-            if (HINT) {
-                const int pp = (int)((pv[n >> 2] >> (8 * (n & 3))) & 255), p1 = pp & 15, p2 = pp >> 4;      // coded earlier on the same context: p1 (nearest), p2 > p1; 0: none
-                const int k1 = (p1 != 0) & (p1 <= top), k2 = (p2 != 0) & (p2 <= top);
-                const int b1 = (int)((nzm >> p1) & 1), b2 = (int)((nzm >> p2) & 1);
-                hint = SM.pu_sig[8 * f + (k2 ? 3 + 2 * b2 + b1 : k1 ? 1 + b1 : 0)];
-            }
             u16 *p = hi - n;
             p = p < lo ? lo : p;
-            *p = (u16)(TK(CX_SIG + ci, (int)((nzm >> n) & 1)) | hint << 1);
+            *p = (u16)(TK(CX_SIG + ci, (int)((nzm >> n) & 1)) | (HINT ? hints[n] << 1 : 0));
         }
         cnt += top + 1 - ((top >= 0) & !(dcg | ((nzm >> 1) != 0)));
     }
@@ -1354,16 +1365,27 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
     {   // greater-1 flags of the first 8 non-zero levels
         const int K = TK(CX_GT1 + 4 * set, 0);
         u16 *const g0 = tb + cnt, *const gend = g0 + m8;
-        int seenbig = 0, hidx = 8;                          // hidx: 8 + (1 << bins coded on context 0 so far) - 1 + their pattern
+        int ghints[8];
+        if (HINT) {                                         // (as above: the eight table reads first)
+            u32 rem2 = nzs; int seen2 = 0, hidx = 8;        // hidx: 8 + (1 << bins coded on context 0 so far) - 1 + their pattern
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) {
+                const int p2 = 31 - clz_nz(rem2 | 1u);
+                const int bigj = (int)((bigs >> p2) & 1u);
+                ghints[j] = SM.pu_gt[seen2 ? hidx : j];
+                hidx = seen2 ? 2 * hidx - 7 + bigj : hidx;  // (8 + m) -> 8 + 2 m + 1 + bin
+                seen2 |= bigj;
+                rem2 &= (1u << p2) - 1u;
+            }
+        }
+        int seenbig = 0;
         UNROLL_FULL
         for (int j = 0; j < 8; j++) {
             const int p2 = 31 - clz_nz(rem | 1u);
             const int bigj = (int)((bigs >> p2) & 1u);
             u16 *p = g0 + j;
             p = p > gend ? gend : p;
-            int hint = 0;
-            if (HINT) { hint = SM.pu_gt[seenbig ? hidx : j]; hidx = seenbig ? 2 * hidx - 7 + bigj : hidx; }      // (8 + m) -> 8 + 2 m + 1 + bin
-            *p = (u16)(K + ((seenbig ? 0 : (j < 2 ? j + 1 : 3)) << 8) + (hint << 1) + bigj);
+            *p = (u16)(K + ((seenbig ? 0 : (j < 2 ? j + 1 : 3)) << 8) + (HINT ? ghints[j] << 1 : 0) + bigj);
             seenbig |= bigj;
             rem &= (1u << p2) - 1u;
         }
@@ -1372,7 +1394,7 @@ HD int tokg_a_fast(u16 *tb, int cnt, const Lv16 &L, u32 nzm, u32 P, int cfg, TgB
     const u32 big8 = bigs & (nzs ^ rem);                  // levels above 1 among the first 8 non-zero ones
     const int anybig = big8 != 0, fb = 31 - clz_nz(big8 | 1u);
     const int g2 = (int)((g2s >> fb) & 1u) & anybig;     // greater-2 flag of the first of them (:1232-1238)
-    tb[cnt] = (u16)(TK(CX_GT2 + set, g2) | (HINT ? SM.cx0[CX_GT2 + set] << 1 : 0));
+    tb[cnt] = (u16)(TK(CX_GT2 + set, g2) | (HINT ? gt2_hint << 1 : 0));
     cnt += anybig;
     int signs = 0;
     UNROLL_FULL
@@ -1592,13 +1614,17 @@ HD void p1_run_4(int wave, const P1Args &P) {
             } else {
                 for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) x[i][j] = 0;   // all-zero levels reconstruct to the prediction
             }
+            u32 oww[4];                                     // (the source rows are read before the first store below: an LDS read behind an LDS write waits for it)
+            for (int yi = 0; yi < 4; yi++) oww[yi] = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
             for (int yi = 0; yi < 4; yi++) {
-                const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
+                const u32 ow = oww[yi];
+                u32 rw4 = 0;
                 for (int xi = 0; xi < 4; xi++) {
                     const int rc = clip3(x[yi][xi] + pr[yi][xi], 0, 255);
                     const int d = (int)((ow >> (8 * xi)) & 255) - rc;
                     part += d * d;
-                    if (P.out_kind == OUT_REC4) W.u.w2.rec4[c][yi * 4 + xi] = (u8)rc;
+                    rw4 |= (u32)rc << (8 * xi);
+                    if (P.out_kind == OUT_REC4) { if (xi == 3) *(u32a *)&W.u.w2.rec4[c][yi * 4] = rw4; }
                     else if (P.out_kind == OUT_TILE) SM.rec[P.y0 + yi + 1][P.x0 + xi + 1] = (u8)rc;
                     else if (P.out_kind == OUT_T3SIDE) {
                         if (P.k < 3 && yi == 3) SM.X.t3row[c][P.k][xi] = (u8)rc;

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 L=$O/${TAG}_variants.log; : > $L
 i=0; LIBS=()
 for v in "$@"; do
-  if [ "$v" = "BASE" ]; then LIBS+=("$R/tools/_ab/libimcvt_hevc_base.so"); else
+  if [ "$v" = "BASE" ]; then LIBS+=("${BASE_LIB:-$R/tools/_ab/libimcvt_hevc_base.so}"); else
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -disable-machine-licm $v imcvt_amd/csrc/hevc_hip.hip -o $O/libv$i.so 2> $O/${TAG}_v$i.build.log || echo "variant $i build failed" >> $L
     LIBS+=("$O/libv$i.so"); fi
   i=$((i+1))
