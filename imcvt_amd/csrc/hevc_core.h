@@ -796,7 +796,7 @@ HDN_BFT void border_from_tile(int wave_, int N_, int y0_, int x0_, int hl_, int 
         if (l == 0) {
             int dc = N;
             for (int i = 0; i < N; i++) dc += b.ul[i] + b.ua[i];
-            b.dc = (i16)(dc / (2 * N));
+            b.dc = (i16)(dc >> (hibit((u32)N) + 1));                   // dc / 2N (N is a power of two, dc is not negative; a shift, not a division sequence)
             b.fc = (u8)((2 + b.ul[0] + b.ua[0] + 2 * b.uc) >> 2);
         }
     }
@@ -831,13 +831,13 @@ HD int tu_above(const TuSrc &s, int i) {         // unfiltered above / above-rig
 }
 template <int K>
 HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int har, int c_lo, int c_hi) {
-    const int h = N / 2, n2 = N;   // 2*h entries per side
+    const int h = N / 2, n2 = N, lg2 = hibit((u32)N);   // 2*h entries per side
     LANES(l) {
         NOUNROLL
         for (int e0 = c_lo * n2; e0 < c_hi * n2; e0 += 64) {
             const int e = e0 + l;
             if (e < c_hi * n2) {
-                const int c = e / n2, i = e - c * n2;
+                const int c = e >> lg2, i = e & (n2 - 1);              // (n2 = 8 or 16)
                 BorderS &b = SM.X.bc[c];
                 TuSrc s;
                 s.h = h; s.hl = hl; s.hbl = hbl; s.ha = ha; s.har = har;
@@ -858,7 +858,7 @@ HD void border_tu_split_k(int N, int y0, int x0, int hl, int hbl, int ha, int ha
                     if (c == 1) {                                       // only the DC mode reads dc (unfiltered border)
                         int dc = h;
                         for (int j = 0; j < h; j++) dc += tu_left<K>(s, j) + tu_above<K>(s, j);
-                        b.dc = (i16)(dc / (2 * h));
+                        b.dc = (i16)(dc >> lg2);                         // dc / 2h
                     }
                 }
             }

@@ -573,9 +573,10 @@ HDN void price_split(int depth_, int N_, int y0_, int x0_) {
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
         int part = 0;
+        const int lgn = hibit((u32)N);
         NOUNROLL
         for (int i = tid; i < N * N; i += WG_THREADS) {
-            const int y = y0 + i / N, x = x0 + i % N;
+            const int y = y0 + (i >> lgn), x = x0 + (i & (N - 1));
             const int d = (int)SM.org[y][x] - SM.rec[y + 1][x + 1];
             part += d * d;
         }
