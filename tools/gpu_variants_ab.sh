@@ -14,7 +14,7 @@ done
 for rep in 1 2; do
   i=0
   for v in "$@"; do
-    echo "== [$v]" >> $L; IMCVT_HEVC_LIB=${LIBS[$i]} PP_LAUNCHES=${PP_LAUNCHES:-2} timeout 900 python tools/pool_probe.py 1920 1080 $N 0 a:a 2>&1 | grep -v amdgpu.ids >> $L
+    echo "== [$v]" >> $L; IMCVT_HEVC_LIB=${LIBS[$i]} PP_LAUNCHES=${PP_LAUNCHES:-2} timeout 900 python tools/pool_probe.py 1920 1080 $N ${QP:-0} a:a 2>&1 | grep -v amdgpu.ids >> $L
     i=$((i+1))
   done
 done
