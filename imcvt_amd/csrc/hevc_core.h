@@ -1576,14 +1576,13 @@ HD void p1_run_4(int wave, const P1Args &P) {
                     const int in = T.incg[st][hibit(nzm)];
                     const LastPos lp = last_pos_prep(0, st, in >> 2, in & 3);
                     w.n = P.hint ? last_pos_emit<0, true, true>(w.o, w.n, lp) : last_pos_emit<0, true>(w.o, w.n, lp);      // PU candidates: tokens with state hints (priced by code_token_r)
-                    ls_flush(ls, w);                        // <= 7 tokens stay staged: each part below then fits the row
-                    TgB B;
+                    TgB B;                                  // (at most 7 + 1 + 7 slots are in use here and part A touches 28 more: the row holds 64)
                     const int cfg4 = TG_DC | TG_LAST | st << TG_ST;
                     w.n = (P.hint ? tokg_a_fast<0, true>(w.o.tb, w.n, L, nzm, mcode, cfg4, B) : tokg_a_fast<0>(w.o.tb, w.n, L, nzm, mcode, cfg4, B)) & 0xFFFF;
                     if (B.esc) {
-                        ls_flush(ls, w);
+                        ls_flush(ls, w);                    // <= 7 tokens stay staged; eight levels add at most 8 x 5 chunks (escape code words of 32 bins)
                         w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B);
-                        ls_flush(ls, w);
+                        if (w.n > 14) ls_flush(ls, w);      // (rarely: 14 + 8 x 5 + the closing chunk + 8 idle tokens still fit the row)
                         w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B);
                     }
                     w.n = tokg_end<true, true>(w.o, w.n, B);
