@@ -105,6 +105,14 @@ def golden_digests(qpd6):
     return g
 
 
+def _lib_srchash():
+    """Content hash of the sources + flags the timed library was built from (imcvt_amd/build.py writes it beside the .so)."""
+    try:
+        return open(os.path.join(ROOT, "imcvt_amd", "csrc", "libimcvt_hevc.so.srchash")).read().strip()
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +200,8 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, dev)
+    ranks_seen = shard.ranks_observed(dev) if use_dist else 1      # an all-reduce of ones: what the collective backend itself counts
+    frames_per_rank = [len(v) for v in shard.gather_lengths([0] * F, dev)] if use_dist else [F]
 
     # ---- correctness of what was just timed
     lens = batch["lens"].cpu().tolist()
@@ -239,13 +249,15 @@ def main():
         achieved = algo_bytes / k_avg / 1e9
         traffic, traffic_src = None, "not collected in this run (rocprofv3 --pmc passes: tools/pmc_traffic.py)"
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # calibrated FETCH_SIZE / WRITE_SIZE of a counter run
+        lib_hash = _lib_srchash()
+        stale = lambda rec: "" if rec.get("lib_srchash") == lib_hash else "STALE (counters were taken on a different build of the library than the one timed here) - "
         if os.path.exists(tp):
             t = json.load(open(tp))
             if t.get("qpd6") == args.qpd6 and t.get("hbm_bytes_per_launch") and t.get("ctus"):
                 same = (t.get("frames"), t.get("w"), t.get("h")) == (F, W, H)
                 traffic = int(t["hbm_bytes_per_launch"] * ctus / t["ctus"])
                 what = f"{t.get('frames')} x {t.get('w')}x{t.get('h')} frames, {t['ctus']} CTUs, {t['hbm_bytes_per_launch']} B per launch"
-                traffic_src = (f"calibrated FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this same workload ({what}; {tp[len(ROOT) + 1:]}); not collected in this run"
+                traffic_src = stale(t) + (f"calibrated FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this same workload ({what}; {tp[len(ROOT) + 1:]}); not collected in this run"
                                if same else f"extrapolated by CTU count from a counter run over {what} ({tp[len(ROOT) + 1:]}); not measured on this workload")
         macs = 12320 * hp * wp * F                                          # transform MACs per launch
         mode = f"{'strong' if strong else 'weak'}: {total_frames} frames over {world} GPU(s), {F} on rank 0"
@@ -257,7 +269,8 @@ def main():
             "data": "synthetic syn(1920,1080,seed), SURVEY App. C",
             "config": {"workload": f"BASELINE configs[3]: batch of {total_frames} independent 1920x1080 gray8 frames -> .h265, qpd6={args.qpd6}, frame-sharded ({mode})",
                        "global_frames": total_frames, "frames_rank0": F, "width": W, "height": H, "qpd6": args.qpd6,
-                       "parallelism": f"frames x{world}; streams gathered to rank 0 over RCCL (send/recv)" if use_dist else "frames x1 (single GPU, no collective)",
+                       "parallelism": f"frames x{world}; streams gathered to rank 0 over RCCL (one batch of isend/irecv)" if use_dist else "frames x1 (single GPU, no collective)",
+                       "rccl_ranks_observed": ranks_seen, "frames_per_rank": frames_per_rank,
                        "stream_bytes_per_frame": int(sum(lens) / max(1, F)), "verified": verified,
                        "step_to_step": "all frames digest-equal between the last warm-up step and the last timed step" if first is not None else "not checked (no warm-up)",
                        "encoder": imcvt_amd.load_library().imcvt_hevc_version().decode()},
@@ -275,7 +288,7 @@ def main():
             line["roofline_issue"] = {"bound": "valu issue", "achieved": round(insts / k_avg / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-inst/s",
                                       "frac": round(insts / k_avg / peak, 4), "peak_unpacked": round(peak4 / 1e9, 1), "frac_of_unpacked_peak": round(insts / k_avg / peak4, 4),
                                       "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"], "lane_activity": iv.get("valu_lane_activity"),
-                                      "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": "instruction count per CTU and lane activity from " + iv["source"] + "; time from this run"}
+                                      "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": stale(iv) + "instruction count per CTU and lane activity from " + iv["source"] + "; time from this run"}
         if world == 1 and not args.no_latency_view:
             line["latency_view"] = latency_view(enc, dev, args.qpd6)
             line["qpd6_4_view"] = qpd6_view(enc, big, 4) if args.qpd6 != 4 else None
@@ -414,7 +427,7 @@ def latency_view(enc, dev, qpd6):
             raise SystemExit(f"latency_view {name}: stream differs from the reference digest")
         out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(w * h / ms / 1e3, 3), "bytes": n, "sha256_equal_to_reference": okd,
                      "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe()}
-    # BASELINE configs[0]: the reference's own sample picture (image/P4.pnm, 300 x 263; its pixels are tests/golden/p4_gray.pgm) through the
+    # BASELINE configs[0]: the reference's own sample picture (image/P4.pnm, 21 x 17 raw PBM -> one 32 x 32 CTU; its pixels as gray8 are tests/golden/p4_gray.pgm) through the
     # reference-shaped FILE entry point, writeHEVCImageFile (src/imageio_hevc.c:9): host buffers, PCIe, the launch and the file write included
     import tempfile
     import numpy as np
@@ -432,7 +445,7 @@ def latency_view(enc, dev, qpd6):
         got = open(path, "rb").read()
     if rc != 0 or got != want:
         raise SystemExit("latency_view p4: writeHEVCImageFile output differs from the reference's stream")
-    out["p4"] = {"what": "BASELINE configs[0]: the reference's 300x263 sample picture -> .h265 through writeHEVCImageFile (host buffers, file write), qpd6 0",
+    out["p4"] = {"what": "BASELINE configs[0]: the reference's 21x17 sample picture image/P4.pnm (one CTU) -> .h265 through writeHEVCImageFile (host buffers, file write), qpd6 0",
                  "wall_ms": round(min(ts) * 1e3, 2), "mpx_s": round(pw * ph / min(ts) / 1e6, 3), "bytes": len(got), "bytes_equal_to_reference": True}
     imcvt_amd.load_library().imcvt_hevc_shutdown()
     return out

@@ -25,12 +25,17 @@ def _run_to(cmd, out):
 # 168 registers they are spilled at once and reloaded inside the loops.  Without it: private segment 1008 -> 720 B per lane, HBM traffic
 # 5.8 -> 4.5 MB per CTU, same speed (A/B on one box, profiles/r03w2_licm_ab.log).
 KERNEL_FLAGS = ["-mllvm", "-disable-machine-licm"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def _source_hash(deps, flags) -> str:
     """sha256 over the sources a library is built from and the flags it is built with."""
     import hashlib
-    h = hashlib.sha256(" ".join(flags).encode())
+    h = hashlib.sha256(" ".join([_hipcc(), *BASE_FLAGS, *flags]).encode())      # the whole command line, compiler path included
     for d in deps:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
@@ -50,9 +55,10 @@ def _is_current(out, deps, flags) -> bool:
         return False
 
 
-def _write_stamp(out, deps, flags):
+def _write_stamp(out, digest):
+    """`digest` = _source_hash() taken BEFORE the compiler ran: a source edited during the compile leaves a stamp that no longer matches."""
     with open(_stamp(out), "w") as f:
-        f.write(_source_hash(deps, flags) + "\n")
+        f.write(digest + "\n")
 
 
 def needs_build() -> bool:
@@ -65,10 +71,9 @@ JLS_DEPS = ["jls_hip.hip", "jls_core.h", "jls_par.h", os.path.join("..", "..", "
 
 def build_jls(force: bool = False) -> str:
     if force or not _is_current(JLS_OUT, JLS_DEPS, []):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run_to([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                 os.path.join(CSRC, "jls_hip.hip")], JLS_OUT)
-        _write_stamp(JLS_OUT, JLS_DEPS, [])
+        digest = _source_hash(JLS_DEPS, [])
+        _run_to([_hipcc(), *BASE_FLAGS, os.path.join(CSRC, "jls_hip.hip")], JLS_OUT)
+        _write_stamp(JLS_OUT, digest)
     return JLS_OUT
 
 
@@ -95,13 +100,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         build_host()
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *KERNEL_FLAGS,
-           *[os.path.join(CSRC, s) for s in SRC]]
+    digest = _source_hash(DEPS, KERNEL_FLAGS)
+    cmd = [_hipcc(), *BASE_FLAGS, *KERNEL_FLAGS, *[os.path.join(CSRC, s) for s in SRC]]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     _run_to(cmd, OUT)
-    _write_stamp(OUT, DEPS, KERNEL_FLAGS)
+    _write_stamp(OUT, digest)
     build_host(force=True)
     return OUT
 

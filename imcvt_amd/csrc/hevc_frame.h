@@ -965,7 +965,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
                         // share of its frame it has finished with the average over all of them, and one that lags more than a CTU and
                         // a half runs at raised wave priority until it has caught up to within half a CTU (priority outranks age).
                         if ((cy | cx) != 0) { F.pace_mine += F.pace_inc; m_add32(&F.pq->progress, (u32)F.pace_inc); }
-                        const u32 running = m_ld32(&F.pq->mains_taken);                  // main workgroups that have actually started (<= the planned number)
+                        const u32 taken_ = m_ld32(&F.pq->mains_taken), running = taken_ < (u32)F.pace_n ? taken_ : (u32)F.pace_n;      // main workgroups that have actually started (the counter is bumped past the planned number by late claimers)
                         const int avg = (int)(m_ld32(&F.pq->progress) / (running ? running : 1u)), lag = avg - F.pace_mine;
                         if (lag * 2 > 3 * F.pace_inc) F.prio_base = 2; else if (lag * 2 < F.pace_inc) F.prio_base = F.pace_base;
                     }
@@ -1074,7 +1074,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
         wg_sync();
         prof_add(PF_CTUIO, tidle);                          // (booked as "idle": waiting for a request)
         const int slot = SM.red[1], id = SM.red[2];
-        if (slot == -3) continue;
+        if (slot == -3) { wg_sync(); continue; }            // (every wave has read red[1..2] before thread 0 polls again and overwrites them)
         if (slot < 0) { taken = slot == -2 ? id : -1; break; }
         WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&mail[id].s[slot].req_flag, 0x10000u | (u32)home_blk); m_st32(&mail[id].s[slot].pad0_[0], (u32)wd_now()); } }      // (debug: who took the request, when)
         serve_request(gK, jobs, &mail[id].s[slot]);

@@ -18,7 +18,10 @@
 #include "hevc_tables.h"
 #include "../../include/imcvt_hevc.h"
 
-__global__ __launch_bounds__(WG_THREADS_PIPE, 3) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
+#ifndef KERNEL_MIN_WAVES
+#define KERNEL_MIN_WAVES 3          // waves per SIMD the register budget is cut for: 3 = 168 registers (four 192-thread or three 256-thread workgroups per compute unit)
+#endif
+__global__ __launch_bounds__(WG_THREADS_PIPE, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
                                                                  TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk) {
     KArgs A;

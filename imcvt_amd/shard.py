@@ -70,17 +70,35 @@ def gather_streams(packed, lengths, device=None):
         return [(lengths, packed)]
     all_lens = gather_lengths(lengths, device)
     rank, world = dist.get_rank(), dist.get_world_size()
+    # every transfer of the step is posted at once (on RCCL: one group, each peer on its own xGMI link to the root); a rank without
+    # frames sends nothing and nothing is posted for it
     if rank != 0:
         if packed.numel():
-            dist.send(packed, dst=0)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed, 0)]):
+                w.wait()
         return None
-    res = [(lengths, packed)]
+    res, ops = [(lengths, packed)], []
     for r in range(1, world):
         buf = torch.empty(sum(all_lens[r]), dtype=torch.uint8, device=packed.device)
         if buf.numel():
-            dist.recv(buf, src=r)
+            ops.append(dist.P2POp(dist.irecv, buf, r))
         res.append((all_lens[r], buf))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     return res
+
+
+def ranks_observed(device=None) -> int:
+    """How many ranks the collective backend itself sees: an all-reduce (SUM) of ones.  bench.py prints it so that an N-GPU line
+    certifies that N ranks took part over RCCL (1 without a process group)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def unpack_streams(lengths, packed):

@@ -67,3 +67,43 @@ def test_two_rank_frame_sharding(built):
     for n in (0, 1, 7, 512):
         got = [i for k in range(3) for i in shard.split_frames(n, k, 3)]
         assert got == list(range(n))
+
+
+def _worker4(rank, world, port, q, n_frames):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from imcvt_amd import shard
+    from oracle import oracle, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import torch
+    seen = shard.ranks_observed()
+    own = list(shard.split_frames(n_frames, rank, world))
+    streams = [oracle.port_encode(synth.syn(24 + 8 * (s % 3), 24, s), 3)[0] for s in own]      # (streams of different lengths)
+    outs = [torch.from_numpy(np.frombuffer(b + bytes(3), dtype=np.uint8).copy()) for b in streams]
+    slens = [len(b) for b in streams]
+    got = shard.gather_streams(shard.pack_streams(outs, slens), slens)
+    gathered = [[bytes(v.numpy().tobytes()) for v in shard.unpack_streams(ls, packed)] for ls, packed in got] if rank == 0 else None
+    assert (got is None) == (rank != 0)
+    dist.barrier()
+    q.put((rank, seen, own, gathered))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [6, 3])      # 4 ranks: shares 2,2,1,1 — and 1,1,1,0 (a rank with nothing to send)
+def test_four_ranks_unequal_shares_and_an_empty_rank(built, n_frames):
+    from oracle import oracle, synth
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q, n_frames)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs: p.join(timeout=60)
+    assert [r[1] for r in res] == [world] * world                              # the backend itself saw four ranks
+    assert sum((r[2] for r in res), []) == list(range(n_frames))               # contiguous blocks, rank-major
+    per_rank = res[0][3]
+    assert [len(v) for v in per_rank] == [len(r[2]) for r in res]              # one list per rank, empty for the rank without frames
+    assert sum(per_rank, []) == [oracle.port_encode(synth.syn(24 + 8 * (s % 3), 24, s), 3)[0] for s in range(n_frames)]

@@ -25,4 +25,9 @@ out = {"source": f"{sys.argv[1].replace('gpurun_out/', 'profiles/')} (rocprofv3 
        "mfma_busy_frac": round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (cycles_per_xcc * 256), 5) if ("SQ_VALU_MFMA_BUSY_CYCLES" in vals and cycles_per_xcc) else None,
        "units": "SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (x4 = cycles); GRBM_GUI_ACTIVE is summed over the 8 XCCs; 1024 SIMDs",
        "frames": frames, "w": w, "h": h, "qpd6": q}
+import os
+try:      # the build these counters were taken on (bench.py marks the numbers stale when the timed library differs)
+    out["lib_srchash"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "imcvt_amd", "csrc", "libimcvt_hevc.so.srchash")).read().strip()
+except OSError:
+    out["lib_srchash"] = None
 print(json.dumps(out, indent=1))

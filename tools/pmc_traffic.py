@@ -30,4 +30,9 @@ if f_scale and w_scale:
 if len(sys.argv) > 6:
     out["w"], out["h"] = int(sys.argv[5]), int(sys.argv[6])
     out["ctus"] = out["frames"] * ((out["w"] + 31) // 32) * ((out["h"] + 31) // 32)
+import os
+try:      # the build these counters were taken on (bench.py marks the numbers stale when the timed library differs)
+    out["lib_srchash"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "imcvt_amd", "csrc", "libimcvt_hevc.so.srchash")).read().strip()
+except OSError:
+    out["lib_srchash"] = None
 print(json.dumps(out, indent=1))
