@@ -24,6 +24,12 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
 // NxN trial of every 8x8 CU off the wave that walks the PU chain.  It joins the workgroup barriers and skips everything else.
 #define PIPE_WAVE NWAVES
 #define WG_THREADS_PIPE ((NWAVES + 1) * 64)
+// Wide workgroups (round 5; launches that leave every main workgroup a compute unit of its own): 512 threads.  Wavefronts 4..7 are the
+// PARTNERS of wavefronts 0..3 — wave 4 + i runs the byte half of every trial coder whose range half wave i runs (stream_seg_R / stream_seg_L
+// below): a lone wavefront issues one instruction per ~4.6 cycles whatever the instruction (tools/valu_rate_probe.hip), so a chain gets
+// shorter only by putting fewer instructions on each wavefront.  Like the pipe wave they join every workgroup barrier and skip the rest.
+#define XWAVES 4
+#define WG_THREADS_WIDE ((NWAVES + 1 + XWAVES) * 64)
 #define NMODE 35
 #define I32MAX 0x7fffffff
 
@@ -58,8 +64,9 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_ld_i32(const i32 *p) { return *(const volatile i32 *)p; }
   HD void lds_st_i32(i32 *p, i32 v) { *(volatile i32 *)p = v; }
   HD void pipe_pause() { emu_yield(); }
-  static int emu_pipe_on();
+  static int emu_pipe_on(); static int emu_wide_on();
   HD int wg_has_pipe_wave() { return emu_pipe_on(); }
+  HD int wg_is_wide() { return emu_wide_on(); }
   HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
   HD void drain_stores() {}
 #else
@@ -111,6 +118,7 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD void lds_st_i32(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   HD void pipe_pause() { __builtin_amdgcn_s_sleep(2); }
   HD int wg_has_pipe_wave() { return blockDim.x > (unsigned)WG_THREADS; }
+  HD int wg_is_wide() { return blockDim.x >= (unsigned)WG_THREADS_WIDE; }
 #endif
 
 #if defined(IMCVT_HOSTEMU)
@@ -417,7 +425,8 @@ struct FrameCtx {
     u32 waited, waited_max;   // 100 MHz ticks this frame's main workgroup spent waiting for answers, and the longest single wait (debug statistics)
     i32 pace_inc, pace_mine, pace_n, pace_base;   // pace control: 65536 / CTUs of this frame, this workgroup's share done, main workgroups of the launch, configured base priority
     i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
-    i32 pipe;           // this launch's workgroups carry a pipe wave (256 threads)
+    i32 pipe;           // this launch's workgroups carry a pipe wave (256 threads or more)
+    i32 wide;           // ... and four partner wavefronts (512 threads): the trial coders of the 8x8 CUs run split over two wavefronts each
 };
 
 struct FourTU {                  // state of the four-TU shape (one wave evaluates it at a time)
@@ -476,6 +485,29 @@ static u8 *g_pipe_host;
 #else
 extern __shared__ __attribute__((aligned(16))) u8 g_pipe_lds[];
 #define PM (*(WaveMem *)g_pipe_lds)
+#endif
+// ---- partner wavefronts (wide workgroups): record queue between the two halves of a trial coder, and the byte half's own lane memory.
+// The range half (stream_seg_R: contexts, range) leaves one 32-bit record per token — what the byte half (stream_seg_L: low, bit
+// position, byte output) needs of it — in a ring of QDEPTH token blocks per lane; prod / cons count the blocks written / read, per lane
+// (the lanes of a wavefront move in lock-step on the device, so one counter would do there; the host emulation's lanes are fibers).
+#define QDEPTH 4
+#define QSTRIDE (QDEPTH * 8 + 4)                 // dwords per lane row: 16-byte aligned rows, 36 l mod 64 spreads the lanes over 16 banks
+struct alignas(16) SplitQ {
+    u32 rec[NMODE][QSTRIDE];
+    i32 prod[NMODE], cons[NMODE];
+    i32 range_out[NMODE];                        // the range each lane's coder ended with
+    i32 go, mid, rdone, done;                    // generation started by the owner / whose last segment may start (pipe wave) / whose ranges are final / finished by the partner
+};
+struct alignas(16) PartnerMem {
+    SplitQ q;
+    alignas(16) LaneMem lm[NMODE];               // byte rings + lead queues of the byte half
+    alignas(4) u8 cx[NMODE][CTX_STRIDE];         // context scratch of its safe path (ring overflow)
+};
+#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem))
+#ifdef IMCVT_HOSTEMU
+#define XM(i) (*(PartnerMem *)(g_pipe_host + PIPE_LDS_BYTES + (i) * sizeof(PartnerMem)))
+#else
+#define XM(i) (*(PartnerMem *)(g_pipe_lds + PIPE_LDS_BYTES + (i) * sizeof(PartnerMem)))
 #endif
 HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
 HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }
@@ -2196,6 +2228,154 @@ HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p
     }
 }
 HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) { stream_seg_t<false>(a, cx, lm, sink, p, n); }
+
+// ---------------------------------------------------------------------------------------------------
+// The trial coder split over two wavefronts (wide workgroups).  A token step (code_token_q) is two recurrences: the RANGE side —
+// context state, LPS range, renormalisation shift, new range (:913-926) — which needs nothing of `low`, and the BYTE side — low,
+// the bit position, bytes leaving (:921-930 for low, :858-878) — which needs of the range side only the addend (range - LPS for
+// an LPS bin), the shift and, for a bypass chunk, the range it multiplies (:898-910).  stream_seg_R runs the first on the owner's
+// wavefront and leaves those numbers as one record per token; stream_seg_L, on the partner wavefront, one token block behind, runs
+// the second on the records.  Same arithmetic, same order, per lane: low = ((low + add) << nb) + range * value, exactly the line of
+// code_token_q — each wavefront just issues half of the instructions.
+//     record = add (9 bits) | range << 9 | nb << 18 | value << 22        (context bin: value = 0; bypass chunk: add = 0)
+// ---------------------------------------------------------------------------------------------------
+HD u32 token_R(int &range, u8 *cx, u32 tok) {
+    const int byp = tok >= 0x8000u;
+    const u32 cim = tok >> 8;
+    const int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
+    const int pz = cx[ci];
+    const uint2 e = SM.T.pst[pz];
+    const int lps = (int)((e.x >> ((range >> 3) & 24)) & 0xFF);
+    const int rm = range - lps;
+    const int is_lps = (int)(tok ^ (u32)pz) & 1;
+    const int r2 = is_lps ? lps : rm;
+    const int sh = clz_nz((u32)r2) - 23;
+    cx[ci] = (u8)(is_lps ? e.y : e.y >> 8);
+    const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+    const int add = (is_lps & !byp) ? rm : 0;
+    const u32 rec = (u32)add | (u32)range << 9 | (u32)nb_ << 18 | (byp ? (tok & 255u) << 22 : 0u);
+    range = byp ? range : (r2 << sh);
+    return rec;
+}
+HD u32 token_R_res(int &range, u32 tok, u32 lw) {                // resolved tokens (code_token_r): no context copy
+    const int byp = tok >= 0x8000u;
+    const int lps = (int)((lw >> ((range >> 3) & 24)) & 0xFF);
+    const int rm = range - lps;
+    const int is_lps = (int)(tok ^ (tok >> 1)) & 1;
+    const int r2 = is_lps ? lps : rm;
+    const int sh = clz_nz((u32)r2) - 23;
+    const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+    const int add = (is_lps & !byp) ? rm : 0;
+    const u32 rec = (u32)add | (u32)range << 9 | (u32)nb_ << 18 | (byp ? (tok & 255u) << 22 : 0u);
+    range = byp ? range : (r2 << sh);
+    return rec;
+}
+HD void token_L(Arith &a, u16 *lq, int &qn, u32 rec) {
+    const int add = (int)(rec & 511u), rg = (int)((rec >> 9) & 511u), nb_ = (int)((rec >> 18) & 15u), val = (int)(rec >> 22);
+    a.low = ((a.low + add) << nb_) + mul24(rg, val);
+    a.nbits -= nb_;
+    const int need = a.nbits < 12;                                                // :858-862
+    lq[qn] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
+    qn += need;
+    a.nbits += need ? 8 : 0;
+    a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
+}
+// the owner's lanes zero their queue counters before the partner is told to start (split_go)
+HD void split_reset(SplitQ &q, int lane) { if (lane < NMODE) { q.prod[lane] = 0; q.cons[lane] = 0; } }
+// Range half of tokens p[0..n): wave collective like stream_seg_t.  `blk` counts this lane's token blocks of the run (it runs on over
+// the segments of one stream).
+template <bool RES>
+HD void stream_seg_R(int &range, u8 *cx, SplitQ &q, int lane, int &blk, const u16 *p, int n) {
+    const int last_blk = imax((n - 1) >> 3, 0);
+    const int ql = lane < NMODE ? lane : 0;
+    u32 *const row = q.rec[ql];
+    U4 cur = g_ld128(p);
+    int cons_seen = lds_ld_i32(&q.cons[ql]);
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        const u16 *pn = p + 8 * imin((k0 >> 3) + 1, last_blk);
+#ifdef IMCVT_HOSTEMU
+        const U4 nxt = g_ld128(pn);
+#else
+        u32x4 nv;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv) : "v"(pn) : "memory");
+#endif
+        if (k0 < n) {
+            // room in the ring: the partner has read block blk - QDEPTH (re-read its counter only when the last look is too old)
+            while (WAVE_ANY(blk - cons_seen >= QDEPTH)) { if (blk - cons_seen >= QDEPTH) { pipe_pause(); cons_seen = lds_ld_i32(&q.cons[ql]); } }
+            u32 rec[8];
+            if constexpr (RES) {
+                u32 lw[8];
+                UNROLL_FULL
+                for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
+                UNROLL_FULL
+                for (int j = 0; j < 8; j++) rec[j] = token_R_res(range, tok_of(cur, j), lw[j]);
+            } else {
+                UNROLL_FULL
+                for (int j = 0; j < 8; j++) rec[j] = token_R(range, cx, tok_of(cur, j));
+            }
+            u32 *d = row + (blk & (QDEPTH - 1)) * 8;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) d[j] = rec[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");                  // the records are issued before the counter (LDS serves a wavefront's accesses in order)
+#endif
+            blk++;
+            lds_st_i32(&q.prod[ql], blk);
+        }
+#ifdef IMCVT_HOSTEMU
+        cur = nxt;
+#else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nv) : : "memory");
+        cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
+#endif
+    }
+}
+// Byte half: consumes the records of n tokens of this lane.  Same trip count as the owner's stream_seg_R (same n).
+HD void stream_seg_L(Arith &a, LaneMem *lm, RingSink &sink, SplitQ &q, int lane, int &blk, int n) {
+    const int ql = lane < NMODE ? lane : 0;
+    const u32 *const row = q.rec[ql];
+    int prod_seen = 0;
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        if (k0 < n) {
+            while (WAVE_ANY(prod_seen <= blk)) { if (prod_seen <= blk) { prod_seen = lds_ld_i32(&q.prod[ql]); if (prod_seen <= blk) pipe_pause(); } }
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            const u32 *sp = row + (blk & (QDEPTH - 1)) * 8;
+            u32 rec[8];
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) rec[j] = sp[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");                  // (the reads are issued before the counter store: the owner may overwrite the slot once it sees it)
+#endif
+            blk++;
+            lds_st_i32(&q.cons[ql], blk);
+            ring_sync(sink, a.cnt);
+            int qn = 0;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) token_L(a, lm->lq, qn, rec[j]);
+            u32 lqw[4];
+            for (int d = 0; d < 4; d++) lqw[d] = *(const u32a *)&lm->lq[2 * d];
+            UNROLL_FULL
+            for (int i = 0; i < 8; i++) {
+                if (!WAVE_ANY(i < qn)) break;
+                const int act = i < qn;
+                const int lead = (int)((i & 1) ? lqw[i >> 1] >> 16 : lqw[i >> 1] & 0xFFFFu);
+                const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
+                const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
+                u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : (u8 *)&lm->lq[LEADQ - 1];
+                *dst = (u8)v1;
+                a.cnt += fast;
+                a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
+                a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
+                const int rare = act & !fast;
+                if (WAVE_ANY(rare)) { if (rare) carry_rare(a, sink, lead); }
+            }
+        }
+    }
+}
 template <bool RES = false>
 HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) {
     RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;

@@ -91,6 +91,84 @@ HDN void tu0_from_pu0(int wave_, u16 *tok1_) {          // (out of line: inlined
     wave_sync_lds();
     LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_taken, 1); }
 }
+// ---- wide workgroups: the two halves of a trial coder (hevc_core.h stream_seg_R / stream_seg_L) --------------------------------
+// owner: counters zeroed, then the partner is told to start (its generation counter)
+HD void split_start(SplitQ &q) {
+    LANES(l) { split_reset(q, l); }
+    wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32(&q.go, lds_ld_i32(&q.go) + 1); }
+}
+HD void split_flag(i32 *flag, SplitQ &q) {              // owner: everything this wavefront stored to LDS so far is visible to whoever sees the flag
+    wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32(flag, lds_ld_i32(&q.go)); }
+}
+HD void split_await(const i32 *flag, const SplitQ &q) { // returns once *flag names the running generation
+    while (lds_ld_i32(flag) != lds_ld_i32(&q.go)) pipe_pause();
+    wave_sync();
+}
+HD void ctx_copy(u8 *dst, const u8 *src) { for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(dst + i) = *(const u32a *)(src + i); }
+// partner of wave `own` (0: one TU, 1: four TUs) of an 8x8 CU: the byte half of its 35 trial coders; writes their final coder states and costs
+HDN void partner_trial(int own_, int depth_) {
+    const int own = uni_i(own_); const int depth = uni_i(depth_);
+    PartnerMem &X = XM(own); SplitQ &q = X.q;
+    WaveMem &W = WM(own);
+    while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
+    wave_sync();                                        // token counts are final, the streams are in memory
+    const RdW rw = rd_weights(F.job.q);
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
+    const u16 *tok = wave_tok(F.sc, own);
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        Arith a = SM.entry_a[depth];
+        const Arith a0 = a;
+        const int len0 = arith_len(a), n = on ? W.tokn[ll] : 0;
+        u8 *gbuf = ubytes + (size_t)(own * NMODE + ll) * TRIAL_BYTES;
+        RingSink sink; sink.ring = X.lm[ll].ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+        int blk = 0;
+        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, n);
+        ring_finish(sink, a.cnt);
+        const int ovf = sink.ovf;
+        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — this lane's bytes again, by the plain coder on a scratch copy of the contexts
+            if (ovf) { a = a0; ctx_copy(X.cx[ll], SM.entry_cx[depth]); }
+            stream_run_safe(a, X.cx[ll], gbuf, tok + (size_t)ll * TOK_CAP, ovf ? n : 0);
+        }
+        split_await(&q.rdone, q);
+        if (on) {
+            a.range = q.range_out[l];
+            W.fin[l] = pack_arith(a);
+            W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
+        }
+    }
+    split_flag(&q.done, q);
+}
+// partner of the PU wave: the byte half of the pricing of each PU's 35 candidates (fresh coder, :1504-1518); writes their costs
+HDN void partner_pu() {
+    PartnerMem &X = XM(2); SplitQ &q = X.q;
+    WaveMem &W = WM(2);
+    const RdW rw = rd_weights(F.job.q);
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
+    const u16 *tok = wave_tok(F.sc, 2);
+    for (int k = 0; k < 4; k++) {
+        while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
+        wave_sync();
+        LANES(l) {
+            const int on = l < NMODE, ll = on ? l : 0;
+            Arith a; arith_reset(a);
+            const int n = on ? W.tokn[ll] - 8 : 0;
+            u8 *gbuf = ubytes + (size_t)(2 * NMODE + ll) * TRIAL_BYTES;
+            RingSink sink; sink.ring = X.lm[ll].ring; sink.gbuf = gbuf; sink.c0 = 0; sink.fl = 0; sink.ovf = 0;
+            int blk = 0;
+            stream_seg_L(a, &X.lm[ll], sink, q, l, blk, n);
+            const int ovf = sink.ovf;
+            if (WAVE_ANY(ovf)) {
+                if (ovf) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
+                stream_run_safe(a, X.cx[ll], gbuf, tok + (size_t)ll * TOK_CAP + 8, ovf ? n : 0);
+            }
+            if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
+        }
+        split_flag(&q.done, q);
+    }
+}
 #ifndef SPL32_0
 #define SPL32_0 23
 #define SPL32_1 24
@@ -101,7 +179,10 @@ HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? SPL32_0 : S
 HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int avm_) {
     const int wave = uni_i(wave_); const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     if (wave >= NWAVES) {                               // the pipe wave has no share in these sets: it only keeps the workgroup's barrier count
-        if (N >= 16) { wg_sync_p(); wg_sync_p(); }
+        if (N >= 16) {
+            wg_sync_p(); wg_sync_p();
+            if (F.wide && (wave == PIPE_WAVE + 1 || wave == PIPE_WAVE + 2)) partner_trial(wave - (PIPE_WAVE + 1), depth);      // wide workgroups: the byte half of the trial coders of waves 0 / 1
+        }
         return;
     }
     const Avail av = unpack_avail(avm);
@@ -165,6 +246,18 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 #ifndef IMCVT_HOSTEMU
     if (big) { if (F.prio_base) SETPRIO(3); else SETPRIO(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
 #endif
+    if (F.wide) {                                       // wide workgroup: this wavefront runs the range half, wave 4 + `wave` the byte half (partner_trial)
+        SplitQ &q = XM(wave).q;
+        split_start(q);
+        LANES(l) {
+            const int on = l < NMODE, ll = on ? l : 0;
+            int range = SM.entry_a[depth].range, blk = 0;
+            if (on) ctx_copy(W.u.p2.cx[ll], SM.entry_cx[depth]);
+            stream_seg_R<false>(range, W.u.p2.cx[ll], q, l, blk, tok + (size_t)ll * TOK_CAP, on ? W.tokn[ll] : 0);
+            if (on) q.range_out[l] = range;
+        }
+        split_flag(&q.rdone, q);                        // (final coder states and costs are the partner's to write, before the barrier that follows the candidate sets)
+    } else
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a = SM.entry_a[depth];
@@ -228,6 +321,18 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         wave_sync();
         if (TU0_SHARE && k == 0) { LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); } }      // tokens in memory, SSE / reconstructions in this wave's slice: the four-TU wave's TU 0
         prof_add(PF_P1_16, pt); pt = prof_now();
+        if (F.wide) {                                   // wide workgroup: range half here, byte half + costs on the partner wavefront (partner_pu)
+            SplitQ &q = XM(2).q;
+            split_start(q);
+            LANES(l) {
+                const int on = l < NMODE, ll = on ? l : 0;
+                int range = 510, blk = 0;
+                const u16 *ts = tok + (size_t)ll * TOK_CAP + 8;
+                if (hint) stream_seg_R<true>(range, W.u.p2.cx[ll], q, l, blk, ts, on ? W.tokn[ll] - 8 : 0);
+                else { if (on) ctx_copy(W.u.p2.cx[ll], SM.cx0); stream_seg_R<false>(range, W.u.p2.cx[ll], q, l, blk, ts, on ? W.tokn[ll] - 8 : 0); }
+            }
+            split_await(&q.done, q);
+        } else
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             const int on = l < NMODE, ll = on ? l : 0;
             Arith a; arith_reset(a);
@@ -384,6 +489,33 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
         }
     }
     wave_sync();                                        // the headers are in memory; the token rows make room for the coders' contexts
+    if (F.wide) {                                       // wide workgroup: the range half of the 35 streams here, the byte half on the partner wavefront (partner_pipe)
+        SplitQ &q = XM(PIPE_WAVE).q;
+        split_start(q);
+        LANES(l) {
+            const int on = l < NMODE, ll = on ? l : 0;
+            const int nh = W.tokn[ll];
+            u8 *cx = W.u.p2.cx[ll];
+            const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
+            int range = SM.entry_a[2].range, blk = 0;
+            if (on) ctx_copy(cx, SM.entry_cx[2]);
+            stream_seg_R<false>(range, cx, q, l, blk, hdr, on ? nh : 0);
+            const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
+            stream_seg_R<false>(range, cx, q, l, blk, kept, on ? n012 : 0);
+            while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
+            wave_sync();
+            if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));      // PU 3 is decided: the partner may go on too
+            const int mine = on & (l == W2.pu_mode[3]);
+            stream_seg_R<false>(range, cx, q, l, blk, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+            if (mine) { q.range_out[l] = range; SM.nxn_lane = l; }
+            if (l == 0) { lds_st_i32(&SM.pipe_a, 0); lds_st_i32(&SM.pipe_b, 0); }
+        }
+        split_flag(&q.rdone, q);
+#ifndef IMCVT_HOSTEMU
+        if (F.prio_base) SETPRIO(2); else SETPRIO(0);
+#endif
+        return;
+    }
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         const int nh = W.tokn[ll];
@@ -423,6 +555,51 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
 #endif
 }
 
+// partner of the pipe wave: the byte half of the 35 speculative NxN streams; the lane that guessed PU 3's mode holds the trial's result
+HDN void partner_pipe() {
+    PartnerMem &X = XM(PIPE_WAVE); SplitQ &q = X.q;
+    WaveMem &W = PM;
+    const WaveMem &W2 = WM(2);
+    const u16 *tok2 = wave_tok(F.sc, 2);
+    const u16 *kept = tok2 + (size_t)NMODE * TOK_CAP + NXN_KEEP;
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
+    const RdW rw = rd_weights(F.job.q);
+    while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
+    wave_sync();
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        const int nh = W.tokn[ll];
+        u8 *gbuf = ubytes + (size_t)(PIPE_WAVE * NMODE + ll) * TRIAL_BYTES;
+        const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
+        Arith a = SM.entry_a[2];
+        const int len0 = arith_len(a);
+        RingSink sink; sink.ring = X.lm[ll].ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+        int blk = 0;
+        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, on ? nh : 0);
+        const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
+        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, on ? n012 : 0);
+        split_await(&q.mid, q);                         // PU 3 is decided (its winner's tokens are in memory)
+        const int mine = on & (l == W2.pu_mode[3]);
+        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, mine ? W2.pu_cnt[3] : 0);
+        if (mine) ring_finish(sink, a.cnt);
+        const int ovf = mine & (sink.ovf != 0);
+        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — the winning lane's bytes again on the safe path (scratch contexts: the owner's are final already)
+            if (ovf) { a = SM.entry_a[2]; ctx_copy(X.cx[ll], SM.entry_cx[2]); }
+            Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
+            stream_seg_safe(a, X.cx[ll], ss, hdr, ovf ? nh : 0);
+            stream_seg_safe(a, X.cx[ll], ss, kept, ovf ? n012 : 0);
+            stream_seg_safe(a, X.cx[ll], ss, kept + 3 * NXN_KEEP_STRIDE, ovf ? W2.pu_cnt[3] : 0);
+        }
+        split_await(&q.rdone, q);
+        if (mine) {
+            a.range = q.range_out[l];
+            W.fin[0] = pack_arith(a);
+            WM(2).nxn_cost = rd_cost(rw, W2.pu_sse[0] + W2.pu_sse[1] + W2.pu_sse[2] + W2.pu_sse[3], arith_len(a) - len0);
+        }
+    }
+    split_flag(&q.done, q);
+}
+
 // ---- the winner's reconstruction (only the winner's is ever needed, so candidates do not store theirs): the winning
 // 2Nx2N shape is run once more, writing the tile.  All waves call this; wave 0 works.
 HDN void rebuild_winner(int kind_, int mode_, int N_, int y0_, int x0_, int avm_) {
@@ -457,7 +634,12 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES_ALL(w) {
-        if (w >= NWAVES && N < 16) nxn_pipe(y0, x0);
+        if (w >= NWAVES && N < 16) {
+            if (w == PIPE_WAVE) nxn_pipe(y0, x0);
+            else if (w == PIPE_WAVE + 1 || w == PIPE_WAVE + 2) partner_trial(w - (PIPE_WAVE + 1), depth);      // partner wavefronts of a wide workgroup: 4, 5 the trial coders of waves 0, 1 ...
+            else if (w == PIPE_WAVE + 3) partner_pu();                                                           // ... 6 the PU pricing of wave 2, 7 the pipe wave's streams
+            else partner_pipe();
+        }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else eval_NxN(2, y0, x0, avm);
     }
@@ -1131,7 +1313,8 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;

@@ -21,7 +21,7 @@
 #ifndef KERNEL_MIN_WAVES
 #define KERNEL_MIN_WAVES 3          // waves per SIMD the register budget is cut for: 3 = 168 registers (four 192-thread or three 256-thread workgroups per compute unit)
 #endif
-__global__ __launch_bounds__(WG_THREADS_PIPE, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
+__global__ __launch_bounds__(WG_THREADS_WIDE, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
                                                                  TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk) {
     KArgs A;
@@ -53,6 +53,7 @@ struct imcvt_hevc_ctx {
     int pipe = -1, pipe_wg = 0, last_pipe = 0;   // pipe wave (256-thread workgroups): < 0 whenever the launch fits pipe_wg workgroups (3 per CU), 0 never, 1 as -1 (forced on where it fits)
     int occ_wg = 0, occ_pipe = 0;           // workgroups per compute unit the HIP occupancy API reports for 192- / 256-thread workgroups of this kernel
     int census_wg = 0, census_pipe = 0;     // workgroups of a max_wg / pipe_wg launch that were resident at once when the context was created (0: not measured)
+    int wide = -1, wide_wg = 0, occ_wide = 0, last_wide = 0;   // wide workgroups (512 threads: pipe wave + four partner wavefronts, one workgroup per compute unit): < 0 whenever a pipe-wave launch fits wide_wg workgroups, 0 never, 1 as -1
     int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
 };
 
@@ -97,8 +98,9 @@ static int pool_limit(int nmains, int nhelp, int kind) {
     return v > 1 ? v : 1;
 }
 // pipe: the workgroups carry a fourth wavefront (hevc_frame.h nxn_pipe) and its LDS slice; three such workgroups fit a CU
+// pipe 2: wide workgroups (512 threads: pipe wave + four partner wavefronts and their record queues), one per compute unit
 static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0) {
-    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(pipe ? WG_THREADS_PIPE : WG_THREADS), pipe ? PIPE_LDS_BYTES : 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
+    hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(pipe >= 2 ? WG_THREADS_WIDE : pipe ? WG_THREADS_PIPE : WG_THREADS), pipe >= 2 ? WIDE_LDS_BYTES : pipe ? PIPE_LDS_BYTES : 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
                        (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
                        c->post16 >= 0 ? c->post16 : pool_split(nmains, nhelp, 0), c->post32 >= 0 ? c->post32 : pool_split(nmains, nhelp, 1),
                        c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1), c->d_fclk);
@@ -134,6 +136,11 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     // launch below (the API has been seen one block high for some register counts).
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_wg, hevc_encode_frames, WG_THREADS, 0) != hipSuccess || c->occ_wg < 1) { (void)hipGetLastError(); c->occ_wg = 4; }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_pipe, hevc_encode_frames, WG_THREADS_PIPE, PIPE_LDS_BYTES) != hipSuccess || c->occ_pipe < 1) { (void)hipGetLastError(); c->occ_pipe = 3; }
+    // wide workgroups: static + dynamic LDS exceed the 64 KB a kernel gets without asking
+    if (hipFuncSetAttribute((const void *)hevc_encode_frames, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) != hipSuccess
+        || hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_wide, hevc_encode_frames, WG_THREADS_WIDE, WIDE_LDS_BYTES) != hipSuccess || c->occ_wide < 1) { (void)hipGetLastError(); c->occ_wide = 0; }
+    c->wide_wg = max_workgroups > 0 ? 0 : c->occ_wide * prop.multiProcessorCount;      // (a context with an explicit workgroup budget plans without them)
+    if (const char *e = getenv("IMCVT_HEVC_WIDE")) c->wide = atoi(e);
     c->max_wg = max_workgroups > 0 ? max_workgroups : c->occ_wg * prop.multiProcessorCount;
     if (const char *e = getenv("IMCVT_HEVC_TEAM")) imcvt_hevc_set_team(c, atoi(e));      // clamped to 0..3 like the API call
     if (const char *e = getenv("IMCVT_POOL_POST16")) c->post16 = atoi(e);
@@ -211,6 +218,14 @@ extern "C" void imcvt_hevc_set_frame_clock(imcvt_hevc_ctx *c, unsigned long long
 extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
 extern "C" void imcvt_hevc_set_pipe(imcvt_hevc_ctx *c, int mode) { if (c) c->pipe = mode; }
 extern "C" int imcvt_hevc_last_pipe(imcvt_hevc_ctx *c) { return c ? c->last_pipe : IMCVT_ERR_ARG; }
+extern "C" void imcvt_hevc_set_wide(imcvt_hevc_ctx *c, int mode) { if (c) c->wide = mode; }
+extern "C" int imcvt_hevc_last_wide(imcvt_hevc_ctx *c) { return c ? c->last_wide : IMCVT_ERR_ARG; }
+// pure: a launch of `grid` workgroups that runs with the pipe wave runs wide workgroups when every one of them gets a compute unit of
+// its own with a sixteenth of the `wide_wg` resident 512-thread workgroups to spare (a forced shape may fill the last one)
+extern "C" int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape) {
+    if (!use_pipe || grid < 1 || wide_wg < 1) return 0;
+    return grid <= (forced_shape ? wide_wg : wide_wg - wide_wg / 16) ? 1 : 0;
+}
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) {
     if (!c) return IMCVT_ERR_ARG;
@@ -351,8 +366,9 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     c->last_mains = nmains; c->last_help = nhelp;
     c->last_pipe = use_pipe;
+    c->last_wide = c->wide != 0 ? imcvt_hevc_plan_wide(use_pipe, grid, c->wide_wg, forced) : 0;
     HIPCHK(hipEventRecord(c->ev0, stream));
-    launch(c, grid, stream, n, mode, nmains, nhelp, c->last_pipe);
+    launch(c, grid, stream, n, mode, nmains, nhelp, c->last_wide ? 2 : c->last_pipe);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;

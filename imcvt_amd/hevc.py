@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
+           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
            "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats")
 
 
@@ -85,6 +85,13 @@ def load_library():
     lib.imcvt_hevc_set_pipe.argtypes = [C.c_void_p, C.c_int]
     lib.imcvt_hevc_last_pipe.restype = C.c_int
     lib.imcvt_hevc_last_pipe.argtypes = [C.c_void_p]
+    if hasattr(lib, "imcvt_hevc_set_wide"):             # (absent only from older builds loaded through IMCVT_HEVC_LIB for A/B runs)
+        lib.imcvt_hevc_set_wide.restype = None
+        lib.imcvt_hevc_set_wide.argtypes = [C.c_void_p, C.c_int]
+        lib.imcvt_hevc_last_wide.restype = C.c_int
+        lib.imcvt_hevc_last_wide.argtypes = [C.c_void_p]
+        lib.imcvt_hevc_plan_wide.restype = C.c_int
+        lib.imcvt_hevc_plan_wide.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.imcvt_hevc_last_team.restype = C.c_int
     lib.imcvt_hevc_last_team.argtypes = [C.c_void_p, _ip]
     lib.imcvt_hevc_batch_devices.restype = C.c_int
@@ -218,6 +225,15 @@ class DeviceEncoder:
     def set_pipe(self, mode: int):
         """Pipe wave (256-thread workgroups, the NxN trial of the 8x8 CUs off the PU chain): < 0 / 1 = whenever the launch fits three workgroups per CU, 0 = never (same results)."""
         self.lib.imcvt_hevc_set_pipe(self.ctx, int(mode))
+
+    def set_wide(self, mode: int):
+        """Wide workgroups (512 threads, split trial coders): -1 automatic, 0 never, 1 wherever they fit.  Results are identical."""
+        if hasattr(self.lib, "imcvt_hevc_set_wide"):
+            self.lib.imcvt_hevc_set_wide(self.ctx, int(mode))
+
+    def last_wide(self) -> bool:
+        """True if the last launch ran wide workgroups."""
+        return hasattr(self.lib, "imcvt_hevc_last_wide") and int(self.lib.imcvt_hevc_last_wide(self.ctx)) == 1
 
     def last_pipe(self) -> bool:
         """True if the last launch ran with the pipe wave."""

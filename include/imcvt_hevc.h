@@ -114,6 +114,16 @@ void imcvt_hevc_set_team(imcvt_hevc_ctx *ctx, int team_size);
 void imcvt_hevc_set_pipe(imcvt_hevc_ctx *ctx, int mode);
 /* 1 if the last launch ran with the pipe wave, else 0. */
 int imcvt_hevc_last_pipe(imcvt_hevc_ctx *ctx);
+/* Wide workgroups (512 threads: the pipe wave and four partner wavefronts, each running the byte half of the trial coders whose
+ * range half its owner wavefront runs, hevc_core.h stream_seg_R / stream_seg_L; one workgroup per compute unit).  mode < 0
+ * (default): whenever a pipe-wave launch leaves every workgroup a compute unit of its own; 0: never; 1: as < 0.  Results are
+ * identical.  Environment override at context creation: IMCVT_HEVC_WIDE. */
+void imcvt_hevc_set_wide(imcvt_hevc_ctx *ctx, int mode);
+/* 1 if the last launch ran wide workgroups, else 0. */
+int imcvt_hevc_last_wide(imcvt_hevc_ctx *ctx);
+/* Pure: does a launch of `grid` workgroups that runs with the pipe wave (use_pipe) run wide workgroups, given `wide_wg` resident
+ * 512-thread workgroups (occupancy x compute units)?  A sixteenth of them stays free unless the shape is forced. */
+int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape);
 /* That choice as a pure function (no device needed), applied to the shape imcvt_hevc_plan returned (mode = its return value; *nmains,
  * *nhelp = its outputs): returns 1 if the launch runs 256-thread workgroups with the pipe wave — it does when it fits 15/16 of three
  * workgroups per compute unit (max_workgroups * 3 / 4), and a pool that misses that by little gives up helpers for it (*nhelp is

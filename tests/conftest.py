@@ -82,6 +82,19 @@ def hostemu_pipe_ovf(built):
 
 
 @pytest.fixture(scope="session")
+def hostemu_wide(built):
+    """Same, with 512-thread workgroups: pipe wave + four partner wavefronts, each running the byte half of the trial coders whose
+    range half its owner runs (hevc_core.h stream_seg_R / stream_seg_L; hevc_frame.h partner_trial / partner_pu / partner_pipe)."""
+    return _hostemu_lib("libhostemu_wide.so", ["-DEMU_DEFAULT_WIDE"])
+
+
+@pytest.fixture(scope="session")
+def hostemu_wide_ovf(built):
+    """Wide workgroups + every rare-path byte overflows the byte rings: the partners' safe-path repeats."""
+    return _hostemu_lib("libhostemu_wide_ovf.so", ["-DEMU_DEFAULT_WIDE", "-DIMCVT_FORCE_OVF"])
+
+
+@pytest.fixture(scope="session")
 def hostemu_abn(built):
     """Same, with main workgroups that stop waiting for a helper's answer after three polls: exercises the path on which a late
     answer is abandoned, the CU evaluated by the main workgroup itself and the mailbox left alone until the answer has arrived."""

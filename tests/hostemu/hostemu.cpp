@@ -17,8 +17,10 @@ asm(".text\n.globl emu_ctx_switch\n.type emu_ctx_switch,@function\nemu_ctx_switc
     "  movq %rsp,(%rdi)\n  movq %rsi,%rsp\n"
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n");
 
-#define EMU_WG_THREADS_MAX 256                              // 192, or 256 when the workgroups carry a pipe wave (hostemu_set_pipe)
-#ifdef EMU_DEFAULT_PIPE
+#define EMU_WG_THREADS_MAX 512                              // 192, 256 when the workgroups carry a pipe wave (hostemu_set_pipe), 512 when they are wide (pipe wave + four partner wavefronts)
+#if defined(EMU_DEFAULT_WIDE)
+static int g_wg_threads = 512;
+#elif defined(EMU_DEFAULT_PIPE)
 static int g_wg_threads = 256;
 #else
 static int g_wg_threads = 192;
@@ -35,7 +37,7 @@ static EmuFiber g_fib[EMU_THREADS];
 static void *g_main_sp;
 static int g_cur;                                           // running fiber (= blockIdx.x * 192 + threadIdx.x)
 static int g_nfib = 192;                                    // fibers of this run (192 or 256 per workgroup)
-static unsigned g_wave_gen[4 * EMU_MAX_WG], g_wave_arr[4 * EMU_MAX_WG], g_wg_gen[EMU_MAX_WG], g_wg_arr[EMU_MAX_WG];
+static unsigned g_wave_gen[8 * EMU_MAX_WG], g_wave_arr[8 * EMU_MAX_WG], g_wg_gen[EMU_MAX_WG], g_wg_arr[EMU_MAX_WG];
 static uint64_t g_xchg[EMU_THREADS];                        // collective exchange slots
 static void (*g_entry)(void);
 static unsigned g_yield_gen;                                // a yielding fiber is runnable again at once
@@ -80,7 +82,7 @@ static int emu_shfl(int v, int src_lane) {                  // value of `v` held
 }
 // Matrix instructions (wave collectives): every lane deposits its operand registers, then computes the result registers
 // the hardware would hand it.  Layouts as verified on the device by tools/mfma_probe.hip.
-static uint32_t g_mx[4 * EMU_MAX_WG][64][8];                // per lane: a[0..3], b[0..3]
+static uint32_t g_mx[8 * EMU_MAX_WG][64][8];                // per lane: a[0..3], b[0..3]
 static long g_mfma_calls[2];                                // wave-level matrix instructions issued so far (32x32x32, 16x16x32)
 static int emu_sx8(uint32_t w, int k) { return (int)(int8_t)(w >> (8 * k)); }
 // v_mfma_i32_32x32x32_i8: lane l holds A[l%32][16*(l/32) .. +15], B[16*(l/32) .. +15][l%32]; acc r: D[8*(r/4) + 4*(l/32) + r%4][l%32]
@@ -117,6 +119,7 @@ struct Shm;
 static Shm *g_shm_of[EMU_MAX_WG];                          // each emulated workgroup's LDS image
 static unsigned char *g_pipe_of[EMU_MAX_WG];               // ... and its dynamic part (the pipe wave's slice)
 static int emu_pipe_on() { return g_wg_threads > 192; }
+static int emu_wide_on() { return g_wg_threads >= 512; }
 static long g_spins;
 static void emu_set_shm(int wg);                            // (defined below, next to the device source's LDS pointer)
 static void emu_trampoline() {
@@ -187,7 +190,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     Scratch sc[EMU_MAX_WG]; void *pool[EMU_MAX_WG];
     for (int b = 0; b < nwg; b++) {
         g_shm_of[b] = (Shm *)calloc(1, sizeof(Shm));
-        g_pipe_of[b] = (unsigned char *)aligned_alloc(16, PIPE_LDS_BYTES); memset(g_pipe_of[b], 0xA5, PIPE_LDS_BYTES);      // (LDS is not zeroed on the device either)
+        g_pipe_of[b] = (unsigned char *)aligned_alloc(16, WIDE_LDS_BYTES); memset(g_pipe_of[b], 0xA5, WIDE_LDS_BYTES);      // (LDS is not zeroed on the device either)
         pool[b] = calloc(1, scratch_bytes_per_wg());
         scratch_carve(sc[b], (u8 *)pool[b]);
     }
@@ -218,6 +221,9 @@ extern "C" int hostemu_HEVCImageEncoderPool(int n, unsigned char *const *pbuffer
 }
 // 1: the emulated workgroups have 256 threads, the fourth wavefront being the pipe wave (hevc_frame.h nxn_pipe); 0: 192 threads
 extern "C" void hostemu_set_pipe(int on) { g_wg_threads = on ? 256 : 192; }
+// 2: wide workgroups (512 threads: pipe wave + four partner wavefronts, the trial coders of the 8x8 CUs split over two wavefronts each)
+extern "C" void hostemu_set_threads(int n) { g_wg_threads = n >= 512 ? 512 : n >= 256 ? 256 : 192; }
+extern "C" int hostemu_wide_lds_bytes(void) { return (int)WIDE_LDS_BYTES; }
 extern "C" long hostemu_mfma_calls(int kind) { return g_mfma_calls[kind & 1]; }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
 extern "C" int hostemu_pipe_lds_bytes(void) { return (int)PIPE_LDS_BYTES; }

@@ -94,6 +94,24 @@ def test_pipe_wave_ring_overflow_path_matches_golden(hostemu_pipe_ovf, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+@pytest.mark.parametrize("e", PIPE_PICK, ids=kat_id)
+def test_wide_workgroup_matches_golden(hostemu_wide, e):
+    # 512-thread workgroups: every trial coder of an 8x8 CU (one-TU and four-TU candidate sets, PU pricing, the pipe wave's NxN
+    # streams) runs as a range half and a byte half on two wavefronts joined by a record queue in LDS — concurrent fibers here
+    stream, rcon = emu_encode(hostemu_wide, kat_input(e["input"]), e["qpd6"])
+    assert len(stream) == e["bytes"]
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_wide_workgroup_ring_overflow_path_matches_golden(hostemu_wide_ovf, e):
+    # a byte half whose ring overflowed repeats its lane's stream with the plain coder on scratch contexts (the owner's contexts are final)
+    stream, rcon = emu_encode(hostemu_wide_ovf, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
 def _extreme_pictures():
     rng = np.random.default_rng(1)
     pics = {"bw_noise": rng.integers(0, 2, (32, 64), dtype=np.uint8) * 255, "noise": rng.integers(0, 256, (32, 64), dtype=np.uint8)}
@@ -216,6 +234,18 @@ def test_pipe_wave_with_and_without_helpers(hostemu_pipe, q, nmains, nhelp):
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
 
 
+@pytest.mark.parametrize("nmains,nhelp", [(1, 2), (2, 1), (2, 0)])
+@pytest.mark.parametrize("q", [0, 4])
+def test_wide_workgroups_with_and_without_helpers(hostemu_wide, q, nmains, nhelp):
+    """Wide workgroups as main and helper workgroups of a pool (the helpers' 16x16 / 32x32 trial coders run split over two wavefronts
+    too) and as plain frame-per-workgroup launches pulling several frames each: the reference's bytes."""
+    es = [e for e in OVF if e["qpd6"] == q]
+    res = emu_encode_pool(hostemu_wide, [kat_input(e["input"]) for e in es], q, nmains, nhelp)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
 @pytest.mark.parametrize("nmains,nhelp", [(1, 1), (2, 2), (4, 1)])
 @pytest.mark.parametrize("q", [0, 3])
 def test_abandoned_answers_are_recomputed_by_the_main_workgroup(hostemu_abn, q, nmains, nhelp):
@@ -275,3 +305,5 @@ def test_lds_budget(hostemu):
     # four 192-thread workgroups per CU, or three 256-thread ones with the pipe wave's dynamic slice
     assert 4 * hostemu.hostemu_shm_bytes() <= 160 * 1024
     assert 3 * (hostemu.hostemu_shm_bytes() + hostemu.hostemu_pipe_lds_bytes()) <= 160 * 1024
+    # one 512-thread wide workgroup per CU with the partner wavefronts' record queues
+    assert hostemu.hostemu_shm_bytes() + hostemu.hostemu_wide_lds_bytes() <= 160 * 1024
