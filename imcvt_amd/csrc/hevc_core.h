@@ -473,7 +473,7 @@ static Shm *g_shm_host;
 __shared__ Shm g_shm;
 #define SM g_shm
 #endif
-#define WM(w) (*(WaveMem *)(SM.wraw + (w) * sizeof(WaveMem)))
+#define WM(w) (*(WaveMem *)wave_mem_ptr(w))
 // The pipe wave's slice (a WaveMem cut off after the trial coders' extent) is dynamic LDS: only 256-thread launches pay for it.
 #define PIPE_UNION_BYTES 5120
 #define PIPE_LDS_BYTES ((sizeof(WaveMem) - 7168 + PIPE_UNION_BYTES + 15) & ~(size_t)15)
@@ -498,17 +498,37 @@ struct alignas(16) SplitQ {
     i32 range_out[NMODE];                        // the range each lane's coder ended with
     i32 go, mid, rdone, done;                    // generation started by the owner / whose last segment may start (pipe wave) / whose ranges are final / finished by the partner
 };
+#ifndef LEADS_CAP
+#define LEADS_CAP 32                             // byte leads a PU candidate's stream may queue before its lane takes the safe path (~60 tokens: 8 - 10 leads)
+#endif
+#define LEADS_STRIDE ((LEADS_CAP + 2) | 2)             // u16 per lane: 17 dwords (odd: the lanes' lists start in different banks); slot LEADS_CAP is the dump slot
 struct alignas(16) PartnerMem {
     SplitQ q;
     alignas(16) LaneMem lm[NMODE];               // byte rings + lead queues of the byte half
     alignas(4) u8 cx[NMODE][CTX_STRIDE];         // context scratch of its safe path (ring overflow)
+    alignas(4) u16 leads[NMODE][LEADS_STRIDE];   // PU pricing: every lead of a candidate's stream, turned into bytes once at the end (stream_seg_L1 / leads_count)
 };
-#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem))
+// Control words of a wide workgroup's 8x8 CUs, and the LDS slices of the two partner wavefronts that LEND themselves for pipeline passes
+// (hevc_frame.h lend_passes: the one-TU candidate set's three passes of an 8x8 CU run on three wavefronts at once).
+#define NLEND 2
+struct alignas(16) WideCtl {
+    i32 a_go, lend_done[NLEND];                  // one-TU set: generation whose headers are in place / finished by each lender
+    i32 b_seg, b_cons;                           // four-TU set: token segments (header + TU 0, TU 1, TU 2, TU 3) complete so far / coded so far, counted over the frame
+    i32 seg_end[4][NMODE];                       // ... and where each candidate's segment ends in its stream (a segment starts on a token-block boundary)
+};
+#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem))
 #ifdef IMCVT_HOSTEMU
-#define XM(i) (*(PartnerMem *)(g_pipe_host + PIPE_LDS_BYTES + (i) * sizeof(PartnerMem)))
+#define DYN_LDS g_pipe_host
 #else
-#define XM(i) (*(PartnerMem *)(g_pipe_lds + PIPE_LDS_BYTES + (i) * sizeof(PartnerMem)))
+#define DYN_LDS g_pipe_lds
 #endif
+#define XM(i) (*(PartnerMem *)(DYN_LDS + PIPE_LDS_BYTES + (i) * sizeof(PartnerMem)))
+#define WCTL (*(WideCtl *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem)))
+#define LEND_WAVE0 (PIPE_WAVE + 1)               // wave 4 lends with slice 0, wave 7 with slice 1
+#define LEND_WAVE1 (PIPE_WAVE + 4)
+HD u8 *wave_mem_ptr(int w) {                     // a wavefront's WaveMem: waves 0..2 in the static image, the lenders' in the dynamic part (wide workgroups only)
+    return w < NWAVES ? SM.wraw + w * sizeof(WaveMem) : (u8 *)DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + (w == LEND_WAVE0 ? 0 : 1) * sizeof(WaveMem);
+}
 HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
 HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }
 
@@ -2329,6 +2349,71 @@ HD void stream_seg_R(int &range, u8 *cx, SplitQ &q, int lane, int &blk, const u1
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(nv) : : "memory");
         cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
 #endif
+    }
+}
+// Byte half when only the LENGTH of the stream is wanted and the stream is short (the pricing of a PU's candidates, :1504-1518: the
+// bytes are never read, ~60 tokens leave 8 - 10 bytes): low and the bit position per token as in token_L, every lead appended to
+// ONE list per lane; the byte-level logic (:863-878, :820-831 — it decides how many bytes the stream has, emulation prevention
+// included) then runs once over the list (leads_count) instead of once per token block.  `qn` counts the leads (beyond LEADS_CAP they
+// land in the dump slot: the caller prices that lane on the safe path).
+HD void stream_seg_L1(Arith &a, u16 *leads, int &qn, SplitQ &q, int lane, int &blk, int n) {
+    const int ql = lane < NMODE ? lane : 0;
+    const u32 *const row = q.rec[ql];
+    int prod_seen = 0;
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        if (k0 < n) {
+            while (WAVE_ANY(prod_seen <= blk)) { if (prod_seen <= blk) { prod_seen = lds_ld_i32(&q.prod[ql]); if (prod_seen <= blk) pipe_pause(); } }
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            const u32 *sp = row + (blk & (QDEPTH - 1)) * 8;
+            u32 rec[8];
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) rec[j] = sp[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            blk++;
+            lds_st_i32(&q.cons[ql], blk);
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) {
+                const u32 r = rec[j];
+                const int add = (int)(r & 511u), rg = (int)((r >> 9) & 511u), nb_ = (int)((r >> 18) & 15u), val = (int)(r >> 22);
+                a.low = ((a.low + add) << nb_) + mul24(rg, val);
+                a.nbits -= nb_;
+                const int need = a.nbits < 12;
+                leads[qn < LEADS_CAP ? qn : LEADS_CAP] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));      // always written; only kept when `need`
+                qn += need;
+                a.nbits += need ? 8 : 0;
+                a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
+            }
+        }
+    }
+}
+struct CountSink { int dummy; };                 // bytes are counted (a.cnt), not kept
+HD void sink_put(CountSink &, int, int) {}
+HD int sink_room(CountSink &, int) { return 1; }
+// the byte-level logic over a lane's whole lead list: a.cnt / nbytes / bufbyte / zeros end as if the bytes had been emitted token by token
+HD void leads_count(Arith &a, const u16 *leads, int qn) {
+    CountSink cs; cs.dummy = 0;
+    NOUNROLL
+    for (int i0 = 0; WAVE_ANY(i0 < qn); i0 += 8) {
+        u32 lqw[4];
+        for (int d = 0; d < 4; d++) lqw[d] = *(const u32a *)&leads[i0 + 2 * d];
+        UNROLL_FULL
+        for (int i = 0; i < 8; i++) {
+            if (!WAVE_ANY(i0 + i < qn)) break;
+            const int act = i0 + i < qn;
+            const int lead = (int)((i & 1) ? lqw[i >> 1] >> 16 : lqw[i >> 1] & 0xFFFFu);
+            const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
+            const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
+            a.cnt += fast;
+            a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
+            a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
+            const int rare = act & !fast;
+            if (WAVE_ANY(rare)) { if (rare) carry_rare(a, cs, lead); }
+        }
     }
 }
 // Byte half: consumes the records of n tokens of this lane.  Same trip count as the owner's stream_seg_R (same n).

@@ -156,11 +156,11 @@ HDN void partner_pu() {
             Arith a; arith_reset(a);
             const int n = on ? W.tokn[ll] - 8 : 0;
             u8 *gbuf = ubytes + (size_t)(2 * NMODE + ll) * TRIAL_BYTES;
-            RingSink sink; sink.ring = X.lm[ll].ring; sink.gbuf = gbuf; sink.c0 = 0; sink.fl = 0; sink.ovf = 0;
-            int blk = 0;
-            stream_seg_L(a, &X.lm[ll], sink, q, l, blk, n);
-            const int ovf = sink.ovf;
-            if (WAVE_ANY(ovf)) {
+            int blk = 0, qn = 0;
+            stream_seg_L1(a, X.leads[ll], qn, q, l, blk, n);            // low and bit position per token, the leads on one list ...
+            const int ovf = qn > LEADS_CAP;
+            leads_count(a, X.leads[ll], ovf ? 0 : qn);                  // ... the byte-level logic once, at the end (the bytes themselves are never read, :1518)
+            if (WAVE_ANY(ovf)) {                                        // a stream with more leads than the list holds: that lane again, by the plain coder
                 if (ovf) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
                 stream_run_safe(a, X.cx[ll], gbuf, tok + (size_t)ll * TOK_CAP + 8, ovf ? n : 0);
             }
@@ -168,6 +168,81 @@ HDN void partner_pu() {
         }
         split_flag(&q.done, q);
     }
+}
+// A lender wavefront (wide workgroups): candidates lo .. hi-1 of the one-TU set of the 8x8 CU at (y0, x0), exactly as wave 0 runs its own
+// (eval_2Nx2N: same border, same pass, tokens / counts / SSE into wave 0's arrays and streams) on this wavefront's own slice.
+HDN void lend_passes(int wave_, int li_, int lo_, int hi_, int y0_, int x0_, int avm_) {
+    const int wave = uni_i(wave_); const int li = uni_i(li_); const int lo = uni_i(lo_); const int hi = uni_i(hi_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
+    WideCtl &C = WCTL;
+    while (lds_ld_i32(&C.a_go) == lds_ld_i32(&C.lend_done[li])) pipe_pause();
+    wave_sync();                                        // the candidates' headers are in memory, their counts in place
+    const Avail av = unpack_avail(avm);
+    border_from_tile(wave, 8, y0, x0, av.l, av.bl, av.a, av.ar);
+    P1Args P;
+    P.q = F.job.q; P.only_mode = -1; P.hint = 0; P.own = 0; P.c_lo = lo; P.c_hi = hi; P.shape = 0; P.tok = wave_tok(F.sc, 0);
+    P.N = 8; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
+    p1_run_t<3>(wave, P);
+    wave_sync();                                        // the tokens are in memory
+    LANES(l) { if (l == 0) lds_st_i32(&C.lend_done[li], lds_ld_i32(&C.a_go)); }
+}
+// four-TU set of an 8x8 CU in a wide workgroup: a token segment (header + TU 0, then one per TU) is complete — note where it ends in every
+// candidate's stream, start the next one on a token-block boundary (the gap holds idle tokens, which leave coder and contexts untouched),
+// and tell the coder wavefront (partner_fourtu)
+HD void seg_close(WaveMem &W, int k) {
+    WideCtl &C = WCTL;
+    LANES(l) {
+        if (l < NMODE) {
+            C.seg_end[k][l] = W.tokn[l];
+            if (k < 3) { W.tokn[l] = (W.tokn[l] + 7) & ~7; blk_idle((u32a *)W.pend[l]); }
+        }
+    }
+    wave_sync();                                        // the segment is in memory
+    LANES(l) { if (l == 0) lds_st_i32(&C.b_seg, lds_ld_i32(&C.b_seg) + 1); }
+}
+// ... whose 35 trial coders run on wave 5 WHILE wave 1 still works on the later TUs: segment by segment on one byte sink each (as the pipe
+// wave codes its stream, stream_seg), contexts in this wavefront's own scratch (wave 1's pass buffer is busy), copied over at the end.
+HDN void partner_fourtu(int depth_) {
+    const int depth = uni_i(depth_);
+    PartnerMem &X = XM(1);
+    WideCtl &C = WCTL;
+    WaveMem &W = WM(1);
+    const RdW rw = rd_weights(F.job.q);
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
+    const u16 *tok = wave_tok(F.sc, 1);
+    const int base = lds_ld_i32(&C.b_cons);
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        Arith a = SM.entry_a[depth];
+        const int len0 = arith_len(a);
+        u8 *cx = X.cx[ll]; LaneMem *lm = &X.lm[ll];
+        u8 *gbuf = ubytes + (size_t)(1 * NMODE + ll) * TRIAL_BYTES;
+        const u16 *ts = tok + (size_t)ll * TOK_CAP;
+        if (on) ctx_copy(cx, SM.entry_cx[depth]);
+        RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
+        int from = 0;
+        for (int k = 0; k < 4; k++) {
+            while (lds_ld_i32(&C.b_seg) - base <= k) pipe_pause();
+            wave_sync();
+            const int end = C.seg_end[k][ll];
+            stream_seg(a, cx, lm, sink, ts + from, on ? end - from : 0);
+            from = (end + 7) & ~7;
+        }
+        if (on) ring_finish(sink, a.cnt);
+        const int ovf = on & (sink.ovf != 0);
+        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — the lane's stream again on the safe path
+            if (ovf) { a = SM.entry_a[depth]; ctx_copy(cx, SM.entry_cx[depth]); }
+            Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
+            int f2 = 0;
+            for (int k = 0; k < 4; k++) { const int end = C.seg_end[k][ll]; stream_seg_safe(a, cx, ss, ts + f2, ovf ? end - f2 : 0); f2 = (end + 7) & ~7; }
+        }
+        if (on) {
+            W.fin[l] = pack_arith(a);
+            W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
+            ctx_copy(W.u.p2.cx[l], cx);                 // (wave 1 finished its last pass before it released the last segment: its pass buffer is free)
+        }
+    }
+    wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32(&C.b_cons, base + 4); }
 }
 #ifndef SPL32_0
 #define SPL32_0 23
@@ -208,9 +283,10 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
             }
         }
     }
-    if (big) wg_sync_p(); else wave_sync_lds();         // wave 2 starts from the owners' header counts
+    const int wide8 = F.wide && !big;                   // 8x8 CU of a wide workgroup: two partner wavefronts take passes of the one-TU set, the four-TU set is coded segment by segment by wave 5
+    if (big) wg_sync_p(); else if (wide8 && wave == 0) { wave_sync(); LANES(l) { if (l == 0) lds_st_i32(&WCTL.a_go, lds_ld_i32(&WCTL.a_go) + 1); } } else wave_sync_lds();         // wave 2 / the lenders start from the owners' header counts
     P1Item it[2]; int nit = 1;
-    if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = NMODE; }
+    if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = (wide8 && wave == 0) ? 16 : NMODE; }
     else if (wave < 2) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = split_mode(N, wave); }
     else { nit = 2; for (int i = 0; i < 2; i++) { it[i].own = i; it[i].shape = i; it[i].lo = split_mode(N, i); it[i].hi = NMODE; } }
     P1Args P;
@@ -221,7 +297,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
         P.own = it[ii].own; P.c_lo = it[ii].lo; P.c_hi = it[ii].hi; P.shape = shape; P.tok = wave_tok(F.sc, it[ii].own);
         const int ntu = (shape == 0) ? 1 : 4;
         int k_first = 0;
-        if (TU0_SHARE && N == 8 && shape == 1) { tu0_from_pu0(wave, P.tok); k_first = 1; }      // TU 0 = the PU wave's PU 0
+        if (TU0_SHARE && N == 8 && shape == 1) { tu0_from_pu0(wave, P.tok); k_first = 1; if (wide8) seg_close(W, 0); }      // TU 0 = the PU wave's PU 0
         for (int k = k_first; k < ntu; k++) {
             if (shape == 0) {
                 border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
@@ -234,8 +310,14 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
                 P.N = h; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
             }
             p1_run(wave, P);
+            if (wide8 && shape == 1) seg_close(W, k);
         }
     }
+    if (wide8 && wave == 0) {                           // the lenders' candidates are done: their tokens are in memory, counts and SSE in this wavefront's arrays
+        while (lds_ld_i32(&WCTL.lend_done[0]) != lds_ld_i32(&WCTL.a_go) || lds_ld_i32(&WCTL.lend_done[1]) != lds_ld_i32(&WCTL.a_go)) pipe_pause();
+        wave_sync();
+    }
+    if (wide8 && wave == 1) { prof_add(PF_P1_4, pt); return; }      // (the trial coders of this set have been running on wave 5 all along: partner_fourtu)
     prof_add(wave == 2 ? PF_P1_4 : wave == 0 ? (N == 32 ? PF_P1_32 : N == 16 ? PF_P1_16 : PF_P1_8) : (N == 32 ? PF_P1_16 : N == 16 ? PF_P1_8 : PF_P1_4), pt);
     if (big) wg_sync_p(); else wave_sync();             // the tokens are in memory
     if (wave >= 2) return;
@@ -636,9 +718,10 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     WAVES_ALL(w) {
         if (w >= NWAVES && N < 16) {
             if (w == PIPE_WAVE) nxn_pipe(y0, x0);
-            else if (w == PIPE_WAVE + 1 || w == PIPE_WAVE + 2) partner_trial(w - (PIPE_WAVE + 1), depth);      // partner wavefronts of a wide workgroup: 4, 5 the trial coders of waves 0, 1 ...
-            else if (w == PIPE_WAVE + 3) partner_pu();                                                           // ... 6 the PU pricing of wave 2, 7 the pipe wave's streams
-            else partner_pipe();
+            else if (w == LEND_WAVE0) { lend_passes(w, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }       // partner wavefronts of a wide workgroup: 4 a pass of the one-TU set, then the byte half of its trial coders
+            else if (w == PIPE_WAVE + 2) partner_fourtu(depth);                                                  // 5 the trial coders of the four-TU set, segment by segment behind wave 1's passes
+            else if (w == PIPE_WAVE + 3) partner_pu();                                                           // 6 the byte half of the PU pricing of wave 2
+            else { lend_passes(w, 1, 32, NMODE, y0, x0, avm); partner_pipe(); }                                   // 7 the last pass of the one-TU set, then the byte half of the pipe wave's streams
         }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else eval_NxN(2, y0, x0, avm);
@@ -1313,7 +1396,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.lend_done[1] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;

@@ -95,6 +95,12 @@ def hostemu_wide_ovf(built):
 
 
 @pytest.fixture(scope="session")
+def hostemu_wide_leads(built):
+    """Wide workgroups with four-entry lead lists: nearly every PU candidate's stream has more leads and is priced on the safe path."""
+    return _hostemu_lib("libhostemu_wide_leads.so", ["-DEMU_DEFAULT_WIDE", "-DLEADS_CAP=4"])
+
+
+@pytest.fixture(scope="session")
 def hostemu_abn(built):
     """Same, with main workgroups that stop waiting for a helper's answer after three polls: exercises the path on which a late
     answer is abandoned, the CU evaluated by the main workgroup itself and the mailbox left alone until the answer has arrived."""

@@ -112,6 +112,14 @@ def test_wide_workgroup_ring_overflow_path_matches_golden(hostemu_wide_ovf, e):
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
 
+@pytest.mark.parametrize("e", OVF, ids=kat_id)
+def test_wide_workgroup_lead_list_overflow_path_matches_golden(hostemu_wide_leads, e):
+    # a PU candidate whose stream queues more leads than its list holds is priced by the plain coder (hevc_frame.h partner_pu)
+    stream, rcon = emu_encode(hostemu_wide_leads, kat_input(e["input"]), e["qpd6"])
+    assert hashlib.sha256(stream).hexdigest() == e["sha256"]
+    assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
+
+
 def _extreme_pictures():
     rng = np.random.default_rng(1)
     pics = {"bw_noise": rng.integers(0, 2, (32, 64), dtype=np.uint8) * 255, "noise": rng.integers(0, 256, (32, 64), dtype=np.uint8)}
