@@ -510,13 +510,28 @@ struct alignas(16) PartnerMem {
 };
 // Control words of a wide workgroup's 8x8 CUs, and the LDS slices of the two partner wavefronts that LEND themselves for pipeline passes
 // (hevc_frame.h lend_passes: the one-TU candidate set's three passes of an 8x8 CU run on three wavefronts at once).
-#define NLEND 2
+#define NLEND 1
 struct alignas(16) WideCtl {
     i32 a_go, lend_done[NLEND];                  // one-TU set: generation whose headers are in place / finished by each lender
     i32 b_seg, b_cons;                           // four-TU set: token segments (header + TU 0, TU 1, TU 2, TU 3) complete so far / coded so far, counted over the frame
     i32 seg_end[4][NMODE];                       // ... and where each candidate's segment ends in its stream (a segment starts on a token-block boundary)
 };
-#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem))
+// The pass over a PU's 35 candidates split between the PU wave and its partner (wide workgroups; p1_run_4a / pu_part_b): the PU wave
+// predicts, transforms and quantises, leaves levels and prediction here and goes on with the first part of every candidate's tokens;
+// the partner makes the remaining-level tokens (rows `brow`) and the reconstruction meanwhile.
+#ifndef BROW_CAP
+#define BROW_CAP 48                              // tokens a partner row holds (a longer remaining-level part is made by the PU wave itself, the plain way); slot BROW_CAP is the dump slot
+#endif
+#define BROW_STRIDE ((BROW_CAP + 2) | 2)         // u16 per lane, an odd number of dwords
+struct alignas(16) PuX {
+    u32 lev[NMODE][13];                          // per candidate: 16 levels (i16, raster order, zero when the weak-group test cleared the block), then the prediction (16 u8)
+    alignas(4) u16 brow[NMODE][BROW_STRIDE];
+    i32 bcnt[NMODE];                             // tokens in the row (> BROW_CAP: the row overflowed)
+    i32 go, bdone;                               // generation published by the PU wave / whose rows are complete
+    // (a PU-wave lane stages at most 7 tokens + BROW_CAP of these + 8 idle ones in its 64-token row)
+};
+#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem) + sizeof(PuX))
+#define PUX (*(PuX *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem)))
 #ifdef IMCVT_HOSTEMU
 #define DYN_LDS g_pipe_host
 #else
@@ -524,10 +539,17 @@ struct alignas(16) WideCtl {
 #endif
 #define XM(i) (*(PartnerMem *)(DYN_LDS + PIPE_LDS_BYTES + (i) * sizeof(PartnerMem)))
 #define WCTL (*(WideCtl *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem)))
-#define LEND_WAVE0 (PIPE_WAVE + 1)               // wave 4 lends with slice 0, wave 7 with slice 1
-#define LEND_WAVE1 (PIPE_WAVE + 4)
-HD u8 *wave_mem_ptr(int w) {                     // a wavefront's WaveMem: waves 0..2 in the static image, the lenders' in the dynamic part (wide workgroups only)
-    return w < NWAVES ? SM.wraw + w * sizeof(WaveMem) : (u8 *)DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + (w == LEND_WAVE0 ? 0 : 1) * sizeof(WaveMem);
+// Who is whose partner follows from where wavefronts run: wavefronts w and w + 4 of a workgroup share a SIMD (tools/simd_map_probe.hip,
+// profiles/r05_simd_map.log), and a SIMD serves ONE wavefront's stream of shifts / bit-field / select instructions at full speed, not two
+// (tools/valu_rate_probe.hip) — so the two halves of a chain sit on different SIMDs, and the PU chain's SIMD-mates are the wavefronts with the least to do:
+//     SIMD a: wave 0 (one-TU set)   + wave 4 (coders of the four-TU set)          SIMD c: wave 2 (PU chain)  + wave 6 (byte half of the pipe wave: idle until PU 2 is decided)
+//     SIMD b: wave 1 (four-TU set)  + wave 5 (a pass + byte half of the one-TU set) SIMD d: wave 3 (pipe wave) + wave 7 (partner of the PU chain)
+#define WAVE_B_CODER (PIPE_WAVE + 1)
+#define WAVE_A_PARTNER (PIPE_WAVE + 2)
+#define WAVE_PIPE_PARTNER (PIPE_WAVE + 3)
+#define WAVE_PU_PARTNER (PIPE_WAVE + 4)
+HD u8 *wave_mem_ptr(int w) {                     // a wavefront's WaveMem: waves 0..2 in the static image, the lender's (wave 5) in the dynamic part (wide workgroups only)
+    return w < NWAVES ? SM.wraw + w * sizeof(WaveMem) : (u8 *)DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl);
 }
 HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
 HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }
@@ -1686,6 +1708,196 @@ HD void p1_run_4(int wave, const P1Args &P) {
             if (P.only_mode < 0) W.sse[c] += part;         // this lane is the only writer of sse[c] in this pass
             MARK("b4_inverse_recon_sse");
             prof_add(threadIdx_wave() == 2 ? PF_RECON : PF_T_NDRAIN, t4);
+        }
+    }
+    wave_sync_lds();
+}
+
+// ---- the same pass split over two wavefronts (wide workgroups, the PU candidates of an 8x8 CU: shape 3, OUT_REC4, state hints) --------
+// what part A of a group's tokens hands to part B (tokg_a_fast's B), from the levels alone
+HD TgB tokg_b_state(const Lv16 &L, u32 nzm, u32 P) {
+    TgB B; B.base2 = 3; B.rice = 0; B.j = 0;
+    const u32 nzs = mc_nz(P), bigs = mc_big(P), g2s = mc_g2(P);
+    const int nnz = popc32(nzm);
+    u32 rem = nzs;
+    UNROLL_FULL
+    for (int j = 0; j < 8; j++) { const int p2 = 31 - clz_nz(rem | 1u); rem &= (1u << p2) - 1u; }
+    const u32 big8 = bigs & (nzs ^ rem);
+    const int anybig = big8 != 0, fb = 31 - clz_nz(big8 | 1u);
+    const int g2 = (int)((g2s >> fb) & 1u) & anybig;
+    int signs = 0;
+    UNROLL_FULL
+    for (int n = 15; n >= 0; n--) { const int v = L.v[n]; signs = (signs << (int)((nzs >> (2 * n)) & 1u)) | (int)((u32)v >> 31); }
+    const int nb = nnz & 7;
+    B.run.nb = nb; B.run.acc = (u32)signs & ((1u << nb) - 1u);
+    B.esc = (nnz > 8) | (popc32(big8) > 1) | g2;
+    return B;
+}
+// PU wave: prediction, residual, DST, RDOQ; levels + prediction to the partner; cbf, last position and part A of the group's tokens; then the
+// partner's part B behind them.  Same tokens, in the same order, as p1_run_4 writes.  `gen`: this pass's generation number (PuX.go).
+HD void p1_run_4a(int wave, const P1Args &P) {
+    WaveMem &W = WM(wave);
+    const Tables &T = SM.T;
+    const QConst Q = qconst<0>(P.q);
+    PuX &U = PUX;
+    LANES(l) {
+        const int c = l;
+        int x[4][4];
+        int any = 0;
+        long long t4 = prof_now();
+        if (c < NMODE) {
+            const int mode = c;
+            BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
+            int pr[4][4], t[4][4];
+            pred_block4(T, br, 4, 2, mode, 0, 0, pr);
+            for (int yi = 0; yi < 4; yi++) {
+                const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
+                for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
+            }
+            for (int j = 0; j < 4; j++) {
+                const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
+                t[0][j] = (29 * a + 55 * b + 74 * cc_ + 84 * d + 1) >> 1;
+                t[1][j] = (74 * (a + b - d) + 1) >> 1;
+                t[2][j] = (84 * a - 29 * b - 74 * cc_ + 55 * d + 1) >> 1;
+                t[3][j] = (55 * a - 84 * b + 74 * cc_ - 29 * d + 1) >> 1;
+            }
+            for (int i = 0; i < 4; i++) {
+                const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
+                x[i][0] = 29 * a + 55 * b + 74 * cc_ + 84 * d + 128;
+                x[i][1] = 74 * (a + b - d) + 128;
+                x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
+                x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
+            }
+            any = rdoq_group<0>(x, Q);
+            u32 *pv = U.lev[c];
+            for (int r = 0; r < 4; r++) {
+                pv[2 * r] = any ? ((u32)(x[r][0] & 0xFFFF) | (u32)x[r][1] << 16) : 0u;
+                pv[2 * r + 1] = any ? ((u32)(x[r][2] & 0xFFFF) | (u32)x[r][3] << 16) : 0u;
+                pv[8 + r] = (u32)pr[r][0] | (u32)pr[r][1] << 8 | (u32)pr[r][2] << 16 | (u32)pr[r][3] << 24;
+            }
+        }
+        wave_sync_lds();
+        if (l == 0) lds_st_i32(&U.go, lds_ld_i32(&U.go) + 1);
+        MARK("a4_stage1");
+        prof_add(PF_T_HDR, t4); t4 = prof_now();        // (IMCVT_PROF builds: t_hdr = predict + DST + RDOQ, passA = part A, passB = waiting for the partner's rows, passC = append + flush)
+        const int live = c < NMODE;
+        const int mode = live ? c : 0, st = scan_type_of(4, mode);
+        Lv16 L; u32 nzm = 0, mcode = 0;
+        LaneStream ls;
+        TokW w; w.n = 0; w.wr = 1; w.o.tb = lane_row(W, 0); w.o.pos = 0; w.o.cap = LCAP; w.o.glob = 0;
+        TgB B; B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
+        if (live) {
+            if (any) nzm = scan_levels(L, x, st, 0, &mcode);
+            w = ls_begin(ls, W, c, lane_row(W, l), P.tok + (size_t)c * TOK_CAP);
+            tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
+            if (nzm != 0) {
+                const int in = T.incg[st][hibit(nzm)];
+                const LastPos lp = last_pos_prep(0, st, in >> 2, in & 3);
+                w.n = last_pos_emit<0, true, true>(w.o, w.n, lp);
+                w.n = tokg_a_fast<0, true>(w.o.tb, w.n, L, nzm, mcode, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
+            } else w.n = last_pos_emit<0, true, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));      // PU pricing codes the residual syntax of an all-zero block (:1515)
+        }
+        MARK("a4_partA");
+        prof_add(PF_T_GEN, t4); t4 = prof_now();
+        // part B: the partner's rows behind part A.  (Every lane waits here, OUTSIDE the lane-divergent code above: a poll inside one side of a
+        // divergent branch runs before or after the other side as the compiler pleases — with the idle lanes' side first, part A started only
+        // once the partner had finished.)
+        while (lds_ld_i32(&U.bdone) != lds_ld_i32(&U.go)) pipe_pause();
+        wave_sync_lds();
+        prof_add(PF_T_DRAIN, t4); t4 = prof_now();
+        if (live) {
+            const int nbk = (nzm != 0) ? U.bcnt[c] : 0;
+            const int big = nbk > BROW_CAP;
+            if (WAVE_ANY(big)) {                            // practically never: more remaining-level tokens than a partner row holds — this lane makes them itself, the plain way
+                if (big) {
+                    if (B.esc) { ls_flush(ls, w); w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B); if (w.n > 14) ls_flush(ls, w); w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B); }
+                    w.n = tokg_end<true, true>(w.o, w.n, B);
+                }
+            }
+            const int ncp = big ? 0 : nbk;
+            if (WAVE_ANY(w.n + ncp > LCAP - 9)) { if (w.n + ncp > LCAP - 9) ls_flush(ls, w); }      // (part A leaves at most 7 staged + 36 tokens; flushed, at most 7 stay)
+            const u16 *br_ = U.brow[c];
+            NOUNROLL
+            for (int i = 0; WAVE_ANY(i < ncp); i += 4) {
+                if (i < ncp) {
+                    const u32 w0 = *(const u32a *)(br_ + i), w1 = *(const u32a *)(br_ + i + 2);
+                    to_put(w.o, w.n + i, (int)(w0 & 0xFFFFu)); to_put(w.o, w.n + i + 1, (int)(w0 >> 16));      // (tokens beyond ncp are overwritten by ls_end's idle tokens)
+                    to_put(w.o, w.n + i + 2, (int)(w1 & 0xFFFFu)); to_put(w.o, w.n + i + 3, (int)(w1 >> 16));
+                }
+            }
+            w.n += ncp;
+            ls_end(ls, w, W, c);
+            W.tnz[c] = (u8)(nzm != 0);
+        }
+        MARK("a4_append_flush");
+        prof_add(PF_T_NDRAIN, t4);
+    }
+    wave_sync_lds();
+}
+// partner: part B of every candidate's group tokens into its row, then dequantisation, inverse DST, reconstruction and SSE (p1_run_4's tail)
+HD void pu_part_b(int own, const P1Args &P) {
+    WaveMem &W = WM(own);
+    const QConst Q = qconst<0>(P.q);
+    PuX &U = PUX;
+    while (lds_ld_i32(&U.go) == lds_ld_i32(&U.bdone)) pipe_pause();
+    wave_sync_lds();
+    LANES(l) {
+        const int c = l;
+        int x[4][4], pr[4][4];
+        if (c < NMODE) {
+            const u32 *pv = U.lev[c];
+            for (int r = 0; r < 4; r++) {
+                const u32 a = pv[2 * r], b = pv[2 * r + 1], pw = pv[8 + r];
+                x[r][0] = lo16(a); x[r][1] = hi16(a); x[r][2] = lo16(b); x[r][3] = hi16(b);
+                for (int xi = 0; xi < 4; xi++) pr[r][xi] = (int)((pw >> (8 * xi)) & 255);
+            }
+            const int st = scan_type_of(4, c);
+            Lv16 L; u32 mcode = 0;
+            const u32 nzm = scan_levels(L, x, st, 0, &mcode);
+            int cnt = 0;
+            if (nzm != 0) {
+                TgB B = tokg_b_state(L, nzm, mcode);
+                TokOut o; o.tb = U.brow[c]; o.pos = 0; o.cap = BROW_CAP; o.glob = 0;
+                cnt = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, 0, L, B), B);
+            }
+            U.bcnt[c] = cnt;
+        }
+        wave_sync_lds();
+        if (l == 0) lds_st_i32(&U.bdone, lds_ld_i32(&U.go));
+        if (c < NMODE) {
+            int t[4][4], part = 0, any = 0;
+            for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) any |= x[r][cc];
+            if (any) {
+                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * (1 << Q.dqs));
+                for (int j = 0; j < 4; j++) {
+                    const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
+                    t[0][j] = clip16((29 * a + 74 * b + 84 * cc_ + 55 * d + 64) >> 7);
+                    t[1][j] = clip16((55 * a + 74 * b - 29 * cc_ - 84 * d + 64) >> 7);
+                    t[2][j] = clip16((74 * (a - cc_ + d) + 64) >> 7);
+                    t[3][j] = clip16((84 * a - 74 * b + 55 * cc_ - 29 * d + 64) >> 7);
+                }
+                for (int i = 0; i < 4; i++) {
+                    const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
+                    x[i][0] = clip16((29 * a + 74 * b + 84 * cc_ + 55 * d + 2048) >> 12);
+                    x[i][1] = clip16((55 * a + 74 * b - 29 * cc_ - 84 * d + 2048) >> 12);
+                    x[i][2] = clip16((74 * (a - cc_ + d) + 2048) >> 12);
+                    x[i][3] = clip16((84 * a - 74 * b + 55 * cc_ - 29 * d + 2048) >> 12);
+                }
+            }
+            u32 oww[4];
+            for (int yi = 0; yi < 4; yi++) oww[yi] = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
+            for (int yi = 0; yi < 4; yi++) {
+                const u32 ow = oww[yi];
+                u32 rw4 = 0;
+                for (int xi = 0; xi < 4; xi++) {
+                    const int rc = clip3(x[yi][xi] + pr[yi][xi], 0, 255);
+                    const int d = (int)((ow >> (8 * xi)) & 255) - rc;
+                    part += d * d;
+                    rw4 |= (u32)rc << (8 * xi);
+                }
+                *(u32a *)&W.u.w2.rec4[c][yi * 4] = rw4;
+            }
+            W.sse[c] += part;
         }
     }
     wave_sync_lds();

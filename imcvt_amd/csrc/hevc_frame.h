@@ -142,13 +142,23 @@ HDN void partner_trial(int own_, int depth_) {
     split_flag(&q.done, q);
 }
 // partner of the PU wave: the byte half of the pricing of each PU's 35 candidates (fresh coder, :1504-1518); writes their costs
-HDN void partner_pu() {
+HDN void partner_pu(int y0_, int x0_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
     PartnerMem &X = XM(2); SplitQ &q = X.q;
     WaveMem &W = WM(2);
     const RdW rw = rd_weights(F.job.q);
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
     const u16 *tok = wave_tok(F.sc, 2);
+#ifndef IMCVT_HOSTEMU
+    if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);      // (part of the PU chain, the longest of an 8x8 CU: as eval_NxN)
+#endif
     for (int k = 0; k < 4; k++) {
+        {   // its share of the pass over PU k's candidates: remaining-level tokens, reconstructions, SSE
+            P1Args P;
+            P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
+            P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
+            pu_part_b(2, P);
+        }
         while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
         wave_sync();
         LANES(l) {
@@ -168,6 +178,9 @@ HDN void partner_pu() {
         }
         split_flag(&q.done, q);
     }
+#ifndef IMCVT_HOSTEMU
+    if (F.prio_base) SETPRIO(2); else SETPRIO(0);
+#endif
 }
 // A lender wavefront (wide workgroups): candidates lo .. hi-1 of the one-TU set of the 8x8 CU at (y0, x0), exactly as wave 0 runs its own
 // (eval_2Nx2N: same border, same pass, tokens / counts / SSE into wave 0's arrays and streams) on this wavefront's own slice.
@@ -256,7 +269,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     if (wave >= NWAVES) {                               // the pipe wave has no share in these sets: it only keeps the workgroup's barrier count
         if (N >= 16) {
             wg_sync_p(); wg_sync_p();
-            if (F.wide && (wave == PIPE_WAVE + 1 || wave == PIPE_WAVE + 2)) partner_trial(wave - (PIPE_WAVE + 1), depth);      // wide workgroups: the byte half of the trial coders of waves 0 / 1
+            if (F.wide && (wave == WAVE_A_PARTNER || wave == WAVE_B_CODER)) partner_trial(wave == WAVE_A_PARTNER ? 0 : 1, depth);      // wide workgroups: the byte half of the trial coders of waves 0 / 1 (on the other one's SIMD)
         }
         return;
     }
@@ -286,7 +299,8 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     const int wide8 = F.wide && !big;                   // 8x8 CU of a wide workgroup: two partner wavefronts take passes of the one-TU set, the four-TU set is coded segment by segment by wave 5
     if (big) wg_sync_p(); else if (wide8 && wave == 0) { wave_sync(); LANES(l) { if (l == 0) lds_st_i32(&WCTL.a_go, lds_ld_i32(&WCTL.a_go) + 1); } } else wave_sync_lds();         // wave 2 / the lenders start from the owners' header counts
     P1Item it[2]; int nit = 1;
-    if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = (wide8 && wave == 0) ? 16 : NMODE; }
+    if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = (wide8 && wave == 0) ? 16 : NMODE;
+                if (wide8 && wave == 0) { nit = 2; it[1].own = 0; it[1].shape = 0; it[1].lo = 32; it[1].hi = NMODE; } }      // (candidates 16..31: wave 5, lend_passes)
     else if (wave < 2) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = split_mode(N, wave); }
     else { nit = 2; for (int i = 0; i < 2; i++) { it[i].own = i; it[i].shape = i; it[i].lo = split_mode(N, i); it[i].hi = NMODE; } }
     P1Args P;
@@ -314,7 +328,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
         }
     }
     if (wide8 && wave == 0) {                           // the lenders' candidates are done: their tokens are in memory, counts and SSE in this wavefront's arrays
-        while (lds_ld_i32(&WCTL.lend_done[0]) != lds_ld_i32(&WCTL.a_go) || lds_ld_i32(&WCTL.lend_done[1]) != lds_ld_i32(&WCTL.a_go)) pipe_pause();
+        while (lds_ld_i32(&WCTL.lend_done[0]) != lds_ld_i32(&WCTL.a_go)) pipe_pause();
         wave_sync();
     }
     if (wide8 && wave == 1) { prof_add(PF_P1_4, pt); return; }      // (the trial coders of this set have been running on wave 5 all along: partner_fourtu)
@@ -398,7 +412,8 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
         P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = hint;
-        p1_run(wave, P);
+        if (F.wide) p1_run_4a(wave, P);                 // wide workgroup: the partner wavefront makes the remaining-level tokens and the reconstructions meanwhile (partner_pu)
+        else p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         wave_sync();
         if (TU0_SHARE && k == 0) { LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); } }      // tokens in memory, SSE / reconstructions in this wave's slice: the four-TU wave's TU 0
@@ -718,10 +733,10 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     WAVES_ALL(w) {
         if (w >= NWAVES && N < 16) {
             if (w == PIPE_WAVE) nxn_pipe(y0, x0);
-            else if (w == LEND_WAVE0) { lend_passes(w, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }       // partner wavefronts of a wide workgroup: 4 a pass of the one-TU set, then the byte half of its trial coders
-            else if (w == PIPE_WAVE + 2) partner_fourtu(depth);                                                  // 5 the trial coders of the four-TU set, segment by segment behind wave 1's passes
-            else if (w == PIPE_WAVE + 3) partner_pu();                                                           // 6 the byte half of the PU pricing of wave 2
-            else { lend_passes(w, 1, 32, NMODE, y0, x0, avm); partner_pipe(); }                                   // 7 the last pass of the one-TU set, then the byte half of the pipe wave's streams
+            else if (w == WAVE_B_CODER) partner_fourtu(depth);                                                   // partner wavefronts of a wide workgroup (hevc_core.h, "who is whose partner"): 4 the trial coders of the four-TU set, segment by segment behind wave 1's passes
+            else if (w == WAVE_A_PARTNER) { lend_passes(w, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }   // 5 a pass of the one-TU set, then the byte half of its trial coders
+            else if (w == WAVE_PIPE_PARTNER) partner_pipe();                                                     // 6 the byte half of the pipe wave's streams
+            else partner_pu(y0, x0);                                                                             // 7 the PU chain's partner: remaining-level tokens, reconstructions, byte half of the pricing
         }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else eval_NxN(2, y0, x0, avm);
@@ -1396,7 +1411,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.lend_done[1] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; PUX.go = 0; PUX.bdone = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
