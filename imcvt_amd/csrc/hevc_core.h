@@ -512,23 +512,24 @@ struct alignas(16) PartnerMem {
 // (hevc_frame.h lend_passes: the one-TU candidate set's three passes of an 8x8 CU run on three wavefronts at once).
 #define NLEND 1
 struct alignas(16) WideCtl {
+    i32 cu8;                                     // 8x8 CUs entered so far (enter_cu): the sequence numbers of their four PU steps follow from it
     i32 a_go, lend_done[NLEND];                  // one-TU set: generation whose headers are in place / finished by each lender
     i32 b_seg, b_cons;                           // four-TU set: token segments (header + TU 0, TU 1, TU 2, TU 3) complete so far / coded so far, counted over the frame
     i32 seg_end[4][NMODE];                       // ... and where each candidate's segment ends in its stream (a segment starts on a token-block boundary)
 };
-// The pass over a PU's 35 candidates split between the PU wave and its partner (wide workgroups; p1_run_4a / pu_part_b): the PU wave
-// predicts, transforms and quantises, leaves levels and prediction here and goes on with the first part of every candidate's tokens;
-// the partner makes the remaining-level tokens (rows `brow`) and the reconstruction meanwhile.
-#ifndef BROW_CAP
-#define BROW_CAP 48                              // tokens a partner row holds (a longer remaining-level part is made by the PU wave itself, the plain way); slot BROW_CAP is the dump slot
-#endif
-#define BROW_STRIDE ((BROW_CAP + 2) | 2)         // u16 per lane, an odd number of dwords
+// A PU step of an 8x8 CU in a wide workgroup (hevc_frame.h pu_step_wide): the PU wave predicts, transforms and quantises the 35 candidates,
+// leaves levels and prediction here, makes the FIRST part of every candidate's tokens (cbf, last position, significance / greater-1 /
+// greater-2 flags, full sign chunks) in its lane rows and runs the range half of the pricing over them straight from LDS; one partner
+// (pu_part_b) makes the REST (remaining levels: rows `brow`), which the range half goes on with; another (pu_recon_price) makes the
+// reconstructions and SSE and runs the byte half of the pricing.  Tokens reach global memory only where someone needs them there.
+#define BROW_CAP 72                              // tokens of a partner row: 16 levels x 32 bins at most + 7 pending sign bins = 519 bins <= 65 chunks
+#define BROW_STRIDE (BROW_CAP + 10)              // u16 per lane (41 dwords: odd): room for the 8 idle tokens that pad the last token block
 struct alignas(16) PuX {
     u32 lev[NMODE][13];                          // per candidate: 16 levels (i16, raster order, zero when the weak-group test cleared the block), then the prediction (16 u8)
     alignas(4) u16 brow[NMODE][BROW_STRIDE];
-    i32 bcnt[NMODE];                             // tokens in the row (> BROW_CAP: the row overflowed)
-    i32 go, bdone;                               // generation published by the PU wave / whose rows are complete
-    // (a PU-wave lane stages at most 7 tokens + BROW_CAP of these + 8 idle ones in its 64-token row)
+    i32 bcnt[NMODE];                             // tokens in the partner's row
+    i32 na[NMODE];                               // tokens of the first part behind cbf_luma (lane row slots 8 ..)
+    u32 pu_seq, b_seq, r_seq;                    // sequence number of the PU whose levels are published / whose rows are complete / whose reconstructions and SSE are in place
 };
 #define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem) + sizeof(PuX))
 #define PUX (*(PuX *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem)))
@@ -595,6 +596,9 @@ HD void wg_sync_p() { const long long t = prof_now(); wg_sync(); prof_add(PF_SYN
 struct Sink { u8 *base; u32 off; };          // byte i of the lane's run lives at base[off + i]; base is wave-uniform
 HD void sink_put(Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), v); }
 HD int sink_room(Sink &, int) { return 1; }
+struct CountSinkT { int dummy; };             // bytes are counted (a.cnt), not kept
+HD void sink_put(CountSinkT &, int, int) {}
+HD int sink_room(CountSinkT &, int) { return 1; }
 struct RingSink { u8 *ring; u8 *gbuf; int c0, fl, ovf; };   // byte i lives at local index j = i - c0: ring[j % RING_BYTES] until flushed, then gbuf[j]; fl = bytes flushed (multiple of 16)
 HD void ring_flush16(RingSink &s) {      // the ring is only 4-byte aligned (odd dword stride between lanes)
     const u32a *r = (const u32a *)(s.ring + (s.fl & (RING_BYTES - 1)));
@@ -1733,139 +1737,86 @@ HD TgB tokg_b_state(const Lv16 &L, u32 nzm, u32 P) {
     B.esc = (nnz > 8) | (popc32(big8) > 1) | g2;
     return B;
 }
-// PU wave: prediction, residual, DST, RDOQ; levels + prediction to the partner; cbf, last position and part A of the group's tokens; then the
-// partner's part B behind them.  Same tokens, in the same order, as p1_run_4 writes.  `gen`: this pass's generation number (PuX.go).
-HD void p1_run_4a(int wave, const P1Args &P) {
-    WaveMem &W = WM(wave);
+// PU wave, first half of the pass: prediction, residual, DST, RDOQ of candidate `c` (= mode); levels (raster) in x, prediction published with them
+HD int pu_stage1(const WaveMem &W, const P1Args &P, int c, int x[4][4]) {
     const Tables &T = SM.T;
     const QConst Q = qconst<0>(P.q);
-    PuX &U = PUX;
-    LANES(l) {
-        const int c = l;
-        int x[4][4];
-        int any = 0;
-        long long t4 = prof_now();
-        if (c < NMODE) {
-            const int mode = c;
-            BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
-            int pr[4][4], t[4][4];
-            pred_block4(T, br, 4, 2, mode, 0, 0, pr);
-            for (int yi = 0; yi < 4; yi++) {
-                const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
-                for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
-            }
-            for (int j = 0; j < 4; j++) {
-                const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
-                t[0][j] = (29 * a + 55 * b + 74 * cc_ + 84 * d + 1) >> 1;
-                t[1][j] = (74 * (a + b - d) + 1) >> 1;
-                t[2][j] = (84 * a - 29 * b - 74 * cc_ + 55 * d + 1) >> 1;
-                t[3][j] = (55 * a - 84 * b + 74 * cc_ - 29 * d + 1) >> 1;
-            }
-            for (int i = 0; i < 4; i++) {
-                const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
-                x[i][0] = 29 * a + 55 * b + 74 * cc_ + 84 * d + 128;
-                x[i][1] = 74 * (a + b - d) + 128;
-                x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
-                x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
-            }
-            any = rdoq_group<0>(x, Q);
-            u32 *pv = U.lev[c];
-            for (int r = 0; r < 4; r++) {
-                pv[2 * r] = any ? ((u32)(x[r][0] & 0xFFFF) | (u32)x[r][1] << 16) : 0u;
-                pv[2 * r + 1] = any ? ((u32)(x[r][2] & 0xFFFF) | (u32)x[r][3] << 16) : 0u;
-                pv[8 + r] = (u32)pr[r][0] | (u32)pr[r][1] << 8 | (u32)pr[r][2] << 16 | (u32)pr[r][3] << 24;
-            }
-        }
-        wave_sync_lds();
-        if (l == 0) lds_st_i32(&U.go, lds_ld_i32(&U.go) + 1);
-        MARK("a4_stage1");
-        prof_add(PF_T_HDR, t4); t4 = prof_now();        // (IMCVT_PROF builds: t_hdr = predict + DST + RDOQ, passA = part A, passB = waiting for the partner's rows, passC = append + flush)
-        const int live = c < NMODE;
-        const int mode = live ? c : 0, st = scan_type_of(4, mode);
-        Lv16 L; u32 nzm = 0, mcode = 0;
-        LaneStream ls;
-        TokW w; w.n = 0; w.wr = 1; w.o.tb = lane_row(W, 0); w.o.pos = 0; w.o.cap = LCAP; w.o.glob = 0;
-        TgB B; B.esc = 0; B.base2 = 3; B.rice = 0; B.j = 0; B.run.acc = 0; B.run.nb = 0;
-        if (live) {
-            if (any) nzm = scan_levels(L, x, st, 0, &mcode);
-            w = ls_begin(ls, W, c, lane_row(W, l), P.tok + (size_t)c * TOK_CAP);
-            tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
-            if (nzm != 0) {
-                const int in = T.incg[st][hibit(nzm)];
-                const LastPos lp = last_pos_prep(0, st, in >> 2, in & 3);
-                w.n = last_pos_emit<0, true, true>(w.o, w.n, lp);
-                w.n = tokg_a_fast<0, true>(w.o.tb, w.n, L, nzm, mcode, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
-            } else w.n = last_pos_emit<0, true, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));      // PU pricing codes the residual syntax of an all-zero block (:1515)
-        }
-        MARK("a4_partA");
-        prof_add(PF_T_GEN, t4); t4 = prof_now();
-        // part B: the partner's rows behind part A.  (Every lane waits here, OUTSIDE the lane-divergent code above: a poll inside one side of a
-        // divergent branch runs before or after the other side as the compiler pleases — with the idle lanes' side first, part A started only
-        // once the partner had finished.)
-        while (lds_ld_i32(&U.bdone) != lds_ld_i32(&U.go)) pipe_pause();
-        wave_sync_lds();
-        prof_add(PF_T_DRAIN, t4); t4 = prof_now();
-        if (live) {
-            const int nbk = (nzm != 0) ? U.bcnt[c] : 0;
-            const int big = nbk > BROW_CAP;
-            if (WAVE_ANY(big)) {                            // practically never: more remaining-level tokens than a partner row holds — this lane makes them itself, the plain way
-                if (big) {
-                    if (B.esc) { ls_flush(ls, w); w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B); if (w.n > 14) ls_flush(ls, w); w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B); }
-                    w.n = tokg_end<true, true>(w.o, w.n, B);
-                }
-            }
-            const int ncp = big ? 0 : nbk;
-            if (WAVE_ANY(w.n + ncp > LCAP - 9)) { if (w.n + ncp > LCAP - 9) ls_flush(ls, w); }      // (part A leaves at most 7 staged + 36 tokens; flushed, at most 7 stay)
-            const u16 *br_ = U.brow[c];
-            NOUNROLL
-            for (int i = 0; WAVE_ANY(i < ncp); i += 4) {
-                if (i < ncp) {
-                    const u32 w0 = *(const u32a *)(br_ + i), w1 = *(const u32a *)(br_ + i + 2);
-                    to_put(w.o, w.n + i, (int)(w0 & 0xFFFFu)); to_put(w.o, w.n + i + 1, (int)(w0 >> 16));      // (tokens beyond ncp are overwritten by ls_end's idle tokens)
-                    to_put(w.o, w.n + i + 2, (int)(w1 & 0xFFFFu)); to_put(w.o, w.n + i + 3, (int)(w1 >> 16));
-                }
-            }
-            w.n += ncp;
-            ls_end(ls, w, W, c);
-            W.tnz[c] = (u8)(nzm != 0);
-        }
-        MARK("a4_append_flush");
-        prof_add(PF_T_NDRAIN, t4);
+    BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
+    int pr[4][4], t[4][4];
+    pred_block4(T, br, 4, 2, c, 0, 0, pr);
+    for (int yi = 0; yi < 4; yi++) {
+        const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
+        for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
     }
-    wave_sync_lds();
+    for (int j = 0; j < 4; j++) {
+        const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
+        t[0][j] = (29 * a + 55 * b + 74 * cc_ + 84 * d + 1) >> 1;
+        t[1][j] = (74 * (a + b - d) + 1) >> 1;
+        t[2][j] = (84 * a - 29 * b - 74 * cc_ + 55 * d + 1) >> 1;
+        t[3][j] = (55 * a - 84 * b + 74 * cc_ - 29 * d + 1) >> 1;
+    }
+    for (int i = 0; i < 4; i++) {
+        const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
+        x[i][0] = 29 * a + 55 * b + 74 * cc_ + 84 * d + 128;
+        x[i][1] = 74 * (a + b - d) + 128;
+        x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
+        x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
+    }
+    const int any = rdoq_group<0>(x, Q);
+    u32 *pv = PUX.lev[c];
+    for (int r = 0; r < 4; r++) {
+        pv[2 * r] = any ? ((u32)(x[r][0] & 0xFFFF) | (u32)x[r][1] << 16) : 0u;
+        pv[2 * r + 1] = any ? ((u32)(x[r][2] & 0xFFFF) | (u32)x[r][3] << 16) : 0u;
+        pv[8 + r] = (u32)pr[r][0] | (u32)pr[r][1] << 8 | (u32)pr[r][2] << 16 | (u32)pr[r][3] << 24;
+    }
+    return any;
 }
-// partner: part B of every candidate's group tokens into its row, then dequantisation, inverse DST, reconstruction and SSE (p1_run_4's tail)
-HD void pu_part_b(int own, const P1Args &P) {
-    WaveMem &W = WM(own);
-    const QConst Q = qconst<0>(P.q);
+HD void pu_levels(int c, int x[4][4], int pr[4][4]) {           // a partner reads what pu_stage1 published
+    const u32 *pv = PUX.lev[c];
+    for (int r = 0; r < 4; r++) {
+        const u32 a = pv[2 * r], b = pv[2 * r + 1], pw = pv[8 + r];
+        x[r][0] = lo16(a); x[r][1] = hi16(a); x[r][2] = lo16(b); x[r][3] = hi16(b);
+        for (int xi = 0; xi < 4; xi++) pr[r][xi] = (int)((pw >> (8 * xi)) & 255);
+    }
+}
+// partner (wave 7): the remaining-level tokens of every candidate of the PU with sequence number `seq` into its row, padded to a token block with idle tokens
+HD void pu_part_b(u32 seq) {
     PuX &U = PUX;
-    while (lds_ld_i32(&U.go) == lds_ld_i32(&U.bdone)) pipe_pause();
+    while ((u32)lds_ld_i32((const i32 *)&U.pu_seq) != seq) pipe_pause();
     wave_sync_lds();
     LANES(l) {
         const int c = l;
-        int x[4][4], pr[4][4];
         if (c < NMODE) {
-            const u32 *pv = U.lev[c];
-            for (int r = 0; r < 4; r++) {
-                const u32 a = pv[2 * r], b = pv[2 * r + 1], pw = pv[8 + r];
-                x[r][0] = lo16(a); x[r][1] = hi16(a); x[r][2] = lo16(b); x[r][3] = hi16(b);
-                for (int xi = 0; xi < 4; xi++) pr[r][xi] = (int)((pw >> (8 * xi)) & 255);
-            }
+            int x[4][4], pr[4][4];
+            pu_levels(c, x, pr);
             const int st = scan_type_of(4, c);
             Lv16 L; u32 mcode = 0;
             const u32 nzm = scan_levels(L, x, st, 0, &mcode);
+            TokOut o; o.tb = U.brow[c]; o.pos = 0; o.cap = BROW_CAP + 8; o.glob = 0;
             int cnt = 0;
             if (nzm != 0) {
                 TgB B = tokg_b_state(L, nzm, mcode);
-                TokOut o; o.tb = U.brow[c]; o.pos = 0; o.cap = BROW_CAP; o.glob = 0;
                 cnt = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, 0, L, B), B);
             }
+            for (int i = 0; i < 8; i++) to_put(o, cnt + i, (int)TOK_IDLE);
             U.bcnt[c] = cnt;
         }
-        wave_sync_lds();
-        if (l == 0) lds_st_i32(&U.bdone, lds_ld_i32(&U.go));
+    }
+    wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32((i32 *)&U.b_seq, (i32)seq); }
+}
+// partner (wave 6, wave 7 for the last PU): dequantisation, inverse DST, reconstruction and SSE of every candidate (p1_run_4's tail) into the PU wave's arrays
+HD void pu_recon(int own, const P1Args &P, u32 seq) {
+    WaveMem &W = WM(own);
+    const QConst Q = qconst<0>(P.q);
+    PuX &U = PUX;
+    while ((u32)lds_ld_i32((const i32 *)&U.pu_seq) != seq) pipe_pause();
+    wave_sync_lds();
+    LANES(l) {
+        const int c = l;
         if (c < NMODE) {
-            int t[4][4], part = 0, any = 0;
+            int x[4][4], pr[4][4], t[4][4], part = 0, any = 0;
+            pu_levels(c, x, pr);
             for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) any |= x[r][cc];
             if (any) {
                 for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * (1 << Q.dqs));
@@ -1901,6 +1852,7 @@ HD void pu_part_b(int own, const P1Args &P) {
         }
     }
     wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32((i32 *)&U.r_seq, (i32)seq); }
 }
 
 // some level among the first 8 non-zero ones (coding order: scan positions 15 .. 0) exceeds 1 — the flag tokg_a reports as
@@ -2563,6 +2515,45 @@ HD void stream_seg_R(int &range, u8 *cx, SplitQ &q, int lane, int &blk, const u1
 #endif
     }
 }
+// The range half on RESOLVED tokens that lie in LDS (a lane's own row, or its row at a partner: hevc_frame.h pu_step_wide), 16-byte-block
+// padded with idle tokens like a stream in memory.
+HD void stream_seg_R_lds(int &range, SplitQ &q, int lane, int &blk, const u16 *p, int n) {
+    const int last_blk = imax((n - 1) >> 3, 0);
+    const int ql = lane < NMODE ? lane : 0;
+    u32 *const row = q.rec[ql];
+    const u32a *pw = (const u32a *)p;
+    U4 cur; cur.x = pw[0]; cur.y = pw[1]; cur.z = pw[2]; cur.w = pw[3];
+    int cons_seen = lds_ld_i32(&q.cons[ql]);
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        const u32a *pn = pw + 4 * imin((k0 >> 3) + 1, last_blk);
+        U4 nxt; nxt.x = pn[0]; nxt.y = pn[1]; nxt.z = pn[2]; nxt.w = pn[3];
+        if (k0 < n) {
+            while (WAVE_ANY(blk - cons_seen >= QDEPTH)) { if (blk - cons_seen >= QDEPTH) { pipe_pause(); cons_seen = lds_ld_i32(&q.cons[ql]); } }
+            u32 lw[8], rec[8];
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) rec[j] = token_R_res(range, tok_of(cur, j), lw[j]);
+            u32 *d = row + (blk & (QDEPTH - 1)) * 8;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) d[j] = rec[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            blk++;
+            lds_st_i32(&q.prod[ql], blk);
+        }
+        cur = nxt;
+    }
+}
+// the plain coder over tokens in LDS, bytes counted only (the safe path of a PU candidate whose lead list overflowed)
+HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
+    CountSinkT cs; cs.dummy = 0;
+    NOUNROLL
+    for (int k = 0; WAVE_ANY(k < n); k++)
+        if (k < n) code_token(a, cx, cs, (u32)p[k]);
+}
 // Byte half when only the LENGTH of the stream is wanted and the stream is short (the pricing of a PU's candidates, :1504-1518: the
 // bytes are never read, ~60 tokens leave 8 - 10 bytes): low and the bit position per token as in token_L, every lead appended to
 // ONE list per lane; the byte-level logic (:863-878, :820-831 — it decides how many bytes the stream has, emulation prevention
@@ -2603,9 +2594,7 @@ HD void stream_seg_L1(Arith &a, u16 *leads, int &qn, SplitQ &q, int lane, int &b
         }
     }
 }
-struct CountSink { int dummy; };                 // bytes are counted (a.cnt), not kept
-HD void sink_put(CountSink &, int, int) {}
-HD int sink_room(CountSink &, int) { return 1; }
+typedef CountSinkT CountSink;
 // the byte-level logic over a lane's whole lead list: a.cnt / nbytes / bufbyte / zeros end as if the bytes had been emitted token by token
 HD void leads_count(Arith &a, const u16 *leads, int qn) {
     CountSink cs; cs.dummy = 0;

@@ -141,46 +141,61 @@ HDN void partner_trial(int own_, int depth_) {
     }
     split_flag(&q.done, q);
 }
-// partner of the PU wave: the byte half of the pricing of each PU's 35 candidates (fresh coder, :1504-1518); writes their costs
-HDN void partner_pu(int y0_, int x0_) {
-    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
+// sequence number of PU k of the 8x8 CU being walked (wide workgroups)
+HD u32 pu_seq_of(int k) { return 4u * (u32)(lds_ld_i32(&WCTL.cu8) - 1) + (u32)k + 1u; }
+// A partner's share of PU k (wide workgroups, pu_step_wide): reconstructions and SSE of the 35 candidates, then the byte half of their pricing
+// (fresh coder, :1504-1518) over the range half's records — first part of the tokens, then the remaining levels — and the costs.
+HD void pu_recon_price(int y0, int x0, int k) {
     PartnerMem &X = XM(2); SplitQ &q = X.q;
     WaveMem &W = WM(2);
+    PuX &U = PUX;
     const RdW rw = rd_weights(F.job.q);
-    u8 *const ubytes = uniform_ptr(F.sc.bytes);
-    const u16 *tok = wave_tok(F.sc, 2);
+    const u32 seq = pu_seq_of(k);
+    P1Args P;
+    P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
+    P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
+    pu_recon(2, P, seq);
+    while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
+    split_await(&q.mid, q);                             // the first parts' token counts are in place
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        Arith a; arith_reset(a);
+        const int na = on ? U.na[ll] : 0;
+        int blk = 0, qn = 0;
+        stream_seg_L1(a, X.leads[ll], qn, q, l, blk, na);
+        while ((u32)lds_ld_i32((const i32 *)&U.b_seq) != seq) pipe_pause();
+        wave_sync_lds();
+        const int nb = on ? U.bcnt[ll] : 0;
+        stream_seg_L1(a, X.leads[ll], qn, q, l, blk, nb);
+        const int ovf = qn > LEADS_CAP;
+        leads_count(a, X.leads[ll], ovf ? 0 : qn);                      // the byte-level logic once, at the end (the bytes themselves are never read, :1518)
+        if (WAVE_ANY(ovf)) {                                            // a stream with more leads than the list holds: that lane again, by the plain coder on a scratch copy of the fresh contexts
+            if (ovf) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
+            stream_seg_safe_lds(a, X.cx[ll], lane_row(W, ll) + 8, ovf ? na : 0);
+            stream_seg_safe_lds(a, X.cx[ll], U.brow[ll], ovf ? nb : 0);
+        }
+        if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
+    }
+    split_flag(&q.done, q);
+}
+// wave 7, partner of the PU chain: the remaining-level tokens of every PU's candidates; for the last PU (the pipe wave's partner is busy by then) reconstructions and pricing too
+HDN void partner_pu(int y0_, int x0_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);      // (part of the PU chain, the longest of an 8x8 CU: as eval_NxN)
 #endif
     for (int k = 0; k < 4; k++) {
-        {   // its share of the pass over PU k's candidates: remaining-level tokens, reconstructions, SSE
-            P1Args P;
-            P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
-            P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
-            pu_part_b(2, P);
-        }
-        while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
-        wave_sync();
-        LANES(l) {
-            const int on = l < NMODE, ll = on ? l : 0;
-            Arith a; arith_reset(a);
-            const int n = on ? W.tokn[ll] - 8 : 0;
-            u8 *gbuf = ubytes + (size_t)(2 * NMODE + ll) * TRIAL_BYTES;
-            int blk = 0, qn = 0;
-            stream_seg_L1(a, X.leads[ll], qn, q, l, blk, n);            // low and bit position per token, the leads on one list ...
-            const int ovf = qn > LEADS_CAP;
-            leads_count(a, X.leads[ll], ovf ? 0 : qn);                  // ... the byte-level logic once, at the end (the bytes themselves are never read, :1518)
-            if (WAVE_ANY(ovf)) {                                        // a stream with more leads than the list holds: that lane again, by the plain coder
-                if (ovf) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
-                stream_run_safe(a, X.cx[ll], gbuf, tok + (size_t)ll * TOK_CAP + 8, ovf ? n : 0);
-            }
-            if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
-        }
-        split_flag(&q.done, q);
+        pu_part_b(pu_seq_of(k));
+        if (k == 3) pu_recon_price(y0, x0, k);
     }
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(2); else SETPRIO(0);
 #endif
+}
+// wave 6 before it becomes the pipe wave's partner: reconstructions and pricing of PUs 0..2
+HDN void partner_pu_early(int y0_, int x0_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
+    for (int k = 0; k < 3; k++) pu_recon_price(y0, x0, k);
 }
 // A lender wavefront (wide workgroups): candidates lo .. hi-1 of the one-TU set of the 8x8 CU at (y0, x0), exactly as wave 0 runs its own
 // (eval_2Nx2N: same border, same pass, tokens / counts / SSE into wave 0's arrays and streams) on this wavefront's own slice.
@@ -380,6 +395,76 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 // Slot NMODE holds the NxN stream ([0..) header, then the four winners' tokens) and, from NXN_KEEP on, the winners' copies.
 #define NXN_KEEP 1024
 #define NXN_KEEP_STRIDE 160
+// One PU step of the NxN chain in a wide workgroup, on the PU wave: pass and pricing of the 35 candidates of PU k (hevc_core.h "A PU step ...").
+//   here      prediction, DST, RDOQ -> levels published; first part of the tokens into the lane rows; range half of the pricing over them from LDS;
+//             then, once wave 7 has made them, over the remaining-level rows; PU 0 only: the complete streams to memory (the four-TU wave's TU 0)
+//   wave 7    remaining-level tokens (pu_part_b)          wave 6 (wave 7 for PU 3)    reconstructions, SSE, byte half of the pricing, costs (pu_recon_price)
+// Same tokens in the same order as p1_run_4 writes, same coder arithmetic as run_trial_r.
+HD void pu_step_wide(int wave, const P1Args &P, int k) {
+    WaveMem &W = WM(wave);
+    const Tables &T = SM.T;
+    PuX &U = PUX; SplitQ &q = XM(2).q;
+    const u32 seq = pu_seq_of(k);
+    LANES(l) { split_reset(q, l); }
+    LANES(l) {
+        const int c = l, live = c < NMODE;
+        int x[4][4];
+        int any = 0;
+        long long t4 = prof_now();
+        if (live) any = pu_stage1(W, P, c, x);
+        wave_sync_lds();
+        if (l == 0) { lds_st_i32((i32 *)&U.pu_seq, (i32)seq); lds_st_i32(&q.go, lds_ld_i32(&q.go) + 1); }      // levels published (waves 7 and 6 start), queue counters zeroed
+        MARK("a4_stage1");
+        prof_add(PF_T_HDR, t4); t4 = prof_now();        // (IMCVT_PROF builds: t_hdr = predict + DST + RDOQ, passA = first part of the tokens, passB = range half over it, passC = waiting for the remaining-level rows, n_cg = range half over them)
+        const int st = scan_type_of(4, live ? c : 0);
+        Lv16 L; u32 nzm = 0, mcode = 0;
+        u16 *const row = lane_row(W, live ? l : 0);
+        TokW w; w.n = 7; w.wr = 1; w.o.tb = row; w.o.pos = 0; w.o.cap = LCAP; w.o.glob = 0;      // (a PU candidate's stream starts at token 7, cbf_luma: the part that is priced, from token 8 on, starts a token block)
+        if (live) {
+            if (any) nzm = scan_levels(L, x, st, 0, &mcode);
+            tk_bin(w, CX_CBF_LUMA + (P.shape == 0 ? 1 : 0), nzm != 0);
+            TgB B;
+            if (nzm != 0) {
+                const int in = T.incg[st][hibit(nzm)];
+                const LastPos lp = last_pos_prep(0, st, in >> 2, in & 3);
+                w.n = last_pos_emit<0, true, true>(w.o, w.n, lp);
+                w.n = tokg_a_fast<0, true>(w.o.tb, w.n, L, nzm, mcode, TG_DC | TG_LAST | st << TG_ST, B) & 0xFFFF;
+            } else w.n = last_pos_emit<0, true, true>(w.o, w.n, last_pos_prep(0, st, 0, 0));      // PU pricing codes the residual syntax of an all-zero block (:1515)
+            for (int i = 0; i < 8; i++) to_put(w.o, w.n + i, (int)TOK_IDLE);     // (at most 8 + 34 tokens so far)
+            U.na[c] = w.n - 8;
+        }
+        const int na = live ? w.n - 8 : 0;
+        wave_sync_lds();
+        if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));                     // the counts are in place: the byte half may start
+        MARK("a4_partA");
+        prof_add(PF_T_GEN, t4); t4 = prof_now();
+        int range = 510, blk = 0;
+        stream_seg_R_lds(range, q, l, blk, row + 8, na);
+        prof_add(PF_T_DRAIN, t4); t4 = prof_now();
+        while ((u32)lds_ld_i32((const i32 *)&U.b_seq) != seq) pipe_pause();      // (every lane waits here, outside lane-divergent code)
+        wave_sync_lds();
+        prof_add(PF_T_NDRAIN, t4); t4 = prof_now();
+        const int nb = live ? U.bcnt[c] : 0;
+        stream_seg_R_lds(range, q, l, blk, U.brow[live ? c : 0], nb);
+        prof_add(PF_T_NTOK, t4);
+        if (live) { W.tokn[c] = 8 + na + nb; W.tnz[c] = (u8)(nzm != 0); }
+        if (TU0_SHARE && k == 0 && live) {              // PU 0: the four-TU wave takes TU 0 from these streams (tu0_from_pu0) — to memory, the remaining-level part behind the first, idle tokens up to the block boundary (the rows stay as they are)
+            u16 *const g = P.tok + (size_t)c * TOK_CAP;
+            g_st16((i16 *)(g + 7), (int)row[7]);
+            row_to_stream(row + 8, g, 8, na);
+            row_to_stream(U.brow[c], g, 8 + na, nb);
+            const int end = 8 + na + nb;
+            for (int i = 0; i < 7; i++) if (((end + i) >> 3) == (end >> 3) && (end & 7) != 0) g_st16((i16 *)(g + end + i), (int)TOK_IDLE);
+        }
+    }
+    if (TU0_SHARE && k == 0) {
+        wave_sync();                                    // the streams are in memory
+        while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // ... and SSE / reconstructions in this wave's slice (long since)
+        wave_sync_lds();
+        LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); }
+    }
+    split_await(&q.done, q);                            // the costs
+}
 HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     const int wave = uni_i(wave_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
 #ifndef IMCVT_HOSTEMU
@@ -412,24 +497,15 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
         P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = hint;
-        if (F.wide) p1_run_4a(wave, P);                 // wide workgroup: the partner wavefront makes the remaining-level tokens and the reconstructions meanwhile (partner_pu)
-        else p1_run(wave, P);
+        if (F.wide) {                                   // wide workgroup: pass and pricing shared with waves 7 and 6
+            pu_step_wide(wave, P, k);
+            prof_add(PF_P1_4, pt); pt = prof_now();
+        } else {
+        p1_run(wave, P);
         prof_add(PF_P1_4, pt); pt = prof_now();
         wave_sync();
         if (TU0_SHARE && k == 0) { LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); } }      // tokens in memory, SSE / reconstructions in this wave's slice: the four-TU wave's TU 0
         prof_add(PF_P1_16, pt); pt = prof_now();
-        if (F.wide) {                                   // wide workgroup: range half here, byte half + costs on the partner wavefront (partner_pu)
-            SplitQ &q = XM(2).q;
-            split_start(q);
-            LANES(l) {
-                const int on = l < NMODE, ll = on ? l : 0;
-                int range = 510, blk = 0;
-                const u16 *ts = tok + (size_t)ll * TOK_CAP + 8;
-                if (hint) stream_seg_R<true>(range, W.u.p2.cx[ll], q, l, blk, ts, on ? W.tokn[ll] - 8 : 0);
-                else { if (on) ctx_copy(W.u.p2.cx[ll], SM.cx0); stream_seg_R<false>(range, W.u.p2.cx[ll], q, l, blk, ts, on ? W.tokn[ll] - 8 : 0); }
-            }
-            split_await(&q.done, q);
-        } else
         LANES(l) {                                      // residual bits on a fresh coder and fresh contexts (:1504-1518)
             const int on = l < NMODE, ll = on ? l : 0;
             Arith a; arith_reset(a);
@@ -440,6 +516,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 #ifdef IMCVT_TOKSTAT
             if (on) fprintf(stderr, "TS %d %d %d %d %d %d %d %d\n", 4, wave, l, W.tokn[l] - 8, W.cost[l], W.sse[l], arith_len(a), -1);
 #endif
+        }
         }
         wave_sync_lds();
         prof_add(PF_P2_PU, pt); pt = prof_now();
@@ -459,6 +536,11 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             // the block boundary after PU 2 and after PU 3
             const int at = !pipe ? k * NXN_KEEP_STRIDE : k == 3 ? 3 * NXN_KEEP_STRIDE : (k >= 1 ? W.pu_cnt[0] : 0) + (k >= 2 ? W.pu_cnt[1] : 0);
             u16 *dst = nxn + NXN_KEEP + at;
+            if (F.wide && k != 0) {                     // wide workgroup: the winner's tokens lie in its lane row (cbf_luma + first part) and in wave 7's row (remaining levels); PU 0's streams went to memory
+                const int na1 = 1 + PUX.na[bm];
+                const u16 *ra = lane_row(W, bm) + 7, *rb = PUX.brow[bm];
+                for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), (int)(i < na1 ? ra[i] : rb[i - na1]));
+            } else
             for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), g_ld16((const i16 *)(src + i)));
             const int end = at + cnt;
             if (pipe && k >= 2 && l < 8 && ((end + l) >> 3) == (end >> 3) && (end & 7) != 0) g_st16((i16 *)(nxn + NXN_KEEP + end + l), (int)TOK_IDLE);
@@ -733,9 +815,10 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     WAVES_ALL(w) {
         if (w >= NWAVES && N < 16) {
             if (w == PIPE_WAVE) nxn_pipe(y0, x0);
+            else if (!F.wide) { }
             else if (w == WAVE_B_CODER) partner_fourtu(depth);                                                   // partner wavefronts of a wide workgroup (hevc_core.h, "who is whose partner"): 4 the trial coders of the four-TU set, segment by segment behind wave 1's passes
             else if (w == WAVE_A_PARTNER) { lend_passes(w, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }   // 5 a pass of the one-TU set, then the byte half of its trial coders
-            else if (w == WAVE_PIPE_PARTNER) partner_pipe();                                                     // 6 the byte half of the pipe wave's streams
+            else if (w == WAVE_PIPE_PARTNER) { partner_pu_early(y0, x0); partner_pipe(); }                        // 6 reconstructions + byte half of the pricing of PUs 0..2, then the byte half of the pipe wave's streams
             else partner_pu(y0, x0);                                                                             // 7 the PU chain's partner: remaining-level tokens, reconstructions, byte half of the pricing
         }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
@@ -809,6 +892,7 @@ HDN void enter_cu(int depth_, int N_, int y0_, int x0_, int code_split_, int avm
         const int tid = w * 64 + l;
         if (tid < CTX_STRIDE) SM.entry_cx[depth][tid] = SM.cx[tid];
         if (tid == 64) SM.entry_a[depth] = SM.live;
+        if (tid == 65 && N == 8 && F.wide) WCTL.cu8++;
     }
     wg_sync();
     if (F.mail && N >= 16) {     // pool: a helper starts on this CU's 70 unsplit candidates now — unless requests already wait unclaimed (every
@@ -1411,8 +1495,8 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; PUX.go = 0; PUX.bdone = 0; } }
-    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide(); SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.cu8 = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide() && PU_HINTS; SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;

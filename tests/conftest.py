@@ -96,9 +96,8 @@ def hostemu_wide_ovf(built):
 
 @pytest.fixture(scope="session")
 def hostemu_wide_leads(built):
-    """Wide workgroups with four-entry lead lists and four-token partner rows: nearly every PU candidate's stream has more leads and is
-    priced on the safe path, and most remaining-level parts overflow the partner's row and are made by the PU wave itself."""
-    return _hostemu_lib("libhostemu_wide_leads.so", ["-DEMU_DEFAULT_WIDE", "-DLEADS_CAP=4", "-DBROW_CAP=4"])
+    """Wide workgroups with four-entry lead lists: nearly every PU candidate's stream has more leads and is priced on the safe path."""
+    return _hostemu_lib("libhostemu_wide_leads.so", ["-DEMU_DEFAULT_WIDE", "-DLEADS_CAP=4"])
 
 
 @pytest.fixture(scope="session")
