@@ -510,7 +510,7 @@ struct alignas(16) PartnerMem {
 };
 // Control words of a wide workgroup's 8x8 CUs, and the LDS slices of the two partner wavefronts that LEND themselves for pipeline passes
 // (hevc_frame.h lend_passes: the one-TU candidate set's three passes of an 8x8 CU run on three wavefronts at once).
-#define NLEND 1
+#define NLEND 3
 struct alignas(16) WideCtl {
     i32 cu8;                                     // 8x8 CUs entered so far (enter_cu): the sequence numbers of their four PU steps follow from it
     i32 a_go, lend_done[NLEND];                  // one-TU set: generation whose headers are in place / finished by each lender
@@ -549,8 +549,8 @@ struct alignas(16) PuX {
 #define WAVE_A_PARTNER (PIPE_WAVE + 2)
 #define WAVE_PIPE_PARTNER (PIPE_WAVE + 3)
 #define WAVE_PU_PARTNER (PIPE_WAVE + 4)
-HD u8 *wave_mem_ptr(int w) {                     // a wavefront's WaveMem: waves 0..2 in the static image, the lender's (wave 5) in the dynamic part (wide workgroups only)
-    return w < NWAVES ? SM.wraw + w * sizeof(WaveMem) : (u8 *)DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl);
+HD u8 *wave_mem_ptr(int w) {                     // a wavefront's WaveMem: waves 0..2 in the static image, the lenders' (waves 5, 6, 7) in the dynamic part (wide workgroups only)
+    return w < NWAVES ? SM.wraw + w * sizeof(WaveMem) : (u8 *)DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + (w - WAVE_A_PARTNER) * sizeof(WaveMem);
 }
 HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
 HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }

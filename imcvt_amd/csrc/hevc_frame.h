@@ -281,7 +281,8 @@ HDN void partner_fourtu(int depth_) {
 HD int split_mode(int N, int shape) { return N == 32 ? (shape == 0 ? SPL32_0 : SPL32_1) : (shape == 0 ? SPL16_0 : SPL16_1); }   // passes come out balanced over the three waves
 HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int avm_) {
     const int wave = uni_i(wave_); const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
-    if (wave >= NWAVES) {                               // the pipe wave has no share in these sets: it only keeps the workgroup's barrier count
+    const int lender = F.wide && N >= 16 && (wave == WAVE_PIPE_PARTNER || wave == WAVE_PU_PARTNER);      // wide workgroups, 16x16 / 32x32 CUs: waves 6 and 7 take pipeline passes too
+    if (wave >= NWAVES && !lender) {                    // the pipe wave has no share in these sets: it only keeps the workgroup's barrier count
         if (N >= 16) {
             wg_sync_p(); wg_sync_p();
             if (F.wide && (wave == WAVE_A_PARTNER || wave == WAVE_B_CODER)) partner_trial(wave == WAVE_A_PARTNER ? 0 : 1, depth);      // wide workgroups: the byte half of the trial coders of waves 0 / 1 (on the other one's SIMD)
@@ -316,6 +317,13 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     P1Item it[2]; int nit = 1;
     if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = (wide8 && wave == 0) ? 16 : NMODE;
                 if (wide8 && wave == 0) { nit = 2; it[1].own = 0; it[1].shape = 0; it[1].lo = 32; it[1].hi = NMODE; } }      // (candidates 16..31: wave 5, lend_passes)
+    else if (F.wide) {                                  // five wavefronts: the one-TU set on waves 0 and 7, the four-TU set's mode chains on waves 1, 2 and 6
+        const int a0 = N == 32 ? 18 : 20, b0 = N == 32 ? 12 : 16, b1 = N == 32 ? 24 : 32;
+        const int sh = (wave == 0 || wave == WAVE_PU_PARTNER) ? 0 : 1;
+        it[0].own = sh; it[0].shape = sh;
+        it[0].lo = wave == 0 ? 0 : wave == WAVE_PU_PARTNER ? a0 : wave == 1 ? 0 : wave == 2 ? b0 : b1;
+        it[0].hi = wave == 0 ? a0 : wave == WAVE_PU_PARTNER ? NMODE : wave == 1 ? b0 : wave == 2 ? b1 : NMODE;
+    }
     else if (wave < 2) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = split_mode(N, wave); }
     else { nit = 2; for (int i = 0; i < 2; i++) { it[i].own = i; it[i].shape = i; it[i].lo = split_mode(N, i); it[i].hi = NMODE; } }
     P1Args P;
