@@ -283,10 +283,20 @@ def main():
         if os.path.exists(ip):
             iv = json.load(open(ip))
             insts = iv["valu_wave_insts_per_ctu"] * ctus
-            peak = 256 * 4 * 2.4e9 / 2                                     # wave-instructions/s: 256 CUs x 4 SIMDs, 2 cycles per wave64 VALU instruction (the packed-math rate)
-            peak4 = peak / 2                                               # plain 32-bit integer / select / shift instructions — all of this kernel — take 4 cycles per wave64
+            nominal = 256 * 4 * 2.4e9 / 2                                  # wave-instructions/s at 2 cycles per wave64 instruction (SIMD-32), the guide's figure for v_fma_f32
+            # what a SIMD sustains on THIS kernel's opcode mix, measured (tools/valu_mix_probe.py: four waves per SIMD on all 256 compute units, every opcode
+            # that makes up >= 0.4 % of the kernel's VALU instructions; adds / logic / right shifts 2.26 cycles, selects / compares / left shifts / bit-field /
+            # 3-operand / multiplies 4.1 - 4.4): the peak the issue fraction is taken against
+            mp = os.path.join(ROOT, "profiles", "valu_mix.json")
+            peak, peak_src = nominal, "nominal 2 cycles per wave64 VALU instruction (no measured mix in profiles/valu_mix.json)"
+            if os.path.exists(mp):
+                mv = json.load(open(mp))
+                peak = 256 * 4 * mv["clock_ghz"] * 1e9 / mv["mix_weighted_cycles_simd"]
+                peak_src = (f"measured: {mv['mix_weighted_cycles_simd']} cycles per wave64 VALU instruction on the kernel's static opcode mix ({round(100 * mv['share_covered'], 1)} % of its VALU "
+                            f"instructions covered), profiles/valu_mix.json (tools/valu_mix_probe.py); a lone wavefront issues one per {mv['mix_weighted_cycles_lone_wave']} cycles")
             line["roofline_issue"] = {"bound": "valu issue", "achieved": round(insts / k_avg / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-inst/s",
-                                      "frac": round(insts / k_avg / peak, 4), "peak_unpacked": round(peak4 / 1e9, 1), "frac_of_unpacked_peak": round(insts / k_avg / peak4, 4),
+                                      "frac": round(insts / k_avg / peak, 4), "peak_source": peak_src,
+                                      "peak_nominal_2_cycles": round(nominal / 1e9, 1), "frac_of_nominal": round(insts / k_avg / nominal, 4),
                                       "valu_wave_insts_per_ctu": iv["valu_wave_insts_per_ctu"], "lane_activity": iv.get("valu_lane_activity"),
                                       "valu_busy_frac_in_counter_run": iv["valu_busy_frac"], "source": stale(iv) + "instruction count per CTU and lane activity from " + iv["source"] + "; time from this run"}
         if world == 1 and not args.no_latency_view:
@@ -426,7 +436,18 @@ def latency_view(enc, dev, qpd6):
         if okd is False:
             raise SystemExit(f"latency_view {name}: stream differs from the reference digest")
         out[name] = {"kernel_ms": round(ms, 1), "mpx_s": round(w * h / ms / 1e3, 3), "bytes": n, "sha256_equal_to_reference": okd,
-                     "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe()}
+                     "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe(), "wide_workgroups": enc.last_wide()}
+    # the same 1080p frame with 256-thread workgroups (round 4's latency shape), and the per-GPU share of the 512-frame job at N = 8 (64 frames)
+    img = torch.from_numpy(synth.syn(1920, 1080, 0)).to(dev)
+    b = enc.make_batch([img], qpd6)
+    enc.set_wide(0); enc.encode(b); out["1080p_256_thread_workgroups"] = {"kernel_ms": round(enc.last_kernel_ms(), 1), "wide_workgroups": enc.last_wide()}; enc.set_wide(-1)
+    imgs64 = [torch.from_numpy(synth.syn(1920, 1080, s)).to(dev) for s in range(64)]
+    b64 = enc.make_batch(imgs64, qpd6)
+    enc.encode(b64)
+    ms64 = enc.last_kernel_ms()
+    out["64_frames"] = {"what": "64 x 1080p in one launch = one GPU's share of BASELINE configs[3] at N = 8", "kernel_ms": round(ms64, 1), "mpx_s": round(64 * 1920 * 1080 / ms64 / 1e3, 2),
+                        "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe(), "wide_workgroups": enc.last_wide()}
+    del b64, imgs64
     # BASELINE configs[0]: the reference's own sample picture (image/P4.pnm, 21 x 17 raw PBM -> one 32 x 32 CTU; its pixels as gray8 are tests/golden/p4_gray.pgm) through the
     # reference-shaped FILE entry point, writeHEVCImageFile (src/imageio_hevc.c:9): host buffers, PCIe, the launch and the file write included
     import tempfile

@@ -249,18 +249,20 @@ def test_auto_team_choice_and_full_hd_team(amd):
 
 
 @pytest.mark.parametrize("team", [1, 3])
-@pytest.mark.parametrize("pipe", [0, 1])
+@pytest.mark.parametrize("pipe", [0, 1, 2])
 def test_pipe_wave_on_and_off(amd, pipe, team):
     """256-thread workgroups whose fourth wavefront prices the NxN candidate of the 8x8 CUs ahead of the PU wave (hevc_frame.h
-    nxn_pipe) against 192-thread ones, alone and as main workgroups of a pool: all small golden vectors, twice each."""
+    nxn_pipe) against 192-thread ones, alone and as main workgroups of a pool: all small golden vectors, twice each.
+    pipe 2: 512-thread wide workgroups — pipe wave + four partner wavefronts, every trial coder split over two wavefronts, the PU
+    steps over three (hevc_core.h stream_seg_R / stream_seg_L, hevc_frame.h pu_step_wide) — as main workgroups, helpers and alone."""
     import torch
     enc = amd.DeviceEncoder()
-    enc.set_pipe(pipe); enc.set_team(team)
+    enc.set_pipe(min(pipe, 1)); enc.set_wide(-1 if pipe == 2 else 0); enc.set_team(team)
     batch = enc.make_batch([torch.from_numpy(np.ascontiguousarray(kat_input(e["input"]))).cuda() for e in SMALL], [e["qpd6"] for e in SMALL])
     for rep in range(2):
         enc.encode(batch)
         got = enc.results(batch)
-        assert enc.last_pipe() == bool(pipe) and enc.last_team()[0] == team
+        assert enc.last_pipe() == bool(pipe) and enc.last_wide() == (pipe == 2) and enc.last_team()[0] == team
         bad = [kat_id(e) for e, (s, r) in zip(SMALL, got)
                if len(s) != e["bytes"] or hashlib.sha256(s).hexdigest() != e["sha256"] or hashlib.sha256(r.tobytes()).hexdigest() != e["rcon_sha256"]]
         assert not bad, (pipe, team, rep, bad)
@@ -287,6 +289,33 @@ def test_pipe_wave_full_hd_frame_and_launches_too_large_for_it(amd):
     sub = enc.make_batch(imgs[:300], 1)
     enc.encode(sub); b = enc.results(sub)
     assert enc.last_pipe()
+    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, b))
+    enc.close()
+
+
+def test_wide_workgroups_full_hd_frame_and_launches_too_large_for_them(amd):
+    """One 1080p frame runs wide workgroups by default (one main + two helper workgroups of 512 threads, a compute unit each) and has
+    the reference's digest; so has the same frame with them switched off; 64 frames (64 + 128 workgroups) still run wide, a launch
+    that needs more workgroups than there are compute units does not — same bytes either way."""
+    import torch
+    from oracle import synth
+    e = next(e for e in LARGE if (e["input"]["arg"], e["qpd6"]) == (3, 0))
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, 3)).cuda()], 0)
+    for wide in (-1, 0):
+        enc.set_wide(wide)
+        enc.encode(batch)
+        (s, r), = enc.results(batch)
+        assert enc.last_pipe() and enc.last_wide() == (wide != 0) and enc.last_team()[0] == 3
+        assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
+    imgs = [torch.from_numpy(synth.syn(160, 96, i)).cuda() for i in range(128)]
+    enc.set_wide(-1)
+    b64 = enc.make_batch(imgs[:64], 0)
+    enc.encode(b64); a = enc.results(b64)
+    assert enc.last_wide() and enc.last_shape() == (64, 128)
+    b128 = enc.make_batch(imgs, 0)
+    enc.encode(b128); b = enc.results(b128)
+    assert not enc.last_wide()
     assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, b))
     enc.close()
 

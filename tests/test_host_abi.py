@@ -156,6 +156,10 @@ def test_launch_shape_policy(built):
         assert use == (mm + hh <= 720)
     m, h = C.c_int(512), C.c_int(256)
     assert lib.imcvt_hevc_plan_pipe(2, 1024, 1, C.byref(m), C.byref(h)) == 1 and (m.value, h.value) == (512, 256)      # a forced shape may fill the last slot
+    # wide workgroups (512 threads, one per compute unit): whenever a pipe-wave launch leaves every workgroup a compute unit of its own, a sixteenth to spare
+    assert lib.imcvt_hevc_plan_wide(1, 3, 256, 0) == 1 and lib.imcvt_hevc_plan_wide(1, 192, 256, 0) == 1 and lib.imcvt_hevc_plan_wide(1, 240, 256, 0) == 1
+    assert lib.imcvt_hevc_plan_wide(1, 241, 256, 0) == 0 and lib.imcvt_hevc_plan_wide(1, 256, 256, 1) == 1 and lib.imcvt_hevc_plan_wide(1, 257, 256, 1) == 0
+    assert lib.imcvt_hevc_plan_wide(0, 3, 256, 0) == 0 and lib.imcvt_hevc_plan_wide(1, 3, 0, 0) == 0
 
 
 def test_submission_queue_merges_concurrent_callers(built):
