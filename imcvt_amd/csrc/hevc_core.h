@@ -543,8 +543,8 @@ struct alignas(16) PuX {
 // Who is whose partner follows from where wavefronts run: wavefronts w and w + 4 of a workgroup share a SIMD (tools/simd_map_probe.hip,
 // profiles/r05_simd_map.log), and a SIMD serves ONE wavefront's stream of shifts / bit-field / select instructions at full speed, not two
 // (tools/valu_rate_probe.hip) — so the two halves of a chain sit on different SIMDs, and the PU chain's SIMD-mates are the wavefronts with the least to do:
-//     SIMD a: wave 0 (one-TU set)   + wave 4 (coders of the four-TU set)          SIMD c: wave 2 (PU chain)  + wave 6 (byte half of the pipe wave: idle until PU 2 is decided)
-//     SIMD b: wave 1 (four-TU set)  + wave 5 (a pass + byte half of the one-TU set) SIMD d: wave 3 (pipe wave) + wave 7 (partner of the PU chain)
+//     SIMD a: wave 0 (one-TU set)   + wave 4 (coders of the four-TU set)            SIMD c: wave 2 (PU chain)  + wave 6 (byte half of the pipe wave: idle until PU 2 is decided)
+//     SIMD b: wave 1 (four-TU set)  + wave 5 (a pass + byte half of the one-TU set) SIMD d: wave 3 (pipe wave; before PU 2 is decided: reconstructions + byte half of the PU pricing) + wave 7 (remaining-level tokens of the PU chain)
 #define WAVE_B_CODER (PIPE_WAVE + 1)
 #define WAVE_A_PARTNER (PIPE_WAVE + 2)
 #define WAVE_PIPE_PARTNER (PIPE_WAVE + 3)
@@ -879,6 +879,32 @@ HDN_BFT void border_from_tile(int wave_, int N_, int y0_, int x0_, int hl_, int 
         }
     }
     wave_sync();
+}
+
+// The same for a 4x4 block, inline and in one step (the PU chain of an 8x8 CU in a wide workgroup walks it four times per CU): 4x4 blocks are
+// predicted from the unfiltered samples only (:274-280), so the [1 2 1] variants are not made, and the DC value is summed from the tile directly.
+HD void border4_from_tile(WaveMem &W, int y0, int x0, int hl, int hbl, int ha, int har) {
+    Border &b = W.bsh;
+    LANES(l) {
+        const u8 *t = &SM.rec[y0 + 1][x0 + 1];
+        const int uc = (hl && ha) ? t[-RS - 1] : hl ? t[-1] : ha ? t[-RS] : 128;
+        if (l < 8) {
+            int lv_, av_;
+            if (l < 4) { lv_ = hl ? t[l * RS - 1] : uc; av_ = ha ? t[-RS + l] : uc; }
+            else {
+                lv_ = hbl ? t[l * RS - 1] : (hl ? t[3 * RS - 1] : uc);
+                av_ = har ? t[-RS + l] : (ha ? t[-RS + 3] : uc);
+            }
+            b.ul[l] = (u8)lv_; b.ua[l] = (u8)av_;
+        }
+        if (l == 8) {
+            int dc = 4;
+            for (int i = 0; i < 4; i++) dc += (hl ? t[i * RS - 1] : uc) + (ha ? t[-RS + i] : uc);
+            b.dc = (i16)(dc >> 3);
+            b.uc = (u8)uc; b.ul[8] = 0; b.ua[8] = 0;
+        }
+    }
+    wave_sync_lds();
 }
 
 // Per-mode borders of TU k (1..3) of the four-TU shape of the CU at (y0,x0,N): samples inside the CU come
@@ -2441,6 +2467,48 @@ HD u32 token_R(int &range, u8 *cx, u32 tok) {
     range = byp ? range : (r2 << sh);
     return rec;
 }
+// The same over a block of eight tokens with the context side run ONE TOKEN AHEAD: the context recurrence (state -> next state, :913-920) does
+// not involve the range, so the state of token j + 1 and its table entry are read while token j's range arithmetic runs — BEFORE token j's
+// state is written back, hence corrected when both tokens use the same context (then the state is token j's next state, known at once, and its
+// table entry was read at the start of token j as well).  Same states, same bins, same order as token_R eight times; a lone wavefront just no
+// longer waits two LDS round trips per token.
+HD void block_R8(int &range, u8 *cx, const U4 &cur, u32 rec[8]) {
+    u32 tok = tok_of(cur, 0);
+    u32 cim = tok >> 8;
+    int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
+    int pz = cx[ci];
+    uint2 e = SM.T.pst[pz];
+    UNROLL_FULL
+    for (int j = 0; j < 8; j++) {
+        const int is_lps = (int)(tok ^ (u32)pz) & 1;
+        const int nx = (int)((is_lps ? e.y : e.y >> 8) & 255u);          // the state this token leaves its context in
+        u32 tokn = 0; int cin = 0, pzn = 0; uint2 en, ef; en.x = en.y = ef.x = ef.y = 0;
+        if (j < 7) {                                                     // next token's reads, ahead of this token's write
+            tokn = tok_of(cur, j + 1);
+            const u32 cimn = tokn >> 8;
+            cin = (int)(cimn < (u32)CX_PAD ? cimn : (u32)CX_PAD);
+            pzn = cx[cin];
+            ef = SM.T.pst[nx];                                           // (its entry if it meets this token's context again)
+            en = SM.T.pst[pzn];
+        }
+        const int byp = tok >= 0x8000u;
+        const int lps = (int)((e.x >> ((range >> 3) & 24)) & 0xFF);
+        const int rm = range - lps;
+        const int r2 = is_lps ? lps : rm;
+        const int sh = clz_nz((u32)r2) - 23;
+        cx[ci] = (u8)nx;
+        const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+        const int add = (is_lps & !byp) ? rm : 0;
+        rec[j] = (u32)add | (u32)range << 9 | (u32)nb_ << 18 | (byp ? (tok & 255u) << 22 : 0u);
+        range = byp ? range : (r2 << sh);
+        if (j < 7) {
+            const int same = cin == ci;
+            pz = same ? nx : pzn;
+            e.x = same ? ef.x : en.x; e.y = same ? ef.y : en.y;
+            tok = tokn; ci = cin;
+        }
+    }
+}
 HD u32 token_R_res(int &range, u32 tok, u32 lw) {                // resolved tokens (code_token_r): no context copy
     const int byp = tok >= 0x8000u;
     const int lps = (int)((lw >> ((range >> 3) & 24)) & 0xFF);
@@ -2495,8 +2563,12 @@ HD void stream_seg_R(int &range, u8 *cx, SplitQ &q, int lane, int &blk, const u1
                 UNROLL_FULL
                 for (int j = 0; j < 8; j++) rec[j] = token_R_res(range, tok_of(cur, j), lw[j]);
             } else {
+#ifdef IMCVT_R_PLAIN
                 UNROLL_FULL
                 for (int j = 0; j < 8; j++) rec[j] = token_R(range, cx, tok_of(cur, j));
+#else
+                block_R8(range, cx, cur, rec);
+#endif
             }
             u32 *d = row + (blk & (QDEPTH - 1)) * 8;
             UNROLL_FULL

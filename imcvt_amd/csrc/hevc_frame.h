@@ -192,9 +192,12 @@ HDN void partner_pu(int y0_, int x0_) {
     if (F.prio_base) SETPRIO(2); else SETPRIO(0);
 #endif
 }
-// wave 6 before it becomes the pipe wave's partner: reconstructions and pricing of PUs 0..2
+// the pipe wave before PU 2 is decided: reconstructions and pricing of PUs 0..2
 HDN void partner_pu_early(int y0_, int x0_) {
     const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
+#ifndef IMCVT_HOSTEMU
+    if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);      // (part of the PU chain)
+#endif
     for (int k = 0; k < 3; k++) pu_recon_price(y0, x0, k);
 }
 // A lender wavefront (wide workgroups): candidates lo .. hi-1 of the one-TU set of the 8x8 CU at (y0, x0), exactly as wave 0 runs its own
@@ -465,13 +468,16 @@ HD void pu_step_wide(int wave, const P1Args &P, int k) {
             for (int i = 0; i < 7; i++) if (((end + i) >> 3) == (end >> 3) && (end & 7) != 0) g_st16((i16 *)(g + end + i), (int)TOK_IDLE);
         }
     }
+    long long t5 = prof_now();
     if (TU0_SHARE && k == 0) {
         wave_sync();                                    // the streams are in memory
         while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // ... and SSE / reconstructions in this wave's slice (long since)
         wave_sync_lds();
         LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); }
     }
+    prof_add(PF_X1, t5); t5 = prof_now();
     split_await(&q.done, q);                            // the costs
+    prof_add(PF_X2, t5);
 }
 HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     const int wave = uni_i(wave_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
@@ -500,7 +506,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.tokn[l] = 7; blk_idle((u32a *)W.pend[l]); } }
         wave_sync_lds();
         long long pt = prof_now();
-        border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
+        if (F.wide) border4_from_tile(W, yk, xk, ca.l, ca.bl, ca.a, ca.ar); else border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
         prof_add(PF_P1_32, pt); pt = prof_now();            // (NxN chain, IMCVT_PROF builds: p1_32 = borders, p1_16 = store drain before pricing, p1_8 = pick + keep,
         P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
@@ -822,11 +828,11 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     u8 *live_sink = F.job.out + F.out_pos;
     WAVES_ALL(w) {
         if (w >= NWAVES && N < 16) {
-            if (w == PIPE_WAVE) nxn_pipe(y0, x0);
+            if (w == PIPE_WAVE) { if (F.wide) partner_pu_early(y0, x0); nxn_pipe(y0, x0); }      // (wide workgroups: until PU 2 is decided the pipe wave has nothing of its own to do — reconstructions and byte half of the pricing of PUs 0..2, on a SIMD the PU wave does not run on)
             else if (!F.wide) { }
             else if (w == WAVE_B_CODER) partner_fourtu(depth);                                                   // partner wavefronts of a wide workgroup (hevc_core.h, "who is whose partner"): 4 the trial coders of the four-TU set, segment by segment behind wave 1's passes
             else if (w == WAVE_A_PARTNER) { lend_passes(w, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }   // 5 a pass of the one-TU set, then the byte half of its trial coders
-            else if (w == WAVE_PIPE_PARTNER) { partner_pu_early(y0, x0); partner_pipe(); }                        // 6 reconstructions + byte half of the pricing of PUs 0..2, then the byte half of the pipe wave's streams
+            else if (w == WAVE_PIPE_PARTNER) partner_pipe();                                                     // 6 the byte half of the pipe wave's streams (the PU wave's SIMD-mate: idle while the first three PUs are walked)
             else partner_pu(y0, x0);                                                                             // 7 the PU chain's partner: remaining-level tokens, reconstructions, byte half of the pricing
         }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
