@@ -572,10 +572,24 @@ HD void prof_cnt(int, int) {}
 #endif
 // Wave collectives for the decisions: the reference's "last minimum wins" scan (`best >= cost` accepts, :1439, :1475, :1520)
 // over a wave's lanes = the minimum over the valid lanes, then the highest valid lane that holds it.
+#ifdef IMCVT_HOSTEMU
 HD int wave_min_i32(int v, int l) {
     for (int d = 32; d >= 1; d >>= 1) v = imin(v, wave_shfl(v, l ^ d));
     return v;
 }
+#else
+// minimum over the wavefront by data-parallel-primitive moves (no LDS round trips: six of them were ~400 cycles on the PU chain's pick):
+// within quads, half rows and rows of 16, then row 15 -> rows 1 / 3 and lane 31 -> the upper half; lane 63 holds the minimum
+HD int wave_min_i32(int v, int) {
+    v = imin(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));       // quad_perm [1,0,3,2]
+    v = imin(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));       // quad_perm [2,3,0,1]
+    v = imin(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));      // row_half_mirror
+    v = imin(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));      // row_mirror
+    v = imin(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));      // row_bcast:15 into rows 1 and 3
+    v = imin(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));      // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
 HD int hibit64(u64 m) { return (m >> 32) ? 32 + hibit((u32)(m >> 32)) : hibit((u32)m); }
 // returns the winning lane (valid lanes only; at least one lane must be valid); *mn receives the minimum
 HD int wave_last_min(int cost, int valid, int l, int *mn) {
@@ -2522,6 +2536,21 @@ HD u32 token_R_res(int &range, u32 tok, u32 lw) {                // resolved tok
     range = byp ? range : (r2 << sh);
     return rec;
 }
+// The pricing of the PU candidates (stream_seg_R_lds -> stream_seg_L1) uses a leaner record: v | nb << 17 with v = add << nb for a context
+// bin, range * value for a bypass chunk — low = (low << nb) + v either way, one instruction on the byte side.
+HD u32 token_R_res2(int &range, u32 tok, u32 lw) {
+    const int byp = tok >= 0x8000u;
+    const int lps = (int)((lw >> ((range >> 3) & 24)) & 0xFF);
+    const int rm = range - lps;
+    const int is_lps = (int)(tok ^ (tok >> 1)) & 1;
+    const int r2 = is_lps ? lps : rm;
+    const int sh = clz_nz((u32)r2) - 23;
+    const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+    const int v = byp ? mul24(range, (int)(tok & 255u)) : ((is_lps ? rm : 0) << sh);      // (rm << sh < 2^15, range * value < 2^17)
+    const u32 rec = (u32)v | (u32)nb_ << 17;
+    range = byp ? range : (r2 << sh);
+    return rec;
+}
 HD void token_L(Arith &a, u16 *lq, int &qn, u32 rec) {
     const int add = (int)(rec & 511u), rg = (int)((rec >> 9) & 511u), nb_ = (int)((rec >> 18) & 15u), val = (int)(rec >> 22);
     a.low = ((a.low + add) << nb_) + mul24(rg, val);
@@ -2606,7 +2635,7 @@ HD void stream_seg_R_lds(int &range, SplitQ &q, int lane, int &blk, const u16 *p
             UNROLL_FULL
             for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
             UNROLL_FULL
-            for (int j = 0; j < 8; j++) rec[j] = token_R_res(range, tok_of(cur, j), lw[j]);
+            for (int j = 0; j < 8; j++) rec[j] = token_R_res2(range, tok_of(cur, j), lw[j]);
             u32 *d = row + (blk & (QDEPTH - 1)) * 8;
             UNROLL_FULL
             for (int j = 0; j < 8; j++) d[j] = rec[j];
@@ -2654,8 +2683,8 @@ HD void stream_seg_L1(Arith &a, u16 *leads, int &qn, SplitQ &q, int lane, int &b
             UNROLL_FULL
             for (int j = 0; j < 8; j++) {
                 const u32 r = rec[j];
-                const int add = (int)(r & 511u), rg = (int)((r >> 9) & 511u), nb_ = (int)((r >> 18) & 15u), val = (int)(r >> 22);
-                a.low = ((a.low + add) << nb_) + mul24(rg, val);
+                const int v = (int)(r & 0x1FFFFu), nb_ = (int)(r >> 17);      // (token_R_res2's records)
+                a.low = (a.low << nb_) + v;
                 a.nbits -= nb_;
                 const int need = a.nbits < 12;
                 leads[qn < LEADS_CAP ? qn : LEADS_CAP] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));      // always written; only kept when `need`
