@@ -200,6 +200,23 @@ HDN void partner_pu_early(int y0_, int x0_) {
 #endif
     for (int k = 0; k < 3; k++) pu_recon_price(y0, x0, k);
 }
+// owner of a 2Nx2N candidate set in a wide workgroup: the range half of its 35 trial coders (final coder states and costs are the partner's to
+// write, before the barrier that follows the candidate sets).  Out of line, so that the other launch shapes' eval_2Nx2N is not charged its registers.
+HDN void coder_range_half(int wave_, int depth_) {
+    const int wave = uni_i(wave_); const int depth = uni_i(depth_);
+    WaveMem &W = WM(wave);
+    SplitQ &q = XM(wave).q;
+    const u16 *tok = wave_tok(F.sc, wave);
+    split_start(q);
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        int range = SM.entry_a[depth].range, blk = 0;
+        if (on) ctx_copy(W.u.p2.cx[ll], SM.entry_cx[depth]);
+        stream_seg_R<false>(range, W.u.p2.cx[ll], q, l, blk, tok + (size_t)ll * TOK_CAP, on ? W.tokn[ll] : 0);
+        if (on) q.range_out[l] = range;
+    }
+    split_flag(&q.rdone, q);
+}
 // A lender wavefront (wide workgroups): candidates lo .. hi-1 of the one-TU set of the 8x8 CU at (y0, x0), exactly as wave 0 runs its own
 // (eval_2Nx2N: same border, same pass, tokens / counts / SSE into wave 0's arrays and streams) on this wavefront's own slice.
 HDN void lend_passes(int wave_, int li_, int lo_, int hi_, int y0_, int x0_, int avm_) {
@@ -368,18 +385,8 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 #ifndef IMCVT_HOSTEMU
     if (big) { if (F.prio_base) SETPRIO(3); else SETPRIO(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
 #endif
-    if (F.wide) {                                       // wide workgroup: this wavefront runs the range half, wave 4 + `wave` the byte half (partner_trial)
-        SplitQ &q = XM(wave).q;
-        split_start(q);
-        LANES(l) {
-            const int on = l < NMODE, ll = on ? l : 0;
-            int range = SM.entry_a[depth].range, blk = 0;
-            if (on) ctx_copy(W.u.p2.cx[ll], SM.entry_cx[depth]);
-            stream_seg_R<false>(range, W.u.p2.cx[ll], q, l, blk, tok + (size_t)ll * TOK_CAP, on ? W.tokn[ll] : 0);
-            if (on) q.range_out[l] = range;
-        }
-        split_flag(&q.rdone, q);                        // (final coder states and costs are the partner's to write, before the barrier that follows the candidate sets)
-    } else
+    if (F.wide) coder_range_half(wave, depth);          // wide workgroup: this wavefront runs the range half of its 35 coders, a partner wavefront the byte half (partner_trial)
+    else
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a = SM.entry_a[depth];
@@ -411,7 +418,11 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 //             then, once wave 7 has made them, over the remaining-level rows; PU 0 only: the complete streams to memory (the four-TU wave's TU 0)
 //   wave 7    remaining-level tokens (pu_part_b)          wave 6 (wave 7 for PU 3)    reconstructions, SSE, byte half of the pricing, costs (pu_recon_price)
 // Same tokens in the same order as p1_run_4 writes, same coder arithmetic as run_trial_r.
-HD void pu_step_wide(int wave, const P1Args &P, int k) {
+HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out of line: inlined, its registers would be eval_NxN's — and the 192- / 256-thread shapes' — to pay for)
+    const int wave = uni_i(wave_); const int k = uni_i(k_);
+    P1Args P;
+    P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = wave_tok(F.sc, wave); P.N = 4; P.y0 = uni_i(yk_); P.x0 = uni_i(xk_); P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
+    P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
     PuX &U = PUX; SplitQ &q = XM(2).q;
@@ -512,7 +523,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
         P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = hint;
         if (F.wide) {                                   // wide workgroup: pass and pricing shared with waves 7 and 6
-            pu_step_wide(wave, P, k);
+            pu_step_wide(wave, yk, xk, k);
             prof_add(PF_P1_4, pt); pt = prof_now();
         } else {
         p1_run(wave, P);
@@ -640,6 +651,38 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 #endif
 }
 
+#define PIPE_HDR_OFF 2048     // the 35 header streams: token PIPE_HDR_OFF.. of the PU wave's candidate slots (a PU candidate uses < 200)
+// the pipe wave's coders in a wide workgroup: range half of the 35 speculative NxN streams (header, winners of PUs 0..2, PU 3's winner on the lane that guessed its mode)
+HDN void nxn_pipe_wide() {
+    WaveMem &W = PM;
+    const WaveMem &W2 = WM(2);
+    u16 *tok2 = wave_tok(F.sc, 2);
+    const u16 *kept = tok2 + (size_t)NMODE * TOK_CAP + NXN_KEEP;
+        SplitQ &q = XM(PIPE_WAVE).q;
+        split_start(q);
+        LANES(l) {
+            const int on = l < NMODE, ll = on ? l : 0;
+            const int nh = W.tokn[ll];
+            u8 *cx = W.u.p2.cx[ll];
+            const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
+            int range = SM.entry_a[2].range, blk = 0;
+            if (on) ctx_copy(cx, SM.entry_cx[2]);
+            stream_seg_R<false>(range, cx, q, l, blk, hdr, on ? nh : 0);
+            const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
+            stream_seg_R<false>(range, cx, q, l, blk, kept, on ? n012 : 0);
+            while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
+            wave_sync();
+            if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));      // PU 3 is decided: the partner may go on too
+            const int mine = on & (l == W2.pu_mode[3]);
+            stream_seg_R<false>(range, cx, q, l, blk, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+            if (mine) { q.range_out[l] = range; SM.nxn_lane = l; }
+            if (l == 0) { lds_st_i32(&SM.pipe_a, 0); lds_st_i32(&SM.pipe_b, 0); }
+        }
+        split_flag(&q.rdone, q);
+#ifndef IMCVT_HOSTEMU
+        if (F.prio_base) SETPRIO(2); else SETPRIO(0);
+#endif
+}
 // ---- the NxN trial of an 8x8 CU on the pipe wave (256-thread launches) -------------------------------------------------
 // The NxN stream is header, then the four PU winners' residuals (:1530-1543), and the header names all four PU modes — so the
 // trial cannot start before PU 3 is decided, and on the PU wave it is a serial tail of ~190 tokens coded by one lane.  Here
@@ -648,7 +691,6 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 // guessed its mode codes PU 3's winner and holds the trial's result; what is left of the tail is that one segment.
 // The stream is coded in three segments (header; PUs 0..2, kept back to back; PU 3), each padded to a token block with idle tokens,
 // which leave the coder untouched: same bins in the same order as :1530-1543.
-#define PIPE_HDR_OFF 2048     // the 35 header streams: token PIPE_HDR_OFF.. of the PU wave's candidate slots (a PU candidate uses < 200)
 HDN_EVAL void nxn_pipe(int y0_, int x0_) {
     const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
 #ifndef IMCVT_HOSTEMU
@@ -682,33 +724,7 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
         }
     }
     wave_sync();                                        // the headers are in memory; the token rows make room for the coders' contexts
-    if (F.wide) {                                       // wide workgroup: the range half of the 35 streams here, the byte half on the partner wavefront (partner_pipe)
-        SplitQ &q = XM(PIPE_WAVE).q;
-        split_start(q);
-        LANES(l) {
-            const int on = l < NMODE, ll = on ? l : 0;
-            const int nh = W.tokn[ll];
-            u8 *cx = W.u.p2.cx[ll];
-            const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
-            int range = SM.entry_a[2].range, blk = 0;
-            if (on) ctx_copy(cx, SM.entry_cx[2]);
-            stream_seg_R<false>(range, cx, q, l, blk, hdr, on ? nh : 0);
-            const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
-            stream_seg_R<false>(range, cx, q, l, blk, kept, on ? n012 : 0);
-            while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
-            wave_sync();
-            if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));      // PU 3 is decided: the partner may go on too
-            const int mine = on & (l == W2.pu_mode[3]);
-            stream_seg_R<false>(range, cx, q, l, blk, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
-            if (mine) { q.range_out[l] = range; SM.nxn_lane = l; }
-            if (l == 0) { lds_st_i32(&SM.pipe_a, 0); lds_st_i32(&SM.pipe_b, 0); }
-        }
-        split_flag(&q.rdone, q);
-#ifndef IMCVT_HOSTEMU
-        if (F.prio_base) SETPRIO(2); else SETPRIO(0);
-#endif
-        return;
-    }
+    if (F.wide) { nxn_pipe_wide(); return; }           // wide workgroup: the range half of the 35 streams here, the byte half on the partner wavefront (partner_pipe)
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         const int nh = W.tokn[ll];

@@ -21,7 +21,10 @@
 #ifndef KERNEL_MIN_WAVES
 #define KERNEL_MIN_WAVES 3          // waves per SIMD the register budget is cut for: 3 = 168 registers (four 192-thread or three 256-thread workgroups per compute unit)
 #endif
-__global__ __launch_bounds__(WG_THREADS_WIDE, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
+#ifndef KERNEL_MAX_THREADS
+#define KERNEL_MAX_THREADS WG_THREADS_WIDE
+#endif
+__global__ __launch_bounds__(KERNEL_MAX_THREADS, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
                                                                  TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk) {
     KArgs A;
@@ -189,6 +192,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
         if (!prewarm()) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
         // census: a launch of max_wg (pipe_wg) workgroups that only count themselves — what is resident at once is what the plans may use
         if (max_workgroups <= 0 && !getenv("IMCVT_HEVC_NO_CENSUS")) {
+            if (c->wide_wg > 0 && c->wide != 0) { const int cw = census(c, c->wide_wg, 2); if (cw > 0 && cw < c->wide_wg) { fprintf(stderr, "imcvt_hevc: %d of %d wide workgroups resident - planning with %d\n", cw, c->wide_wg, cw); c->wide_wg = cw; } }
             c->census_pipe = census(c, c->pipe_wg, 1); c->census_wg = census(c, c->max_wg, 0);
             if (c->census_wg > 0 && c->census_wg < c->max_wg) { fprintf(stderr, "imcvt_hevc: %d of %d workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_wg, c->max_wg, c->occ_wg, c->census_wg); c->max_wg = c->census_wg; }
             if (c->census_pipe > 0 && c->census_pipe < c->pipe_wg) { fprintf(stderr, "imcvt_hevc: %d of %d pipe-wave workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_pipe, c->pipe_wg, c->occ_pipe, c->census_pipe); c->pipe_wg = c->census_pipe; }
@@ -225,6 +229,17 @@ extern "C" int imcvt_hevc_last_wide(imcvt_hevc_ctx *c) { return c ? c->last_wide
 extern "C" int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape) {
     if (!use_pipe || grid < 1 || wide_wg < 1) return 0;
     return grid <= (forced_shape ? wide_wg : wide_wg - wide_wg / 16) ? 1 : 0;
+}
+// ... and a pool that does not fit that way still runs wide when its main workgroups take at most half of the compute units: the helpers are
+// cut to the rest (*nhelp; one per main workgroup at least) — 128 frames: 128 + 128 wide workgroups (2.92 s) against 128 + 256 of 256 threads
+// (3.28 s), profiles/r05s_wide_128f_shapes.log.  Every workgroup then needs a compute unit of its own, none to spare: nothing in a pool depends
+// on a workgroup that is not running, so a missing compute unit costs time, not results.  Returns 1 if the launch runs wide.
+extern "C" int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shape, int wide_wg, const int *nmains, int *nhelp) {
+    if (!nmains || !nhelp) return 0;
+    if (imcvt_hevc_plan_wide(use_pipe, *nmains + *nhelp, wide_wg, forced_shape)) return 1;
+    if (!use_pipe || forced_shape || mode < 2 || *nmains < 1 || 2 * *nmains > wide_wg) return 0;
+    *nhelp = wide_wg - *nmains;
+    return 1;
 }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) {
@@ -330,7 +345,13 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     int nmains = 0, nhelp = 0, forced = 0;
     const int mode = pick_shape(c, n, &nmains, &nhelp, &forced);
-    const int use_pipe = (mode > 0 && c->pipe != 0) ? plan_pipe_wg(mode, c->max_wg, c->pipe_wg, forced, &nmains, &nhelp) : 0;
+    int use_pipe = (mode > 0 && c->pipe != 0) ? plan_pipe_wg(mode, c->max_wg, c->pipe_wg, forced, &nmains, &nhelp) : 0;
+    int use_wide = 0;
+    if (mode > 0 && c->pipe != 0 && c->wide != 0) {      // (a pool too large for 256-thread workgroups with its planned helpers may still fit wide ones with fewer)
+        int h2 = nhelp;
+        use_wide = imcvt_hevc_plan_wide_pool(1, mode, forced, c->wide_wg, &nmains, &h2);
+        if (use_wide) { nhelp = h2; use_pipe = 1; }
+    }
     const int grid = nmains + nhelp;
     if (mode <= 0 || grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) {
         fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap);
@@ -366,7 +387,8 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     c->last_mains = nmains; c->last_help = nhelp;
     c->last_pipe = use_pipe;
-    c->last_wide = c->wide != 0 ? imcvt_hevc_plan_wide(use_pipe, grid, c->wide_wg, forced) : 0;
+    c->last_wide = use_wide;
+
     HIPCHK(hipEventRecord(c->ev0, stream));
     launch(c, grid, stream, n, mode, nmains, nhelp, c->last_wide ? 2 : c->last_pipe);
     HIPCHK(hipGetLastError());

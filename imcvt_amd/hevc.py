@@ -26,7 +26,7 @@ ERRORS = {-1: "no HIP device visible (no CPU fallback)", -2: "HIP runtime error"
 EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "imcvt_hevc_create", "imcvt_hevc_destroy",
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
-           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
+           "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_plan_wide_pool", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
            "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats")
 
 
@@ -92,6 +92,8 @@ def load_library():
         lib.imcvt_hevc_last_wide.argtypes = [C.c_void_p]
         lib.imcvt_hevc_plan_wide.restype = C.c_int
         lib.imcvt_hevc_plan_wide.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.imcvt_hevc_plan_wide_pool.restype = C.c_int
+        lib.imcvt_hevc_plan_wide_pool.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.imcvt_hevc_last_team.restype = C.c_int
     lib.imcvt_hevc_last_team.argtypes = [C.c_void_p, _ip]
     lib.imcvt_hevc_batch_devices.restype = C.c_int

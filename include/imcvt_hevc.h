@@ -124,6 +124,10 @@ int imcvt_hevc_last_wide(imcvt_hevc_ctx *ctx);
 /* Pure: does a launch of `grid` workgroups that runs with the pipe wave (use_pipe) run wide workgroups, given `wide_wg` resident
  * 512-thread workgroups (occupancy x compute units)?  A sixteenth of them stays free unless the shape is forced. */
 int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape);
+/* Pure: the same for a launch shape (*nmains, *nhelp as imcvt_hevc_plan / imcvt_hevc_plan_pipe left them; mode = what imcvt_hevc_plan
+ * returned): a pool that does not fit as planned still runs wide when its main workgroups take at most half of the `wide_wg`
+ * workgroups — *nhelp is cut to the rest.  Returns 1 if the launch runs wide workgroups. */
+int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shape, int wide_wg, const int *nmains, int *nhelp);
 /* That choice as a pure function (no device needed), applied to the shape imcvt_hevc_plan returned (mode = its return value; *nmains,
  * *nhelp = its outputs): returns 1 if the launch runs 256-thread workgroups with the pipe wave — it does when it fits 15/16 of three
  * workgroups per compute unit (max_workgroups * 3 / 4), and a pool that misses that by little gives up helpers for it (*nhelp is

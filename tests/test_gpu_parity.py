@@ -295,8 +295,8 @@ def test_pipe_wave_full_hd_frame_and_launches_too_large_for_it(amd):
 
 def test_wide_workgroups_full_hd_frame_and_launches_too_large_for_them(amd):
     """One 1080p frame runs wide workgroups by default (one main + two helper workgroups of 512 threads, a compute unit each) and has
-    the reference's digest; so has the same frame with them switched off; 64 frames (64 + 128 workgroups) still run wide, a launch
-    that needs more workgroups than there are compute units does not — same bytes either way."""
+    the reference's digest; so has the same frame with them switched off; 64 frames (64 + 128 workgroups) run wide, 128 frames too (the
+    main workgroups take half of the compute units, the helpers are cut to the other half), 200 frames do not — same bytes either way."""
     import torch
     from oracle import synth
     e = next(e for e in LARGE if (e["input"]["arg"], e["qpd6"]) == (3, 0))
@@ -308,15 +308,19 @@ def test_wide_workgroups_full_hd_frame_and_launches_too_large_for_them(amd):
         (s, r), = enc.results(batch)
         assert enc.last_pipe() and enc.last_wide() == (wide != 0) and enc.last_team()[0] == 3
         assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
-    imgs = [torch.from_numpy(synth.syn(160, 96, i)).cuda() for i in range(128)]
+    imgs = [torch.from_numpy(synth.syn(160, 96, i)).cuda() for i in range(200)]
     enc.set_wide(-1)
     b64 = enc.make_batch(imgs[:64], 0)
     enc.encode(b64); a = enc.results(b64)
     assert enc.last_wide() and enc.last_shape() == (64, 128)
-    b128 = enc.make_batch(imgs, 0)
+    b128 = enc.make_batch(imgs[:128], 0)
     enc.encode(b128); b = enc.results(b128)
+    cus = enc.residency()["cus"]
+    assert enc.last_wide() and enc.last_shape() == (128, cus - 128)
+    b200 = enc.make_batch(imgs, 0)
+    enc.encode(b200); c200 = enc.results(b200)
     assert not enc.last_wide()
-    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, b))
+    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, b)) and all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(b, c200))
     enc.close()
 
 

@@ -160,6 +160,14 @@ def test_launch_shape_policy(built):
     assert lib.imcvt_hevc_plan_wide(1, 3, 256, 0) == 1 and lib.imcvt_hevc_plan_wide(1, 192, 256, 0) == 1 and lib.imcvt_hevc_plan_wide(1, 240, 256, 0) == 1
     assert lib.imcvt_hevc_plan_wide(1, 241, 256, 0) == 0 and lib.imcvt_hevc_plan_wide(1, 256, 256, 1) == 1 and lib.imcvt_hevc_plan_wide(1, 257, 256, 1) == 0
     assert lib.imcvt_hevc_plan_wide(0, 3, 256, 0) == 0 and lib.imcvt_hevc_plan_wide(1, 3, 0, 0) == 0
+    def wide_pool(mm, hh, mode=2, forced=0, wg=256):
+        m, h = C.c_int(mm), C.c_int(hh)
+        return lib.imcvt_hevc_plan_wide_pool(1, mode, forced, wg, C.byref(m), C.byref(h)), h.value
+    assert wide_pool(64, 128) == (1, 128)            # fits as planned
+    assert wide_pool(128, 256) == (1, 128)           # the main workgroups take half of the compute units: the helpers get the other half
+    assert wide_pool(100, 200) == (1, 156)
+    assert wide_pool(129, 258) == (0, 258)           # more main workgroups than that: 256-thread workgroups as planned
+    assert wide_pool(128, 256, forced=1) == (0, 256) # a forced shape is never changed
 
 
 def test_submission_queue_merges_concurrent_callers(built):
