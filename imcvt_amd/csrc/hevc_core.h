@@ -2648,6 +2648,44 @@ HD void stream_seg_R_lds(int &range, SplitQ &q, int lane, int &blk, const u16 *p
         cur = nxt;
     }
 }
+// The whole coder step on resolved tokens in LDS for streams whose bytes are never read (PU pricing): range and low as code_token_r, every lead
+// appended to ONE list per lane (turned into a byte count once, at the end: leads_count) — no byte ring, no per-block drain, no records, no partner.
+HD void stream_seg_lean(int &range, Arith &a, u16 *leads, int &qn, const u16 *p, int n) {
+    const int last_blk = imax((n - 1) >> 3, 0);
+    const u32a *pw = (const u32a *)p;
+    U4 cur; cur.x = pw[0]; cur.y = pw[1]; cur.z = pw[2]; cur.w = pw[3];
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        const u32a *pn = pw + 4 * imin((k0 >> 3) + 1, last_blk);
+        U4 nxt; nxt.x = pn[0]; nxt.y = pn[1]; nxt.z = pn[2]; nxt.w = pn[3];
+        if (k0 < n) {
+            u32 lw[8];
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) {
+                const u32 tok = tok_of(cur, j);
+                const int byp = tok >= 0x8000u;
+                const int lps = (int)((lw[j] >> ((range >> 3) & 24)) & 0xFF);
+                const int rm = range - lps;
+                const int is_lps = (int)(tok ^ (tok >> 1)) & 1;
+                const int r2 = is_lps ? lps : rm;
+                const int sh = clz_nz((u32)r2) - 23;
+                const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+                const int v = byp ? mul24(range, (int)(tok & 255u)) : ((is_lps ? rm : 0) << sh);
+                range = byp ? range : (r2 << sh);
+                a.low = (a.low << nb_) + v;
+                a.nbits -= nb_;
+                const int need = a.nbits < 12;
+                leads[qn < LEADS_CAP ? qn : LEADS_CAP] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
+                qn += need;
+                a.nbits += need ? 8 : 0;
+                a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
+            }
+        }
+        cur = nxt;
+    }
+}
 // the plain coder over tokens in LDS, bytes counted only (the safe path of a PU candidate whose lead list overflowed)
 HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
     CountSinkT cs; cs.dummy = 0;

@@ -58,6 +58,9 @@ struct P1Item { int own, shape, lo, hi; };
 #ifndef NXN_UNI
 #define NXN_UNI 1         // launches without a pipe wave: the NxN trial of an 8x8 CU runs on wave-uniform values, i.e. on the scalar unit (hevc_core.h stream_run_uni)
 #endif
+#ifndef PU_PRICE_LEAN
+#define PU_PRICE_LEAN 0    // 1: the PU wave of a wide workgroup prices its candidates itself, bytes counted from one lead list per lane (measured: no faster than the split below — a token step is ~235 cycles whole against ~190 + ~170 split, profiles/r05aa_*); 0: range half here, byte half on a partner wavefront
+#endif
 #ifndef PU_HINTS
 #define PU_HINTS 1        // launches with a pipe wave: the PU candidates of an 8x8 CU carry state hints and are priced without context copies
 #endif
@@ -155,6 +158,10 @@ HD void pu_recon_price(int y0, int x0, int k) {
     P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
     P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
     pu_recon(2, P, seq);
+#if PU_PRICE_LEAN
+    (void)X; (void)q; (void)W; (void)U; (void)rw;
+    return;                                             // (the PU wave prices the candidates itself)
+#endif
     while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
     split_await(&q.mid, q);                             // the first parts' token counts are in place
     LANES(l) {
@@ -461,13 +468,35 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         MARK("a4_partA");
         prof_add(PF_T_GEN, t4); t4 = prof_now();
         int range = 510, blk = 0;
+#if PU_PRICE_LEAN
+        Arith a; arith_reset(a);
+        int qn = 0;
+        u16 *const leads = XM(2).leads[live ? c : 0];
+        stream_seg_lean(range, a, leads, qn, row + 8, na);
+#else
         stream_seg_R_lds(range, q, l, blk, row + 8, na);
+#endif
         prof_add(PF_T_DRAIN, t4); t4 = prof_now();
         while ((u32)lds_ld_i32((const i32 *)&U.b_seq) != seq) pipe_pause();      // (every lane waits here, outside lane-divergent code)
         wave_sync_lds();
         prof_add(PF_T_NDRAIN, t4); t4 = prof_now();
         const int nb = live ? U.bcnt[c] : 0;
+#if PU_PRICE_LEAN
+        stream_seg_lean(range, a, leads, qn, U.brow[live ? c : 0], nb);
+        const int lov = qn > LEADS_CAP;
+        leads_count(a, leads, lov ? 0 : qn);            // the byte-level logic once over the list (:863-878, :820-831: it decides how many bytes the stream has)
+        if (WAVE_ANY(lov)) {                            // more leads than the list holds: that lane again, by the plain coder on a scratch copy of the fresh contexts
+            u8 *cx = XM(2).cx[live ? c : 0];
+            if (lov) { arith_reset(a); ctx_copy(cx, SM.cx0); }
+            stream_seg_safe_lds(a, cx, row + 8, lov ? na : 0);
+            stream_seg_safe_lds(a, cx, U.brow[live ? c : 0], lov ? nb : 0);
+        }
+        while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // SSE (and reconstructions) are in this wave's slice — long since
+        wave_sync_lds();
+        if (live) { const RdW rw = rd_weights(P.q); W.cost[c] = rd_cost(rw, W.sse[c], arith_len(a)); }
+#else
         stream_seg_R_lds(range, q, l, blk, U.brow[live ? c : 0], nb);
+#endif
         prof_add(PF_T_NTOK, t4);
         if (live) { W.tokn[c] = 8 + na + nb; W.tnz[c] = (u8)(nzm != 0); }
         if (TU0_SHARE && k == 0 && live) {              // PU 0: the four-TU wave takes TU 0 from these streams (tu0_from_pu0) — to memory, the remaining-level part behind the first, idle tokens up to the block boundary (the rows stay as they are)
@@ -487,7 +516,9 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); }
     }
     prof_add(PF_X1, t5); t5 = prof_now();
+#if !PU_PRICE_LEAN
     split_await(&q.done, q);                            // the costs
+#endif
     prof_add(PF_X2, t5);
 }
 HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
