@@ -454,6 +454,7 @@ struct alignas(16) Shm {
     i32 pu0_ready, pu0_taken;    // 8x8 CU: the PU wave's pass over PU 0 is complete / the four-TU wave has taken its copy (hevc_frame.h tu0_from_pu0)
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
+    unsigned long long tl_t0;    // (-DIMCVT_PROF_TL: when the 8x8 CU being walked was entered)
 #endif
     FourTU X;
     alignas(4) u8 cx0[CTX_STRIDE];       // fresh context states of this frame's qpd6 (:1505)
@@ -498,15 +499,10 @@ struct alignas(16) SplitQ {
     i32 range_out[NMODE];                        // the range each lane's coder ended with
     i32 go, mid, rdone, done;                    // generation started by the owner / whose last segment may start (pipe wave) / whose ranges are final / finished by the partner
 };
-#ifndef LEADS_CAP
-#define LEADS_CAP 32                             // byte leads a PU candidate's stream may queue before its lane takes the safe path (~60 tokens: 8 - 10 leads)
-#endif
-#define LEADS_STRIDE ((LEADS_CAP + 2) | 2)             // u16 per lane: 17 dwords (odd: the lanes' lists start in different banks); slot LEADS_CAP is the dump slot
 struct alignas(16) PartnerMem {
     SplitQ q;
     alignas(16) LaneMem lm[NMODE];               // byte rings + lead queues of the byte half
     alignas(4) u8 cx[NMODE][CTX_STRIDE];         // context scratch of its safe path (ring overflow)
-    alignas(4) u16 leads[NMODE][LEADS_STRIDE];   // PU pricing: every lead of a candidate's stream, turned into bytes once at the end (stream_seg_L1 / leads_count)
 };
 // Control words of a wide workgroup's 8x8 CUs, and the LDS slices of the two partner wavefronts that LEND themselves for pipeline passes
 // (hevc_frame.h lend_passes: the one-TU candidate set's three passes of an 8x8 CU run on three wavefronts at once).
@@ -515,6 +511,7 @@ struct alignas(16) WideCtl {
     i32 cu8;                                     // 8x8 CUs entered so far (enter_cu): the sequence numbers of their four PU steps follow from it
     i32 a_go, lend_done[NLEND];                  // one-TU set: generation whose headers are in place / finished by each lender
     i32 b_seg, b_cons;                           // four-TU set: token segments (header + TU 0, TU 1, TU 2, TU 3) complete so far / coded so far, counted over the frame
+    i32 b_hand;                                  // ... and 8x8 CUs whose last segment's range half wave 4 has handed to wave 1 (= cu8 once the current CU's is)
     i32 seg_end[4][NMODE];                       // ... and where each candidate's segment ends in its stream (a segment starts on a token-block boundary)
 };
 // A PU step of an 8x8 CU in a wide workgroup (hevc_frame.h pu_step_wide): the PU wave predicts, transforms and quantises the 35 candidates,
@@ -555,20 +552,33 @@ HD u8 *wave_mem_ptr(int w) {                     // a wavefront's WaveMem: waves
 HD int cg_pos(int st, int s, int g) { return st == 0 ? SM.T.cgpos_d[s][g] : (s == 0 ? 0 : SM.T.cgpos_hv[st - 1][g]); }
 HD int cg_rank(int st, int s, int bit) { return st == 0 ? SM.T.cgrank_d[s][bit] : (s == 0 ? 0 : SM.T.cgrank_hv[st - 1][bit]); }
 
-// Optional cycle accounting per wave (build with -DIMCVT_PROF): category -> accumulated shader clocks
-#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+// Optional cycle accounting per wave (build with -DIMCVT_PROF): category -> accumulated shader clocks.
+// -DIMCVT_PROF -DIMCVT_PROF_TL instead records a TIMELINE of the 8x8 CUs of a wide workgroup: tl_mark(ev) adds the time since the CU was entered
+// (decide_cu) to slot ev of the same array (slot 0 counts the CUs), from whichever wavefront reaches the event; tools/prof_timeline.py names the slots.
+#if defined(IMCVT_PROF) && defined(IMCVT_PROF_TL) && !defined(IMCVT_HOSTEMU)
+HD long long prof_now() { return 0; }
+HD int threadIdx_wave() { return (int)(threadIdx.x >> 6); }
+HD void prof_add(int, long long) {}
+HD void prof_add_row(int, int, long long) {}
+HD void prof_cnt(int, int) {}
+HD void tl_start() { if (threadIdx.x == 0) { SM.tl_t0 = (unsigned long long)clock64(); ((unsigned long long *)SM.prof)[0] += 1; } }
+HD void tl_mark(int ev) { if ((threadIdx.x & 63u) == 0) ((unsigned long long *)SM.prof)[ev] += (unsigned long long)clock64() - SM.tl_t0; }
+#elif defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
 HD long long prof_now() { return clock64(); }
 HD int threadIdx_wave() { return (int)(threadIdx.x >> 6); }
 HD void prof_add(int cat, long long t0) { if ((threadIdx.x & 63u) == 0 && threadIdx.x < WG_THREADS) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)(clock64() - t0); }
+HD void prof_add_row(int row, int cat, long long t0) { if ((threadIdx.x & 63u) == 0) SM.prof[row][cat] += (unsigned long long)(clock64() - t0); }      // a partner wavefront's time, booked in a column its owner's row does not use
+HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0 && threadIdx.x < WG_THREADS) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)n; }
+HD void tl_start() {}
+HD void tl_mark(int) {}
 #else
 HD long long prof_now() { return 0; }
 HD int threadIdx_wave() { return 0; }
 HD void prof_add(int, long long) {}
-#endif
-#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
-HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0 && threadIdx.x < WG_THREADS) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)n; }
-#else
+HD void prof_add_row(int, int, long long) {}
 HD void prof_cnt(int, int) {}
+HD void tl_start() {}
+HD void tl_mark(int) {}
 #endif
 // Wave collectives for the decisions: the reference's "last minimum wins" scan (`best >= cost` accepts, :1439, :1475, :1520)
 // over a wave's lanes = the minimum over the valid lanes, then the highest valid lane that holds it.
@@ -1783,7 +1793,13 @@ HD int pu_stage1(const WaveMem &W, const P1Args &P, int c, int x[4][4]) {
     const QConst Q = qconst<0>(P.q);
     BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
     int pr[4][4], t[4][4];
+#if defined(IMCVT_PROF_TL)
+    const int tl1 = ((PUX.pu_seq - 1u) & 3u) == 0u;      // (timeline builds: PU 1 is being walked)
+#else
+    const int tl1 = 0;
+#endif
     pred_block4(T, br, 4, 2, c, 0, 0, pr);
+    if (tl1) tl_mark(62);                                // 62: PU 1: predicted
     for (int yi = 0; yi < 4; yi++) {
         const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
         for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
@@ -1802,7 +1818,9 @@ HD int pu_stage1(const WaveMem &W, const P1Args &P, int c, int x[4][4]) {
         x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
         x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
     }
+    if (tl1) tl_mark(63);                                // 63: PU 1: transformed
     const int any = rdoq_group<0>(x, Q);
+    if (tl1) tl_mark(64);                                // 64: PU 1: quantised
     u32 *pv = PUX.lev[c];
     for (int r = 0; r < 4; r++) {
         pv[2 * r] = any ? ((u32)(x[r][0] & 0xFFFF) | (u32)x[r][1] << 16) : 0u;
@@ -1824,6 +1842,7 @@ HD void pu_part_b(u32 seq) {
     PuX &U = PUX;
     while ((u32)lds_ld_i32((const i32 *)&U.pu_seq) != seq) pipe_pause();
     wave_sync_lds();
+    const long long tb = prof_now();                    // (IMCVT_PROF builds: booked in wave 2's row, column `idle`)
     LANES(l) {
         const int c = l;
         if (c < NMODE) {
@@ -1843,6 +1862,8 @@ HD void pu_part_b(u32 seq) {
         }
     }
     wave_sync_lds();
+    prof_add_row(2, PF_CTUIO, tb);
+    tl_mark(28 + (int)((seq - 1u) & 3u));               // 28 .. 31: PU k's remaining-level rows made
     LANES(l) { if (l == 0) lds_st_i32((i32 *)&U.b_seq, (i32)seq); }
 }
 // partner (wave 6, wave 7 for the last PU): dequantisation, inverse DST, reconstruction and SSE of every candidate (p1_run_4's tail) into the PU wave's arrays
@@ -1892,6 +1913,7 @@ HD void pu_recon(int own, const P1Args &P, u32 seq) {
         }
     }
     wave_sync_lds();
+    tl_mark(32 + (int)((seq - 1u) & 3u));               // 32 .. 35: PU k's reconstructions and SSE made
     LANES(l) { if (l == 0) lds_st_i32((i32 *)&U.r_seq, (i32)seq); }
 }
 
@@ -2539,17 +2561,19 @@ HD u32 token_R_res(int &range, u32 tok, u32 lw) {                // resolved tok
 // The pricing of the PU candidates (stream_seg_R_lds -> stream_seg_L1) uses a leaner record: v | nb << 17 with v = add << nb for a context
 // bin, range * value for a bypass chunk — low = (low << nb) + v either way, one instruction on the byte side.
 HD u32 token_R_res2(int &range, u32 tok, u32 lw) {
-    const int byp = tok >= 0x8000u;
-    const int lps = (int)((lw >> ((range >> 3) & 24)) & 0xFF);
+    // Branch-free, by masks: a select with the product in one arm is compiled into exec-mask control flow — four or five scalar
+    // instructions per token, each a pipeline turn-around on a serial chain (profiles/r05_valu_sgpr.log).  A bypass chunk goes through the
+    // same arithmetic with an LPS range of zero: range - 0, shift clz(range) - 23 = 0, nothing added — the range stays.
+    const int bm = (int)(tok << 16) >> 31;                                      // all ones: bypass chunk
+    const int lps = (int)(((lw & ~(u32)bm) >> ((range >> 3) & 24)) & 0xFF);
     const int rm = range - lps;
-    const int is_lps = (int)(tok ^ (tok >> 1)) & 1;
-    const int r2 = is_lps ? lps : rm;
+    const int lm = -(int)((tok ^ (tok >> 1)) & 1u) & ~bm;                        // all ones: context bin that takes the LPS path
+    const int r2 = (lps & lm) | (rm & ~lm);
     const int sh = clz_nz((u32)r2) - 23;
-    const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
-    const int v = byp ? mul24(range, (int)(tok & 255u)) : ((is_lps ? rm : 0) << sh);      // (rm << sh < 2^15, range * value < 2^17)
-    const u32 rec = (u32)v | (u32)nb_ << 17;
-    range = byp ? range : (r2 << sh);
-    return rec;
+    const int nb_ = sh + ((int)(tok >> 8) & 15 & bm);
+    const int v = mul24(range, (int)(tok & 255u) & bm) + ((rm & lm) << sh);      // (rm << sh < 2^15, range * value < 2^17)
+    range = r2 << sh;
+    return (u32)v | (u32)nb_ << 17;
 }
 HD void token_L(Arith &a, u16 *lq, int &qn, u32 rec) {
     const int add = (int)(rec & 511u), rg = (int)((rec >> 9) & 511u), nb_ = (int)((rec >> 18) & 15u), val = (int)(rec >> 22);
@@ -2648,44 +2672,6 @@ HD void stream_seg_R_lds(int &range, SplitQ &q, int lane, int &blk, const u16 *p
         cur = nxt;
     }
 }
-// The whole coder step on resolved tokens in LDS for streams whose bytes are never read (PU pricing): range and low as code_token_r, every lead
-// appended to ONE list per lane (turned into a byte count once, at the end: leads_count) — no byte ring, no per-block drain, no records, no partner.
-HD void stream_seg_lean(int &range, Arith &a, u16 *leads, int &qn, const u16 *p, int n) {
-    const int last_blk = imax((n - 1) >> 3, 0);
-    const u32a *pw = (const u32a *)p;
-    U4 cur; cur.x = pw[0]; cur.y = pw[1]; cur.z = pw[2]; cur.w = pw[3];
-    NOUNROLL
-    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
-        const u32a *pn = pw + 4 * imin((k0 >> 3) + 1, last_blk);
-        U4 nxt; nxt.x = pn[0]; nxt.y = pn[1]; nxt.z = pn[2]; nxt.w = pn[3];
-        if (k0 < n) {
-            u32 lw[8];
-            UNROLL_FULL
-            for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
-            UNROLL_FULL
-            for (int j = 0; j < 8; j++) {
-                const u32 tok = tok_of(cur, j);
-                const int byp = tok >= 0x8000u;
-                const int lps = (int)((lw[j] >> ((range >> 3) & 24)) & 0xFF);
-                const int rm = range - lps;
-                const int is_lps = (int)(tok ^ (tok >> 1)) & 1;
-                const int r2 = is_lps ? lps : rm;
-                const int sh = clz_nz((u32)r2) - 23;
-                const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
-                const int v = byp ? mul24(range, (int)(tok & 255u)) : ((is_lps ? rm : 0) << sh);
-                range = byp ? range : (r2 << sh);
-                a.low = (a.low << nb_) + v;
-                a.nbits -= nb_;
-                const int need = a.nbits < 12;
-                leads[qn < LEADS_CAP ? qn : LEADS_CAP] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
-                qn += need;
-                a.nbits += need ? 8 : 0;
-                a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
-            }
-        }
-        cur = nxt;
-    }
-}
 // the plain coder over tokens in LDS, bytes counted only (the safe path of a PU candidate whose lead list overflowed)
 HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
     CountSinkT cs; cs.dummy = 0;
@@ -2693,12 +2679,32 @@ HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
     for (int k = 0; WAVE_ANY(k < n); k++)
         if (k < n) code_token(a, cx, cs, (u32)p[k]);
 }
-// Byte half when only the LENGTH of the stream is wanted and the stream is short (the pricing of a PU's candidates, :1504-1518: the
-// bytes are never read, ~60 tokens leave 8 - 10 bytes): low and the bit position per token as in token_L, every lead appended to
-// ONE list per lane; the byte-level logic (:863-878, :820-831 — it decides how many bytes the stream has, emulation prevention
-// included) then runs once over the list (leads_count) instead of once per token block.  `qn` counts the leads (beyond LEADS_CAP they
-// land in the dump slot: the caller prices that lane on the safe path).
-HD void stream_seg_L1(Arith &a, u16 *leads, int &qn, SplitQ &q, int lane, int &blk, int n) {
+// Byte half when only the LENGTH of the stream is wanted (the pricing of a PU's candidates, :1504-1518: the bytes are never read).  low and
+// the bit position go token by token as in token_L; of the byte-level logic (:863-878, :820-831) only this matters for the length: every
+// lead becomes exactly one byte sooner or later (buffered, part of a run of 0xFF, or emitted), so bytes emitted + bytes buffered = leads
+// taken — unless an emulation-prevention byte was inserted, which takes two emitted zero bytes in a row and then a byte of 3 or less.  An
+// emitted byte is its lead's low byte plus a carry: zero only if the low byte is 0x00 or 0xFF, at most 3 only if it is 0xFF or 0x00..0x03.
+// `zt` keeps those two bits per lead (zero-capable in the low half-word, small-capable in the high one; last lead in bit 0 of each); a lane
+// that ever shows two zero-capable leads and then a small-capable one is priced again by the plain coder (the caller's safe path) — a
+// handful of lanes per frame.
+#ifndef EP_GUARD_MASK
+#define EP_GUARD_MASK 0xFEu                      // (lead + 1) & mask == 0  <=>  low byte 0xFF or 0x00 (tests widen both nets with a smaller mask: many lanes on the safe path)
+#endif
+#define EP_GUARD_MASK3 ((EP_GUARD_MASK << 2 | 3u) & 0xF8u & (EP_GUARD_MASK | 7u))      // ... low byte 0xFF or 0x00..0x06 (a superset of "at most 3 with a carry")
+HD void len_step(Arith &a, int &qn, u32 &zt, int nb_, int v) {
+    a.low = (a.low << nb_) + v;
+    a.nbits -= nb_;
+    const int need = a.nbits < 12;                                                // :858-862
+    const u32 u = ((u32)a.low >> ((24 - a.nbits) & 31)) + 1u;                     // the lead, plus one
+    const u32 zb = ((u & EP_GUARD_MASK) == 0u ? 1u : 0u) | ((u & EP_GUARD_MASK3) == 0u ? 0x10000u : 0u);
+    zt = need ? ((zt << 1) & 0xFFFEFFFEu) | zb : zt;                              // (15 leads of history per half-word: checked every token block, eight leads at most apart)
+    qn += need;
+    a.nbits += need ? 8 : 0;
+    a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
+}
+HD int ep_guard(u32 zt) { return ((zt >> 16) & (zt >> 1) & (zt >> 2) & 0x3FFFu) != 0u; }       // a small-capable lead right after two zero-capable ones
+HD int arith_len_leads(const Arith &a, int qn) { return 8 * qn + 23 - a.nbits; }      // arith_len with bytes emitted + buffered = qn
+HD void stream_seg_L1(Arith &a, int &qn, u32 &zz, int &slow, SplitQ &q, int lane, int &blk, int n) {
     const int ql = lane < NMODE ? lane : 0;
     const u32 *const row = q.rec[ql];
     int prod_seen = 0;
@@ -2719,40 +2725,27 @@ HD void stream_seg_L1(Arith &a, u16 *leads, int &qn, SplitQ &q, int lane, int &b
             blk++;
             lds_st_i32(&q.cons[ql], blk);
             UNROLL_FULL
-            for (int j = 0; j < 8; j++) {
-                const u32 r = rec[j];
-                const int v = (int)(r & 0x1FFFFu), nb_ = (int)(r >> 17);      // (token_R_res2's records)
-                a.low = (a.low << nb_) + v;
-                a.nbits -= nb_;
-                const int need = a.nbits < 12;
-                leads[qn < LEADS_CAP ? qn : LEADS_CAP] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));      // always written; only kept when `need`
-                qn += need;
-                a.nbits += need ? 8 : 0;
-                a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
-            }
+            for (int j = 0; j < 8; j++) len_step(a, qn, zz, (int)(rec[j] >> 17), (int)(rec[j] & 0x1FFFFu));      // (token_R_res2's records)
+            slow |= ep_guard(zz);
         }
     }
 }
-typedef CountSinkT CountSink;
-// the byte-level logic over a lane's whole lead list: a.cnt / nbytes / bufbyte / zeros end as if the bytes had been emitted token by token
-HD void leads_count(Arith &a, const u16 *leads, int qn) {
-    CountSink cs; cs.dummy = 0;
+// The same over tokens that are ALL bypass chunks (the remaining-level rows a partner makes, pu_part_b): a bypass chunk leaves the range as it
+// is (:898-910), so the range half has nothing to do there — the byte half takes the chunks from the row itself, with the range the first
+// part ended on.  (An idle token is a chunk of no bins.)
+HD void stream_seg_L1_byp(Arith &a, int &qn, u32 &zz, int &slow, const u16 *p, int n, int range) {
+    const u32a *pw = (const u32a *)p;
     NOUNROLL
-    for (int i0 = 0; WAVE_ANY(i0 < qn); i0 += 8) {
-        u32 lqw[4];
-        for (int d = 0; d < 4; d++) lqw[d] = *(const u32a *)&leads[i0 + 2 * d];
-        UNROLL_FULL
-        for (int i = 0; i < 8; i++) {
-            if (!WAVE_ANY(i0 + i < qn)) break;
-            const int act = i0 + i < qn;
-            const int lead = (int)((i & 1) ? lqw[i >> 1] >> 16 : lqw[i >> 1] & 0xFFFFu);
-            const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
-            const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
-            a.cnt += fast;
-            a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
-            a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
-            const int rare = act & !fast;
-            if (WAVE_ANY(rare)) { if (rare) carry_rare(a, cs, lead); }
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        if (k0 < n) {
+            const u32a *pb = pw + (k0 >> 1);
+            U4 cur; cur.x = pb[0]; cur.y = pb[1]; cur.z = pb[2]; cur.w = pb[3];
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) {
+                const u32 tok = tok_of(cur, j);
+                len_step(a, qn, zz, (int)((tok >> 8) & 15u), mul24(range, (int)(tok & 255u)));
+            }
+            slow |= ep_guard(zz);
         }
     }
 }

@@ -58,9 +58,6 @@ struct P1Item { int own, shape, lo, hi; };
 #ifndef NXN_UNI
 #define NXN_UNI 1         // launches without a pipe wave: the NxN trial of an 8x8 CU runs on wave-uniform values, i.e. on the scalar unit (hevc_core.h stream_run_uni)
 #endif
-#ifndef PU_PRICE_LEAN
-#define PU_PRICE_LEAN 0    // 1: the PU wave of a wide workgroup prices its candidates itself, bytes counted from one lead list per lane (measured: no faster than the split below — a token step is ~235 cycles whole against ~190 + ~170 split, profiles/r05aa_*); 0: range half here, byte half on a partner wavefront
-#endif
 #ifndef PU_HINTS
 #define PU_HINTS 1        // launches with a pipe wave: the PU candidates of an 8x8 CU carry state hints and are priced without context copies
 #endif
@@ -146,55 +143,73 @@ HDN void partner_trial(int own_, int depth_) {
 }
 // sequence number of PU k of the 8x8 CU being walked (wide workgroups)
 HD u32 pu_seq_of(int k) { return 4u * (u32)(lds_ld_i32(&WCTL.cu8) - 1) + (u32)k + 1u; }
-// A partner's share of PU k (wide workgroups, pu_step_wide): reconstructions and SSE of the 35 candidates, then the byte half of their pricing
-// (fresh coder, :1504-1518) over the range half's records — first part of the tokens, then the remaining levels — and the costs.
-HD void pu_recon_price(int y0, int x0, int k) {
+// The partners' shares of PU k (wide workgroups, pu_step_wide).  pu_recon_k: reconstructions and SSE of the 35 candidates.  pu_price: the byte
+// half of their pricing (fresh coder, :1504-1518) — over the range half's records for the first part of the tokens, over the remaining-level rows
+// themselves (bypass chunks: no range half needed) for the rest — and the costs.
+HD void pu_recon_k(int y0, int x0, int k) {
+    P1Args P;
+    P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
+    P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
+    const long long tq = prof_now();                    // (IMCVT_PROF builds: the partners' times go to columns wave 2's row leaves empty — p2_32 reconstructions, p2_16 waiting for the first counts, p2_8 byte half over the first part, p2_nxn waiting for rows and final range, p1_16 byte half over the rows, x3 costs; idle: the remaining-level rows)
+    pu_recon(2, P, pu_seq_of(k));
+    prof_add_row(2, PF_P2_32, tq);
+}
+HD void pu_price(int k) {
     PartnerMem &X = XM(2); SplitQ &q = X.q;
     WaveMem &W = WM(2);
     PuX &U = PUX;
     const RdW rw = rd_weights(F.job.q);
     const u32 seq = pu_seq_of(k);
-    P1Args P;
-    P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
-    P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
-    pu_recon(2, P, seq);
-#if PU_PRICE_LEAN
-    (void)X; (void)q; (void)W; (void)U; (void)rw;
-    return;                                             // (the PU wave prices the candidates itself)
-#endif
+    long long tq = prof_now();
+    while ((u32)lds_ld_i32((const i32 *)&U.pu_seq) != seq) pipe_pause();      // (the step's generation has started: q.go is this step's)
     while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
     split_await(&q.mid, q);                             // the first parts' token counts are in place
+    prof_add_row(2, PF_P2_16, tq); tq = prof_now();
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a; arith_reset(a);
         const int na = on ? U.na[ll] : 0;
-        int blk = 0, qn = 0;
-        stream_seg_L1(a, X.leads[ll], qn, q, l, blk, na);
+        int blk = 0, qn = 0, slow = 0; u32 zz = 0;
+        stream_seg_L1(a, qn, zz, slow, q, l, blk, na);
+        tl_mark(44 + k);                                 // 44 .. 47: byte half through the first part of PU k
+        prof_add_row(2, PF_P2_8, tq); tq = prof_now();
         while ((u32)lds_ld_i32((const i32 *)&U.b_seq) != seq) pipe_pause();
         wave_sync_lds();
         const int nb = on ? U.bcnt[ll] : 0;
-        stream_seg_L1(a, X.leads[ll], qn, q, l, blk, nb);
-        const int ovf = qn > LEADS_CAP;
-        leads_count(a, X.leads[ll], ovf ? 0 : qn);                      // the byte-level logic once, at the end (the bytes themselves are never read, :1518)
-        if (WAVE_ANY(ovf)) {                                            // a stream with more leads than the list holds: that lane again, by the plain coder on a scratch copy of the fresh contexts
-            if (ovf) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
-            stream_seg_safe_lds(a, X.cx[ll], lane_row(W, ll) + 8, ovf ? na : 0);
-            stream_seg_safe_lds(a, X.cx[ll], U.brow[ll], ovf ? nb : 0);
+        split_await(&q.rdone, q);                                       // the range half is through the first part: the range it ended on (the rest is bypass chunks, which this half takes from the rows itself)
+        prof_add_row(2, PF_P2_NXN, tq); tq = prof_now();
+        stream_seg_L1_byp(a, qn, zz, slow, U.brow[ll], nb, on ? q.range_out[ll] : 510);
+        tl_mark(48 + k);                                 // 48 .. 51: ... and through its rows
+        prof_add_row(2, PF_P1_16, tq); tq = prof_now();
+        int len = arith_len_leads(a, qn);                               // (the bytes themselves are never read, :1518)
+        if (WAVE_ANY(slow)) {                                           // two leads in a row that may have become zero bytes — an emulation-prevention byte may follow: that lane again, by the plain coder on a scratch copy of the fresh contexts
+            if (slow) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
+            stream_seg_safe_lds(a, X.cx[ll], lane_row(W, ll) + 8, slow ? na : 0);
+            stream_seg_safe_lds(a, X.cx[ll], U.brow[ll], slow ? nb : 0);
+            if (slow) len = arith_len(a);
         }
-        if (on) W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a));
+        if (k == 1) tl_mark(58);                         // 58: PU 1: guard checked
+        while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // SSE and reconstructions of this PU's candidates are in place (long since)
+        wave_sync_lds();
+        if (k == 1) tl_mark(59);                         // 59: PU 1: reconstructions seen
+        if (on) W.cost[l] = rd_cost(rw, W.sse[l], len);
+        if (k == 1) tl_mark(60);                         // 60: PU 1: costs stored
+        prof_add_row(2, PF_X3, tq);
     }
     split_flag(&q.done, q);
 }
-// wave 7, partner of the PU chain: the remaining-level tokens of every PU's candidates; for the last PU (the pipe wave's partner is busy by then) reconstructions and pricing too
+// Who does what for PU k of an 8x8 CU (wide workgroups), next to the PU wave (pu_step_wide):
+//   k = 0..2   wave 7: remaining-level rows      pipe wave (3): reconstructions + SSE, then the pricing's byte half (it has nothing of its own to do until PU 2 is decided)
+//   k = 3      wave 7: remaining-level rows, then the pricing's byte half      the PU wave itself: reconstructions + SSE, once its range half is through
+//              (nobody else is free by then: the pipe wave and wave 6 are coding PUs 0..2, waves 0 / 5 and 1 / 4 are still in the 2Nx2N sets' trial coders —
+//              with the rows on wave 5 or 4 the PU wave waited 11 k cycles per step for them, profiles/r05ae, r05af)
 HDN void partner_pu(int y0_, int x0_) {
-    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_);
+    (void)y0_; (void)x0_;
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);      // (part of the PU chain, the longest of an 8x8 CU: as eval_NxN)
 #endif
-    for (int k = 0; k < 4; k++) {
-        pu_part_b(pu_seq_of(k));
-        if (k == 3) pu_recon_price(y0, x0, k);
-    }
+    for (int k = 0; k < 4; k++) pu_part_b(pu_seq_of(k));
+    pu_price(3);
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(2); else SETPRIO(0);
 #endif
@@ -205,7 +220,7 @@ HDN void partner_pu_early(int y0_, int x0_) {
 #ifndef IMCVT_HOSTEMU
     if (F.prio_base) SETPRIO(3); else SETPRIO(NXN_PRIO_SOLO);      // (part of the PU chain)
 #endif
-    for (int k = 0; k < 3; k++) pu_recon_price(y0, x0, k);
+    for (int k = 0; k < 3; k++) { pu_recon_k(y0, x0, k); pu_price(k); }
 }
 // owner of a 2Nx2N candidate set in a wide workgroup: the range half of its 35 trial coders (final coder states and costs are the partner's to
 // write, before the barrier that follows the candidate sets).  Out of line, so that the other launch shapes' eval_2Nx2N is not charged its registers.
@@ -275,12 +290,25 @@ HDN void partner_fourtu(int depth_) {
         if (on) ctx_copy(cx, SM.entry_cx[depth]);
         RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
         int from = 0;
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 3; k++) {
             while (lds_ld_i32(&C.b_seg) - base <= k) pipe_pause();
             wave_sync();
             const int end = C.seg_end[k][ll];
             stream_seg(a, cx, lm, sink, ts + from, on ? end - from : 0);
             from = (end + 7) & ~7;
+        }
+        {   // the last segment: wave 1 is through with its passes by the time it is complete and takes the range half (fourtu_last_range_half); the byte half stays here
+            SplitQ &q = X.q;
+            if (on) q.range_out[l] = a.range;
+            wave_sync_lds();
+            if (l == 0) lds_st_i32(&C.b_hand, lds_ld_i32(&C.cu8));
+            while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
+            wave_sync();
+            const int end = C.seg_end[3][ll];
+            int blk = 0;
+            stream_seg_L(a, lm, sink, q, l, blk, on ? end - from : 0);
+            split_await(&q.rdone, q);
+            if (on) a.range = q.range_out[l];
         }
         if (on) ring_finish(sink, a.cnt);
         const int ovf = on & (sink.ovf != 0);
@@ -296,8 +324,25 @@ HDN void partner_fourtu(int depth_) {
             ctx_copy(W.u.p2.cx[l], cx);                 // (wave 1 finished its last pass before it released the last segment: its pass buffer is free)
         }
     }
-    wave_sync_lds();
+    split_flag(&X.q.done, X.q);
     LANES(l) { if (l == 0) lds_st_i32(&C.b_cons, base + 4); }
+}
+// wave 1, its four passes done: the range half of the four-TU set's last segment, from the range wave 4's coders reached and on their contexts
+HDN void fourtu_last_range_half() {
+    PartnerMem &X = XM(1); SplitQ &q = X.q;
+    WideCtl &C = WCTL;
+    const u16 *tok = wave_tok(F.sc, 1);
+    while (lds_ld_i32(&C.b_hand) != lds_ld_i32(&C.cu8)) pipe_pause();
+    wave_sync();
+    split_start(q);
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        int range = on ? q.range_out[ll] : 510, blk = 0;
+        const int from = (C.seg_end[2][ll] + 7) & ~7, end = C.seg_end[3][ll];
+        stream_seg_R<false>(range, X.cx[ll], q, l, blk, tok + (size_t)ll * TOK_CAP + from, on ? end - from : 0);
+        if (on) q.range_out[l] = range;
+    }
+    split_flag(&q.rdone, q);
 }
 #ifndef SPL32_0
 #define SPL32_0 23
@@ -375,13 +420,14 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
             }
             p1_run(wave, P);
             if (wide8 && shape == 1) seg_close(W, k);
+            if (wide8) tl_mark(shape == 1 ? 36 + k : 40 + ii);       // 36 .. 39: the four-TU set's TU k passed; 40, 41: wave 0's passes
         }
     }
     if (wide8 && wave == 0) {                           // the lenders' candidates are done: their tokens are in memory, counts and SSE in this wavefront's arrays
         while (lds_ld_i32(&WCTL.lend_done[0]) != lds_ld_i32(&WCTL.a_go)) pipe_pause();
         wave_sync();
     }
-    if (wide8 && wave == 1) { prof_add(PF_P1_4, pt); return; }      // (the trial coders of this set have been running on wave 5 all along: partner_fourtu)
+    if (wide8 && wave == 1) { prof_add(PF_P1_4, pt); fourtu_last_range_half(); return; }      // (the trial coders of this set have been running on wave 5 all along: partner_fourtu)
     prof_add(wave == 2 ? PF_P1_4 : wave == 0 ? (N == 32 ? PF_P1_32 : N == 16 ? PF_P1_16 : PF_P1_8) : (N == 32 ? PF_P1_16 : N == 16 ? PF_P1_8 : PF_P1_4), pt);
     if (big) wg_sync_p(); else wave_sync();             // the tokens are in memory
     if (wave >= 2) return;
@@ -392,6 +438,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 #ifndef IMCVT_HOSTEMU
     if (big) { if (F.prio_base) SETPRIO(3); else SETPRIO(1); }   // the third wave of the workgroup waits for these two: they are its critical path (1024 frames in flight: +4 %)
 #endif
+    if (wide8) tl_mark(42);                             // 42: the one-TU set's tokens complete (lenders included)
     if (F.wide) coder_range_half(wave, depth);          // wide workgroup: this wavefront runs the range half of its 35 coders, a partner wavefront the byte half (partner_trial)
     else
     LANES(l) {
@@ -443,6 +490,7 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         if (live) any = pu_stage1(W, P, c, x);
         wave_sync_lds();
         if (l == 0) { lds_st_i32((i32 *)&U.pu_seq, (i32)seq); lds_st_i32(&q.go, lds_ld_i32(&q.go) + 1); }      // levels published (waves 7 and 6 start), queue counters zeroed
+        tl_mark(16 + k);                                 // 16 .. 19: PU k's levels published
         MARK("a4_stage1");
         prof_add(PF_T_HDR, t4); t4 = prof_now();        // (IMCVT_PROF builds: t_hdr = predict + DST + RDOQ, passA = first part of the tokens, passB = range half over it, passC = waiting for the remaining-level rows, n_cg = range half over them)
         const int st = scan_type_of(4, live ? c : 0);
@@ -465,38 +513,19 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         const int na = live ? w.n - 8 : 0;
         wave_sync_lds();
         if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));                     // the counts are in place: the byte half may start
+        tl_mark(24 + k);                                 // 24 .. 27: first part of PU k's tokens made
         MARK("a4_partA");
         prof_add(PF_T_GEN, t4); t4 = prof_now();
         int range = 510, blk = 0;
-#if PU_PRICE_LEAN
-        Arith a; arith_reset(a);
-        int qn = 0;
-        u16 *const leads = XM(2).leads[live ? c : 0];
-        stream_seg_lean(range, a, leads, qn, row + 8, na);
-#else
         stream_seg_R_lds(range, q, l, blk, row + 8, na);
-#endif
+        if (live) q.range_out[l] = range;
+        split_flag(&q.rdone, q);                                                 // (the remaining-level rows are bypass chunks only: the byte half goes on alone)
+        tl_mark(20 + k);                                 // 20 .. 23: range half of PU k through
         prof_add(PF_T_DRAIN, t4); t4 = prof_now();
         while ((u32)lds_ld_i32((const i32 *)&U.b_seq) != seq) pipe_pause();      // (every lane waits here, outside lane-divergent code)
         wave_sync_lds();
         prof_add(PF_T_NDRAIN, t4); t4 = prof_now();
         const int nb = live ? U.bcnt[c] : 0;
-#if PU_PRICE_LEAN
-        stream_seg_lean(range, a, leads, qn, U.brow[live ? c : 0], nb);
-        const int lov = qn > LEADS_CAP;
-        leads_count(a, leads, lov ? 0 : qn);            // the byte-level logic once over the list (:863-878, :820-831: it decides how many bytes the stream has)
-        if (WAVE_ANY(lov)) {                            // more leads than the list holds: that lane again, by the plain coder on a scratch copy of the fresh contexts
-            u8 *cx = XM(2).cx[live ? c : 0];
-            if (lov) { arith_reset(a); ctx_copy(cx, SM.cx0); }
-            stream_seg_safe_lds(a, cx, row + 8, lov ? na : 0);
-            stream_seg_safe_lds(a, cx, U.brow[live ? c : 0], lov ? nb : 0);
-        }
-        while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // SSE (and reconstructions) are in this wave's slice — long since
-        wave_sync_lds();
-        if (live) { const RdW rw = rd_weights(P.q); W.cost[c] = rd_cost(rw, W.sse[c], arith_len(a)); }
-#else
-        stream_seg_R_lds(range, q, l, blk, U.brow[live ? c : 0], nb);
-#endif
         prof_add(PF_T_NTOK, t4);
         if (live) { W.tokn[c] = 8 + na + nb; W.tnz[c] = (u8)(nzm != 0); }
         if (TU0_SHARE && k == 0 && live) {              // PU 0: the four-TU wave takes TU 0 from these streams (tu0_from_pu0) — to memory, the remaining-level part behind the first, idle tokens up to the block boundary (the rows stay as they are)
@@ -516,9 +545,9 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         LANES(l) { if (l == 0) lds_st_i32(&SM.pu0_ready, 1); }
     }
     prof_add(PF_X1, t5); t5 = prof_now();
-#if !PU_PRICE_LEAN
+    if (k == 3) pu_recon(2, P, seq);                    // the last PU: nobody else has the time (who does what: above partner_pu)
     split_await(&q.done, q);                            // the costs
-#endif
+    tl_mark(12 + k);                                    // 12 .. 15: PU k priced
     prof_add(PF_X2, t5);
 }
 HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
@@ -548,7 +577,9 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         LANES(l) { if (l < NMODE) { W.sse[l] = 0; W.tokn[l] = 7; blk_idle((u32a *)W.pend[l]); } }
         wave_sync_lds();
         long long pt = prof_now();
+        if (F.wide && k == 1) tl_mark(56);              // 56: PU 1's step begins
         if (F.wide) border4_from_tile(W, yk, xk, ca.l, ca.bl, ca.a, ca.ar); else border_from_tile(wave, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
+        if (F.wide && k == 1) tl_mark(57);              // 57: its borders made
         prof_add(PF_P1_32, pt); pt = prof_now();            // (NxN chain, IMCVT_PROF builds: p1_32 = borders, p1_16 = store drain before pricing, p1_8 = pick + keep,
         P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
@@ -585,6 +616,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             }
         }
         wave_sync_lds();
+        if (F.wide && k == 1) tl_mark(61);              // 61: PU 1's mode picked
         LANES(l) {                                      // keep its tokens and put its reconstruction in place (:1523-1524)
             const int bm = W.pu_mode[k], cnt = W.pu_cnt[k];
             const u16 *src = tok + (size_t)bm * TOK_CAP + 7;
@@ -607,6 +639,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             wave_sync();                                // the kept tokens are in memory
             LANES(l) { if (l == 0) lds_st_i32(k == 2 ? &SM.pipe_a : &SM.pipe_b, 1); }
         }
+        if (F.wide) tl_mark(52 + k);                     // 52 .. 55: PU k decided and kept
         prof_add(PF_P1_8, pt);
     }
     if (pipe) {
@@ -873,6 +906,8 @@ HDN void rebuild_winner(int kind_, int mode_, int N_, int y0_, int x0_, int avm_
 HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     const int depth = uni_i(depth_); const int N = uni_i(N_); const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     u8 *live_sink = F.job.out + F.out_pos;
+    const int tl = N == 8 && F.wide;                     // (-DIMCVT_PROF_TL builds: timeline of a wide workgroup's 8x8 CUs)
+    if (tl) tl_start();
     WAVES_ALL(w) {
         if (w >= NWAVES && N < 16) {
             if (w == PIPE_WAVE) { if (F.wide) partner_pu_early(y0, x0); nxn_pipe(y0, x0); }      // (wide workgroups: until PU 2 is decided the pipe wave has nothing of its own to do — reconstructions and byte half of the pricing of PUs 0..2, on a SIMD the PU wave does not run on)
@@ -884,8 +919,10 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
         }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else eval_NxN(2, y0, x0, avm);
+        if (tl) tl_mark(1 + w);                          // 1 .. 8: wave w is through with its part of the candidate sets
     }
     wg_sync_p();
+    if (tl) WAVES(w) { if (w == 0) tl_mark(9); }         // 9: every wave is
     WAVES(w) LANES(l) {
         // split cost first, then modes 0..34 with one TU, 0..34 with four TUs, then NxN, each accepted with `best >= cost`: the last
         // minimum wins.  Wave 0 scans: the minimum of the 70, a four-TU candidate that holds it beats every one-TU candidate.
@@ -942,6 +979,7 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
         prof_add(PF_RECON, ptr_);
         wg_sync_p();
     }
+    if (tl) WAVES(w) { if (w == 0) tl_mark(10); }        // 10: winner committed
 }
 
 // snapshot the live coder as the entry state of `depth`, optionally after coding split_cu_flag=1 (:1363-1364, :1403)
@@ -1556,7 +1594,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.cu8 = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide() && PU_HINTS; SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;

@@ -95,9 +95,10 @@ def hostemu_wide_ovf(built):
 
 
 @pytest.fixture(scope="session")
-def hostemu_wide_leads(built):
-    """Wide workgroups with four-entry lead lists: nearly every PU candidate's stream has more leads and is priced on the safe path."""
-    return _hostemu_lib("libhostemu_wide_leads.so", ["-DEMU_DEFAULT_WIDE", "-DLEADS_CAP=4"])
+def hostemu_wide_ep(built):
+    """Wide workgroups with a wide net for the emulation-prevention guard of the PU pricing (low bytes 0xFF and 0x00..0x1E count as possible zero
+    bytes): many PU candidates are priced a second time, on the safe path."""
+    return _hostemu_lib("libhostemu_wide_ep.so", ["-DEMU_DEFAULT_WIDE", "-DEP_GUARD_MASK=0xE0u"])
 
 
 @pytest.fixture(scope="session")

@@ -113,9 +113,9 @@ def test_wide_workgroup_ring_overflow_path_matches_golden(hostemu_wide_ovf, e):
 
 
 @pytest.mark.parametrize("e", OVF, ids=kat_id)
-def test_wide_workgroup_lead_list_overflow_path_matches_golden(hostemu_wide_leads, e):
-    # a PU candidate whose stream queues more leads than its list holds is priced by the plain coder (hevc_frame.h partner_pu)
-    stream, rcon = emu_encode(hostemu_wide_leads, kat_input(e["input"]), e["qpd6"])
+def test_wide_workgroup_ep_guard_safe_path_matches_golden(hostemu_wide_ep, e):
+    # a PU candidate whose stream may hold two zero bytes in a row is priced again by the plain coder (hevc_frame.h pu_price); this build widens the guard
+    stream, rcon = emu_encode(hostemu_wide_ep, kat_input(e["input"]), e["qpd6"])
     assert hashlib.sha256(stream).hexdigest() == e["sha256"]
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
 
@@ -315,3 +315,63 @@ def test_lds_budget(hostemu):
     assert 3 * (hostemu.hostemu_shm_bytes() + hostemu.hostemu_pipe_lds_bytes()) <= 160 * 1024
     # one 512-thread wide workgroup per CU with the partner wavefronts' record queues
     assert hostemu.hostemu_shm_bytes() + hostemu.hostemu_wide_lds_bytes() <= 160 * 1024
+
+
+def test_pu_pricing_length_rule_leads_equal_bytes_unless_guard_fires():
+    """hevc_core.h len_step / ep_guard: the PU pricing never runs the byte-level logic (:820-831, :858-878).  It relies on: every lead taken becomes
+    exactly one byte (emitted, buffered or part of a 0xFF run), so emitted + buffered bytes = leads — unless an emulation-prevention byte was
+    inserted, and that takes two leads in a row whose low byte is 0x00 or 0xFF and then one whose low byte is 0xFF or at most 3 (the guard says 6).  Checked against a model of the byte-level logic on random and on
+    adversarial lead sequences (9-bit leads: a carry on top of a byte)."""
+    import random
+
+    def model(leads):
+        nbytes, buf, zeros, cnt = 0, 0xFF, 0, 0
+
+        def emit(v):
+            nonlocal zeros, cnt
+            v &= 0xFF
+            if zeros >= 2 and v <= 3:
+                cnt += 1; zeros = 0
+            cnt += 1
+            zeros = 0 if v else zeros + 1
+
+        for lead in leads:
+            if lead == 0xFF:
+                nbytes += 1
+            elif nbytes > 0:
+                carry = lead >> 8
+                v = buf + carry
+                buf = lead & 0xFF
+                emit(v)
+                v = (0xFF + carry) & 0xFF
+                while nbytes > 1:
+                    emit(v); nbytes -= 1
+            else:
+                nbytes, buf = 1, lead
+        return cnt + nbytes
+
+    def guard(leads):                   # len_step / ep_guard: a small-capable lead right after two zero-capable ones, checked at least every eight leads
+        zt, hit = 0, False
+        for i, lead in enumerate(leads):
+            u = lead + 1
+            zb = (1 if (u & 0xFE) == 0 else 0) | (0x10000 if (u & 0xF8) == 0 else 0)
+            zt = (((zt << 1) & 0xFFFEFFFE) | zb) & 0xFFFFFFFF
+            if i % 8 == 7 or i == len(leads) - 1:
+                hit |= ((zt >> 16) & (zt >> 1) & (zt >> 2) & 0x3FFF) != 0
+        return hit
+
+    rng = random.Random(5)
+    pools = [list(range(512)), [0x00, 0xFF, 0x100, 0x1FF, 0x01, 0x02, 0x03, 0xFE, 0x101, 0x55], [0x00, 0xFF, 0x100, 0x1FF]]
+    fired = quiet = inserted = 0
+    for it in range(60000):
+        pool = pools[it % 3]
+        leads = [rng.choice(pool) for _ in range(rng.randint(1, 40))]
+        # a carry never arrives on top of a full run it cannot resolve: the coder guarantees lead < 0x200 only; the model accepts all of them
+        n = model(leads)
+        if guard(leads):
+            fired += 1
+            inserted += n != len(leads)
+        else:
+            quiet += 1
+            assert n == len(leads), leads
+    assert fired > 1000 and quiet > 1000 and inserted > 100          # both sides exercised, and insertions do happen behind the guard
