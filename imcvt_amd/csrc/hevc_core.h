@@ -303,8 +303,9 @@ struct alignas(16) WaveMem {
 };
 #define WAVE2_BYTES (sizeof(WaveMem) - 7168 + W2_PAD + NMODE * 16)
 
-#define TRIAL_BYTES 3584          // bytes one trial may emit: the reference's own per-CTU coder buffer is TMPBUF_LEN = 3200 (:794), unchecked there too
-static_assert(TRIAL_BYTES >= 3200 + 256, "a trial's byte buffer must cover the reference's per-CTU coder buffer plus the 16-byte flush granularity");
+#define TRIAL_OUT_BYTES 3584      // bytes one trial may emit: the reference's own per-CTU coder buffer is TMPBUF_LEN = 3200 (:794), unchecked there too
+static_assert(TRIAL_OUT_BYTES >= 3200 + 256, "a trial's byte buffer must cover the reference's per-CTU coder buffer plus the 16-byte flush granularity");
+#define TRIAL_BYTES (2 * TRIAL_OUT_BYTES)      // a trial coder's buffer: it leaves the 9-bit LEAD of every byte (u16, LeadSink), not the byte; its last word holds the number of leads
 // Per-frame job and per-workgroup scratch (global memory)
 struct FrameJob {
     const u8 *img;   // h*w gray8
@@ -357,7 +358,7 @@ struct alignas(16) HelpRes {                     // helper -> main: the best uns
     FinState fin; i32 pad_;                      // coder state the winning trial ended in
     alignas(4) u8 ctx[CTX_STRIDE];               // its contexts
     alignas(16) u8 rec[1024];                    // its reconstruction, N x N row-major
-    alignas(16) u8 bytes[TRIAL_BYTES];           // its bytes
+    alignas(16) u8 bytes[TRIAL_OUT_BYTES];       // its bytes
 };
 struct alignas(256) MailSlot {
     i32 req_flag; i32 pad0_[63];                 // sequence number of the request in `req` (flags on their own lines)
@@ -623,20 +624,50 @@ HD int sink_room(Sink &, int) { return 1; }
 struct CountSinkT { int dummy; };             // bytes are counted (a.cnt), not kept
 HD void sink_put(CountSinkT &, int, int) {}
 HD int sink_room(CountSinkT &, int) { return 1; }
-struct RingSink { u8 *ring; u8 *gbuf; int c0, fl, ovf; };   // byte i lives at local index j = i - c0: ring[j % RING_BYTES] until flushed, then gbuf[j]; fl = bytes flushed (multiple of 16)
-HD void ring_flush16(RingSink &s) {      // the ring is only 4-byte aligned (odd dword stride between lanes)
-    const u32a *r = (const u32a *)(s.ring + (s.fl & (RING_BYTES - 1)));
-    U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
-    g_st128(s.gbuf + s.fl, b); s.fl += 16;
+// LeadSink — the trial coders.  A trial's BYTES are wanted only if it wins; its cost needs their NUMBER.  So a trial coder does not run the
+//   byte-level logic (:863-878, :820-831: carry into the buffered byte, runs of 0xFF, emulation prevention) at all: it leaves the 9-bit lead
+//   (carry + byte) of every byte that leaves `low` (:858-862) in a 16-entry LDS ring per lane, flushed as aligned 16-byte global stores
+//   between token blocks (the hot loop issues no VMEM instruction).  Every lead becomes exactly one byte — buffered, part of a run of
+//   0xFF, or emitted — so bytes emitted + buffered grow by the number of leads, plus one per emulation-prevention byte inserted; and such a
+//   byte takes two emitted zero bytes in a row and then a byte of 3 or less, i.e. (a byte is its lead's low byte plus a carry) two leads
+//   with low byte 0x00 / 0xFF and then one with 0xFF / 0x00..0x03.  The flush looks for that pattern (`hit`; the bytes still buffered on
+//   entry count as leads: lsink_begin); a lane that shows it gets its byte-level state by the real logic over its list (leads_exact) —
+//   a few lanes per frame.  The winner's list is turned into bytes once, by a whole wavefront (resolve_leads).
+#ifndef EP_GUARD_MASK
+#define EP_GUARD_MASK 0xFEu                      // (lead + 1) & mask == 0  <=>  low byte 0xFF or 0x00 (tests widen both nets with a smaller mask: many lanes on the exact path)
+#endif
+#define EP_GUARD_MASK3 ((EP_GUARD_MASK << 2 | 3u) & 0xF8u & (EP_GUARD_MASK | 7u))      // ... low byte 0xFF or 0x00..0x06 (a superset of "at most 3 with a carry")
+#define LRING 16
+struct LeadSink { u16 *ring; u8 *gbuf; int fl; u32 zp; int hit; };     // lead i: ring[i % 16] until flushed (fl leads, a multiple of 8), then ((u16 *)gbuf)[i]; zp: zero-capable bits of the last two leads (bit 0 the last)
+HD u32 lead_zt(u32 lead) { const u32 u = lead + 1u; return ((u & EP_GUARD_MASK) == 0u ? 1u : 0u) | ((u & EP_GUARD_MASK3) == 0u ? 2u : 0u); }      // bit 0: may become a zero byte; bit 1: may become a byte of 3 or less
+HD void lsink_begin(LeadSink &s, const Arith &a0, u16 *ring, u8 *gbuf) {
+    s.ring = ring; s.gbuf = gbuf; s.fl = 0;
+    const u32 zh = a0.zeros >= 2 ? 3u : a0.zeros == 1 ? 1u : 0u;              // emitted zero bytes before the buffered ones
+    const int r = a0.nbytes - 1;                                               // 0xFF bytes buffered behind bufbyte (zero- and small-capable, all of them)
+    const u32 b = lead_zt((u32)a0.bufbyte & 0xFFu), zb = b & 1u, tb = b >> 1;
+    const int hb = (int)(tb & (zh >> 1) & zh) | (r >= 1 ? (int)(zb & zh) : 0) | (r >= 2 ? (int)zb : 0) | (r >= 3);
+    s.hit = a0.nbytes >= 1 ? (hb & 1) : 0;
+    s.zp = a0.nbytes < 1 ? zh : r >= 2 ? 3u : r == 1 ? (1u | zb << 1) : (zb | (zh & 1u) << 1);
 }
-HD void sink_put(RingSink &s, int i, int v) { s.ring[(i - s.c0) & (RING_BYTES - 1)] = (u8)v; }
-#ifdef IMCVT_FORCE_OVF      // test builds: every rare-path byte overflows, so the safe path is exercised
-HD int sink_room(RingSink &s, int) { s.ovf = 1; return 0; }
-#else
-HD int sink_room(RingSink &s, int i) { if (i - s.c0 - s.fl >= RING_BYTES - 8) { s.ovf = 1; return 0; } return 1; }
-#endif   // rare paths leave 8 slots for the block's common-path bytes
-HD void ring_sync(RingSink &s, int cnt) { NOUNROLL while (cnt - s.c0 - s.fl >= 16) ring_flush16(s); }   // between token blocks: < 16 bytes stay pending
-HD void ring_finish(RingSink &s, int cnt) { NOUNROLL while (cnt - s.c0 > s.fl) ring_flush16(s); }        // tail: the bytes beyond cnt are never read
+HD void lsink_flush8(LeadSink &s, int valid) {           // the ring is only 4-byte aligned (odd dword stride between lanes); `valid` of the 8 leads are real
+    const u32a *r = (const u32a *)(s.ring + (s.fl & (LRING - 1)));
+    U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
+    g_st128(s.gbuf + 2 * s.fl, b); s.fl += 8;
+    u32 z = 0, t = 0;                                    // bit k: lead k of the eight
+    const u32 w[4] = { b.x, b.y, b.z, b.w };
+    for (int d = 0; d < 4; d++) {
+        const u32 lo = lead_zt(w[d] & 0xFFFFu), hi = lead_zt(w[d] >> 16);
+        z |= (lo & 1u) << (2 * d) | (hi & 1u) << (2 * d + 1);
+        t |= (lo >> 1) << (2 * d) | (hi >> 1) << (2 * d + 1);
+    }
+    const u32 live = valid >= 8 ? 0xFFu : (1u << valid) - 1u;
+    z &= live; t &= live;
+    const u32 ze = z << 2 | (s.zp & 1u) << 1 | (s.zp >> 1);               // bit k + 2: lead k; bits 1, 0: the two leads before
+    s.hit |= (t & (ze >> 1) & ze) != 0u;                                  // lead k small-capable, leads k - 1 and k - 2 zero-capable
+    s.zp = (ze >> (valid >= 8 ? 9 : valid + 1) & 1u) | (ze >> (valid >= 8 ? 8 : valid) & 1u) << 1;
+}
+HD void lsink_sync(LeadSink &s, int qn) { NOUNROLL while (qn - s.fl >= 8) lsink_flush8(s, 8); }             // between token blocks: < 8 leads stay pending
+HD void lsink_finish(LeadSink &s, int qn) { NOUNROLL while (qn > s.fl) lsink_flush8(s, qn - s.fl); }       // tail: the leads beyond qn are never read
 template <class S>
 HD void emit_byte(Arith &a, S &sink, int v) {                                                     // :820-831
     v &= 0xFF;
@@ -2351,7 +2382,7 @@ HD void code_token_q(Arith &a, u8 *cx, u16 *lq, int &qn, u32 tok) {
     a.range = byp ? a.range : (r2 << sh);
     a.nbits -= nb_;
     const int need = a.nbits < 12;                                                // :858-862
-    lq[qn] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));                          // always written; only kept when `need`
+    lq[qn & (LRING - 1)] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));                          // always written; only kept when `need`
     qn += need;
     a.nbits += need ? 8 : 0;
     a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
@@ -2373,7 +2404,7 @@ HD void code_token_r(Arith &a, u16 *lq, int &qn, u32 tok, u32 lw) {
     a.range = byp ? a.range : (r2 << sh);
     a.nbits -= nb_;
     const int need = a.nbits < 12;
-    lq[qn] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
+    lq[qn & (LRING - 1)] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
     qn += need;
     a.nbits += need ? 8 : 0;
     a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
@@ -2396,7 +2427,7 @@ HD u32 tok_of(const U4 &b, int j) { const u32 w = (j < 2) ? b.x : (j < 4) ? b.y 
 // (stream_seg: one segment of a stream on a sink that outlives it — the pipe wave codes a CU's stream in pieces as they become known)
 // RES: the tokens are resolved (code_token_r); cx is not used
 template <bool RES>
-HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) {
+HD void stream_seg_t(Arith &a, u8 *cx, LeadSink &sink, int &qn, const u16 *p, int n) {
     // token blocks are loaded unconditionally (index clamped to the stream's last block; p is always a valid address),
     // so the loop carries no conditional load and the only wait for a block is where it is first used, one round later
     const int last_blk = imax((n - 1) >> 3, 0);
@@ -2416,10 +2447,9 @@ HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p
         u32x4 nv;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv) : "v"(pn) : "memory");
 #endif
-        if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / lm rows belong to lane 0
+        if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / ring rows belong to lane 0
             const long long tp0 = prof_now();
-            ring_sync(sink, a.cnt);                         // full 16-byte runs of output leave the ring
-            int qn = 0;
+            lsink_sync(sink, qn);                           // full 16-byte runs of leads leave the ring
             MARK("p2_ring_sync");
             prof_add(PF_T_NDRAIN, tp0);
             const long long tp1 = prof_now();
@@ -2428,40 +2458,14 @@ HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p
                 UNROLL_FULL
                 for (int j = 0; j < 8; j++) lw[j] = SM.T.pst[(tok_of(cur, j) >> 1) & 127u].x;
                 UNROLL_FULL
-                for (int j = 0; j < 8; j++) code_token_r(a, lm->lq, qn, tok_of(cur, j), lw[j]);
+                for (int j = 0; j < 8; j++) code_token_r(a, sink.ring, qn, tok_of(cur, j), lw[j]);
             } else {
             UNROLL_FULL
             for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
-                code_token_q(a, cx, lm->lq, qn, tok_of(cur, j));
+                code_token_q(a, cx, sink.ring, qn, tok_of(cur, j));
             }
             MARK("p2_eight_tokens");
             prof_add(PF_T_NTOK, tp1); prof_cnt(PF_BORDER, 1);
-            const long long tp2 = prof_now();
-#if DRAIN_REGS
-            u32 lqw[4];                                     // the block's (at most 8) queued leads, read once: the loop below then has no LDS read to wait for
-            for (int d = 0; d < 4; d++) lqw[d] = *(const u32a *)&lm->lq[2 * d];
-            UNROLL_FULL
-            for (int i = 0; i < 8; i++) {
-                if (!WAVE_ANY(i < qn)) break;
-                const int act = i < qn;
-                const int lead = (int)((i & 1) ? lqw[i >> 1] >> 16 : lqw[i >> 1] & 0xFFFFu);
-#else
-            NOUNROLL
-            for (int i = 0; WAVE_ANY(i < qn); i++) {        // the bytes this block pushed out of `low` (:863-878): the common case is
-                const int act = i < qn;                     // straight-line (one byte buffered, no 0xFF run, no emulation prevention)
-                const int lead = (int)lm->lq[i];
-#endif
-                const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
-                const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
-                u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : (u8 *)&lm->lq[LEADQ - 1];
-                *dst = (u8)v1;
-                a.cnt += fast;
-                a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
-                a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
-                const int rare = act & !fast;
-                if (WAVE_ANY(rare)) { if (rare) carry_rare(a, sink, lead); }
-            }
-            prof_add(PF_T_DRAIN, tp2);
         }
 #ifdef IMCVT_HOSTEMU
         cur = nxt;
@@ -2473,7 +2477,7 @@ HD void stream_seg_t(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p
 #endif
     }
 }
-HD void stream_seg(Arith &a, u8 *cx, LaneMem *lm, RingSink &sink, const u16 *p, int n) { stream_seg_t<false>(a, cx, lm, sink, p, n); }
+HD void stream_seg(Arith &a, u8 *cx, LeadSink &sink, int &qn, const u16 *p, int n) { stream_seg_t<false>(a, cx, sink, qn, p, n); }
 
 // ---------------------------------------------------------------------------------------------------
 // The trial coder split over two wavefronts (wide workgroups).  A token step (code_token_q) is two recurrences: the RANGE side —
@@ -2580,7 +2584,7 @@ HD void token_L(Arith &a, u16 *lq, int &qn, u32 rec) {
     a.low = ((a.low + add) << nb_) + mul24(rg, val);
     a.nbits -= nb_;
     const int need = a.nbits < 12;                                                // :858-862
-    lq[qn] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
+    lq[qn & (LRING - 1)] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));
     qn += need;
     a.nbits += need ? 8 : 0;
     a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
@@ -2687,10 +2691,6 @@ HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
 // `zt` keeps those two bits per lead (zero-capable in the low half-word, small-capable in the high one; last lead in bit 0 of each); a lane
 // that ever shows two zero-capable leads and then a small-capable one is priced again by the plain coder (the caller's safe path) — a
 // handful of lanes per frame.
-#ifndef EP_GUARD_MASK
-#define EP_GUARD_MASK 0xFEu                      // (lead + 1) & mask == 0  <=>  low byte 0xFF or 0x00 (tests widen both nets with a smaller mask: many lanes on the safe path)
-#endif
-#define EP_GUARD_MASK3 ((EP_GUARD_MASK << 2 | 3u) & 0xF8u & (EP_GUARD_MASK | 7u))      // ... low byte 0xFF or 0x00..0x06 (a superset of "at most 3 with a carry")
 HD void len_step(Arith &a, int &qn, u32 &zt, int nb_, int v) {
     a.low = (a.low << nb_) + v;
     a.nbits -= nb_;
@@ -2750,7 +2750,7 @@ HD void stream_seg_L1_byp(Arith &a, int &qn, u32 &zz, int &slow, const u16 *p, i
     }
 }
 // Byte half: consumes the records of n tokens of this lane.  Same trip count as the owner's stream_seg_R (same n).
-HD void stream_seg_L(Arith &a, LaneMem *lm, RingSink &sink, SplitQ &q, int lane, int &blk, int n) {
+HD void stream_seg_L(Arith &a, LeadSink &sink, int &qn, SplitQ &q, int lane, int &blk, int n) {
     const int ql = lane < NMODE ? lane : 0;
     const u32 *const row = q.rec[ql];
     int prod_seen = 0;
@@ -2770,38 +2770,120 @@ HD void stream_seg_L(Arith &a, LaneMem *lm, RingSink &sink, SplitQ &q, int lane,
 #endif
             blk++;
             lds_st_i32(&q.cons[ql], blk);
-            ring_sync(sink, a.cnt);
-            int qn = 0;
+            lsink_sync(sink, qn);
             UNROLL_FULL
-            for (int j = 0; j < 8; j++) token_L(a, lm->lq, qn, rec[j]);
-            u32 lqw[4];
-            for (int d = 0; d < 4; d++) lqw[d] = *(const u32a *)&lm->lq[2 * d];
-            UNROLL_FULL
-            for (int i = 0; i < 8; i++) {
-                if (!WAVE_ANY(i < qn)) break;
-                const int act = i < qn;
-                const int lead = (int)((i & 1) ? lqw[i >> 1] >> 16 : lqw[i >> 1] & 0xFFFFu);
-                const int v1 = (a.bufbyte + (lead >> 8)) & 0xFF;
-                const int fast = act & (a.nbytes == 1) & (lead != 0xFF) & !((a.zeros >= 2) & (v1 <= 3));
-                u8 *dst = fast ? sink.ring + ((a.cnt - sink.c0) & (RING_BYTES - 1)) : (u8 *)&lm->lq[LEADQ - 1];
-                *dst = (u8)v1;
-                a.cnt += fast;
-                a.zeros = fast ? (v1 ? 0 : a.zeros + 1) : a.zeros;
-                a.bufbyte = fast ? (lead & 0xFF) : a.bufbyte;
-                const int rare = act & !fast;
-                if (WAVE_ANY(rare)) { if (rare) carry_rare(a, sink, lead); }
+            for (int j = 0; j < 8; j++) token_L(a, sink.ring, qn, rec[j]);
+        }
+    }
+}
+// What a trial ends with (every lane of the wavefront; `on`: the lane has a stream): the rest of the leads to memory, their number behind
+// them, and the byte-level state — counted (bytes = leads: the state the coder started from, cnt moved on by the leads) or, for a lane
+// whose leads show the emulation-prevention pattern, by the real logic over its list.
+HD void leads_exact(Arith &a, const Arith &a0, const u8 *gbuf, int qn, int mine) {      // (wave collective: `mine` — this lane is one of those it is run for)
+    CountSinkT cs; cs.dummy = 0;
+    Arith t = a0;
+    const int n = mine ? qn : 0;
+    NOUNROLL
+    for (int i = 0; WAVE_ANY(i < n); i++)
+        if (i < n) { const int lead = (int)(u16)g_ld16((const i16 *)(gbuf + 2 * i)); lead_step(t, cs, lead); }
+    if (mine) { a.cnt = t.cnt; a.nbytes = t.nbytes; a.bufbyte = t.bufbyte; a.zeros = t.zeros; }
+}
+HD void trial_finish(Arith &a, const Arith &a0, LeadSink &sink, int qn, int on) {
+    if (on) {
+        lsink_finish(sink, qn);
+        g_st32(sink.gbuf + TRIAL_BYTES - 4, (u32)qn);
+        a.cnt = a0.cnt + qn; a.nbytes = a0.nbytes; a.bufbyte = a0.bufbyte; a.zeros = a0.zeros;
+    }
+    const int ex = on & sink.hit;
+    if (WAVE_ANY(ex)) {
+        drain_stores();                                     // (the list is read back from memory)
+        leads_exact(a, a0, sink.gbuf, qn, ex);
+    }
+}
+// The winner's leads -> bytes (one wavefront, every lane).  `a`: the coder state the winner's trial started from, with low / range / nbits
+// already those it ended with; on return its byte-level part (cnt, nbytes, bufbyte, zeros) is what the byte-level logic of :863-878, :820-831
+// leaves after the n leads, and the bytes emitted on the way are at dst[a0.cnt ..).
+// A lead is a digit of a long number with a carry bit on top; the bytes buffered on entry are its first digits.  The carry out of digit k is
+// c_k | (v_k == 0xFF & carry out of digit k + 1): a carry-lookahead over the ballots of the two predicates — by the scalar adder, 64 digits a
+// round, from the last round to the first.  What stays buffered at the end is the last digit that is not a plain 0xFF lead, and the 0xFF
+// run behind it.  Emulation prevention is checked on the resolved bytes (a second pass, forward); if it would strike — two zero bytes, then
+// one of 3 or less — or nothing anchors the buffer, lane 0 walks the list with the byte-level logic itself (practically never).
+#ifdef IMCVT_HOSTEMU
+HD u64 brev64(u64 x) { u64 r = 0; for (int i = 0; i < 64; i++) r |= ((x >> i) & 1ull) << (63 - i); return r; }
+#else
+HD u64 brev64(u64 x) { return __builtin_bitreverse64(x); }
+#endif
+HD void resolve_leads(Arith &a, const u8 *list, int n, u8 *dst) {
+    const Arith a0 = a;
+    const int nb0 = a0.nbytes, m = nb0 + n;                 // digits: nb0 buffered bytes (bufbyte, then 0xFF), then the leads
+    const int nch = (m + 63) >> 6;
+    int fallback = 0;
+    LANES(l) {
+        // pass 1, last round first: carries; the resolved digits go to dst as if all were emitted (the buffered tail is overwritten later or never read)
+        u32 cin = 0;
+        int anchor = -1;                                    // last digit that is not a plain 0xFF lead
+        NOUNROLL
+        for (int ch = nch - 1; ch >= 0; ch--) {
+            const int k = ch * 64 + l, live = k < m;
+            int L = 0xFF;
+            if (live) L = k < nb0 ? (k == 0 ? (a0.bufbyte & 0xFF) | 0x200 : 0xFF) : (int)(u16)g_ld16((const i16 *)(list + 2 * (k - nb0)));      // (0x200: the buffered byte anchors the run behind it)
+            if (live && nb0 == 0 && k == 0) L = (L & 0xFF) | 0x200;             // the very first lead of a stream: it becomes the buffered byte, its carry is dropped (:876)
+            const int c = (L >> 8) & 1, ff = (L & 0xFF) == 0xFF;
+            const u64 G = brev64(wave_ballot(live && c)), P = brev64(wave_ballot(live && ff));
+            const u64 A = G | P, S = A + G + (u64)cin;
+            const u64 CI = brev64(S ^ A ^ G);               // bit l: carry INTO this lane's digit (= out of the next one)
+            cin = (u32)((((A & G) | ((A | G) & ~S)) >> 63) & 1u);
+            const int v = ((L & 0xFF) + (int)((CI >> l) & 1u)) & 0xFF;
+            if (live) g_st8(dst + a0.cnt + k, v);
+            const u64 an = wave_ballot(live && L != 0xFF);
+            if (anchor < 0 && an != 0) anchor = ch * 64 + hibit64(an);
+        }
+        const int jt = anchor;                              // digits 0 .. jt - 1 are emitted, jt .. m - 1 stay buffered
+        if (jt < 0) fallback = 1;
+        else {
+            // pass 2, forward: would emulation prevention have struck?  and the run of zero bytes the emitted part ends with
+            wave_sync();
+            u32 zprev = a0.zeros >= 2 ? 3u : a0.zeros == 1 ? 1u : 0u;      // bit 0: the byte before is zero, bit 1: the one before that
+            int zrun = a0.zeros;
+            NOUNROLL
+            for (int ch = 0; ch * 64 < jt; ch++) {
+                const int k = ch * 64 + l, live = k < jt;
+                const int v = live ? (int)g_ld8(dst + a0.cnt + k) : 1;
+                const u64 Z = wave_ballot(live && v == 0), T = wave_ballot(live && v <= 3);
+                const u64 Z1 = Z << 1 | (zprev & 1u), Z2 = Z << 2 | (u64)(zprev & 1u) << 1 | (zprev >> 1);
+                if ((T & Z1 & Z2) != 0) fallback = 1;
+                const int cnt = imin(64, jt - ch * 64);
+                const u64 livem = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
+                const u64 nz = ~Z & livem;                  // non-zero emitted bytes of this round
+                zrun = nz ? cnt - 1 - hibit64(nz) : zrun + cnt;
+                zprev = (u32)((Z >> (cnt - 1)) & 1u) | (u32)(cnt >= 2 ? (Z >> (cnt - 2)) & 1u : (zprev & 1u)) << 1;
             }
+            if (!fallback) {
+                const int Lt = jt < nb0 ? a0.bufbyte : (int)(u16)g_ld16((const i16 *)(list + 2 * (jt - nb0)));
+                a.cnt = a0.cnt + jt; a.nbytes = m - jt; a.bufbyte = (jt < nb0 || jt == 0) ? Lt : (Lt & 0xFF); a.zeros = zrun;      // (the buffered byte of the entry state stays as it is; a stream's very first lead is kept whole, :876)
+            }
+        }
+        if (fallback) {                                     // lane 0, lead by lead (every lane computes the same state; one lane stores)
+            Arith t = a0;
+            Sink sk; sk.base = dst; sk.off = 0;
+            NOUNROLL
+            for (int i = 0; i < n; i++) {
+                const int lead = (int)(u16)g_ld16((const i16 *)(list + 2 * i));
+                if (l == 0) lead_step(t, sk, lead); else { CountSinkT cs; cs.dummy = 0; lead_step(t, cs, lead); }
+            }
+            a.cnt = t.cnt; a.nbytes = t.nbytes; a.bufbyte = t.bufbyte; a.zeros = t.zeros;
         }
     }
 }
 template <bool RES = false>
-HD int stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n) {
-    RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
-    stream_seg_t<RES>(a, cx, lm, sink, p, n);
+HD void stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n, int on) {
+    const Arith a0 = a;
+    LeadSink sink; lsink_begin(sink, a0, (u16 *)lm->ring, gbuf);
+    int qn = 0;
+    stream_seg_t<RES>(a, cx, sink, qn, p, n);
     const long long tx3 = prof_now();
-    ring_finish(sink, a.cnt);
+    trial_finish(a, a0, sink, qn, on);
     prof_add(PF_X3, tx3);
-    return sink.ovf;
 }
 // the same on the safe path: bytes go straight to memory, one token load per step
 HD void stream_seg_safe(Arith &a, u8 *cx, Sink &sink, const u16 *p, int n) {
@@ -2818,31 +2900,21 @@ HD void stream_run_safe(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n) {
 static long long g_tokstat[4];    // trials, tokens, lanes with a stream
 #endif
 HD void run_trial(Arith &a, const u8 *cx_src, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n, int on) {
-    const Arith a0 = a;
 #ifdef IMCVT_TOKSTAT
     if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
 #endif
     const long long tx1 = prof_now();
     if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i);
     prof_add(PF_X1, tx1);                                   // (IMCVT_PROF builds: x1 = context copy, x2 = wait for the first token block, x3 = after the last block)
-    const int ovf = stream_run(a, cx, lm, gbuf, p, on ? n : 0);
-    if (WAVE_ANY(ovf)) {                                    // practically never: redo the overflowed lanes without the ring
-        if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_src + i); }
-        stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
-    }
+    stream_run(a, cx, lm, gbuf, p, on ? n : 0, on);
 }
-// One trial on resolved tokens (the 4x4 PU candidates: fresh contexts, state hints in the tokens): no context copy at all.  The
-// safe path (ring overflow) is the ordinary coder on a copy of the fresh contexts — the tokens carry their context indices too.
+// One trial on resolved tokens (the 4x4 PU candidates: fresh contexts, state hints in the tokens): no context copy at all.
 HD void run_trial_r(Arith &a, const u8 *cx_fresh, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n, int on) {
-    const Arith a0 = a;
+    (void)cx_fresh;
 #ifdef IMCVT_TOKSTAT
     if (on) { g_tokstat[1] += n; g_tokstat[2]++; if (n > g_tokstat[3]) g_tokstat[3] = n; }
 #endif
-    const int ovf = stream_run<true>(a, cx, lm, gbuf, p, on ? n : 0);
-    if (WAVE_ANY(ovf)) {
-        if (ovf) { a = a0; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(cx_fresh + i); }
-        stream_run_safe(a, cx, gbuf, p, ovf ? n : 0);
-    }
+    stream_run<true>(a, cx, lm, gbuf, p, on ? n : 0, on);
 }
 
 // ---------------------------------------------------------------------------------------------------

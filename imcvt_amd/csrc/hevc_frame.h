@@ -116,22 +116,16 @@ HDN void partner_trial(int own_, int depth_) {
     wave_sync();                                        // token counts are final, the streams are in memory
     const RdW rw = rd_weights(F.job.q);
     u8 *const ubytes = uniform_ptr(F.sc.bytes);
-    const u16 *tok = wave_tok(F.sc, own);
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a = SM.entry_a[depth];
         const Arith a0 = a;
         const int len0 = arith_len(a), n = on ? W.tokn[ll] : 0;
         u8 *gbuf = ubytes + (size_t)(own * NMODE + ll) * TRIAL_BYTES;
-        RingSink sink; sink.ring = X.lm[ll].ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
-        int blk = 0;
-        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, n);
-        ring_finish(sink, a.cnt);
-        const int ovf = sink.ovf;
-        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — this lane's bytes again, by the plain coder on a scratch copy of the contexts
-            if (ovf) { a = a0; ctx_copy(X.cx[ll], SM.entry_cx[depth]); }
-            stream_run_safe(a, X.cx[ll], gbuf, tok + (size_t)ll * TOK_CAP, ovf ? n : 0);
-        }
+        LeadSink sink; lsink_begin(sink, a0, (u16 *)X.lm[ll].ring, gbuf);
+        int blk = 0, qn = 0;
+        stream_seg_L(a, sink, qn, q, l, blk, n);
+        trial_finish(a, a0, sink, qn, on);
         split_await(&q.rdone, q);
         if (on) {
             a.range = q.range_out[l];
@@ -288,13 +282,14 @@ HDN void partner_fourtu(int depth_) {
         u8 *gbuf = ubytes + (size_t)(1 * NMODE + ll) * TRIAL_BYTES;
         const u16 *ts = tok + (size_t)ll * TOK_CAP;
         if (on) ctx_copy(cx, SM.entry_cx[depth]);
-        RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
-        int from = 0;
+        const Arith a0 = a;
+        LeadSink sink; lsink_begin(sink, a0, (u16 *)lm->ring, gbuf);
+        int from = 0, qn = 0;
         for (int k = 0; k < 3; k++) {
             while (lds_ld_i32(&C.b_seg) - base <= k) pipe_pause();
             wave_sync();
             const int end = C.seg_end[k][ll];
-            stream_seg(a, cx, lm, sink, ts + from, on ? end - from : 0);
+            stream_seg(a, cx, sink, qn, ts + from, on ? end - from : 0);
             from = (end + 7) & ~7;
         }
         {   // the last segment: wave 1 is through with its passes by the time it is complete and takes the range half (fourtu_last_range_half); the byte half stays here
@@ -306,18 +301,11 @@ HDN void partner_fourtu(int depth_) {
             wave_sync();
             const int end = C.seg_end[3][ll];
             int blk = 0;
-            stream_seg_L(a, lm, sink, q, l, blk, on ? end - from : 0);
+            stream_seg_L(a, sink, qn, q, l, blk, on ? end - from : 0);
             split_await(&q.rdone, q);
             if (on) a.range = q.range_out[l];
         }
-        if (on) ring_finish(sink, a.cnt);
-        const int ovf = on & (sink.ovf != 0);
-        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — the lane's stream again on the safe path
-            if (ovf) { a = SM.entry_a[depth]; ctx_copy(cx, SM.entry_cx[depth]); }
-            Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
-            int f2 = 0;
-            for (int k = 0; k < 4; k++) { const int end = C.seg_end[k][ll]; stream_seg_safe(a, cx, ss, ts + f2, ovf ? end - f2 : 0); f2 = (end + 7) & ~7; }
-        }
+        trial_finish(a, a0, sink, qn, on);
         if (on) {
             W.fin[l] = pack_arith(a);
             W.cost[l] = rd_cost(rw, W.sse[l], arith_len(a) - len0);
@@ -798,23 +786,17 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
         Arith a = SM.entry_a[2];
         const int len0 = arith_len(a);
         if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i);
-        RingSink sink; sink.ring = lm->ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
-        stream_seg(a, cx, lm, sink, hdr, on ? nh : 0);
+        const Arith a0 = a;
+        LeadSink sink; lsink_begin(sink, a0, (u16 *)lm->ring, gbuf);
+        int qn = 0;
+        stream_seg(a, cx, sink, qn, hdr, on ? nh : 0);
         const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
-        stream_seg(a, cx, lm, sink, kept, on ? n012 : 0);
+        stream_seg(a, cx, sink, qn, kept, on ? n012 : 0);
         while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
         wave_sync();
         const int mine = on & (l == W2.pu_mode[3]);
-        stream_seg(a, cx, lm, sink, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
-        if (mine) ring_finish(sink, a.cnt);
-        const int ovf = mine & (sink.ovf != 0);
-        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — the whole stream again on the safe path
-            if (ovf) { a = SM.entry_a[2]; for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i); }
-            Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
-            stream_seg_safe(a, cx, ss, hdr, ovf ? nh : 0);
-            stream_seg_safe(a, cx, ss, kept, ovf ? n012 : 0);
-            stream_seg_safe(a, cx, ss, kept + 3 * NXN_KEEP_STRIDE, ovf ? W2.pu_cnt[3] : 0);
-        }
+        stream_seg(a, cx, sink, qn, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+        trial_finish(a, a0, sink, qn, mine);
         if (mine) {
             W.fin[0] = pack_arith(a);
             WM(2).nxn_cost = rd_cost(rw, W2.pu_sse[0] + W2.pu_sse[1] + W2.pu_sse[2] + W2.pu_sse[3], arith_len(a) - len0);
@@ -846,23 +828,16 @@ HDN void partner_pipe() {
         const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
         Arith a = SM.entry_a[2];
         const int len0 = arith_len(a);
-        RingSink sink; sink.ring = X.lm[ll].ring; sink.gbuf = gbuf; sink.c0 = a.cnt; sink.fl = 0; sink.ovf = 0;
-        int blk = 0;
-        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, on ? nh : 0);
+        const Arith a0 = a;
+        LeadSink sink; lsink_begin(sink, a0, (u16 *)X.lm[ll].ring, gbuf);
+        int blk = 0, qn = 0;
+        stream_seg_L(a, sink, qn, q, l, blk, on ? nh : 0);
         const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
-        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, on ? n012 : 0);
+        stream_seg_L(a, sink, qn, q, l, blk, on ? n012 : 0);
         split_await(&q.mid, q);                         // PU 3 is decided (its winner's tokens are in memory)
         const int mine = on & (l == W2.pu_mode[3]);
-        stream_seg_L(a, &X.lm[ll], sink, q, l, blk, mine ? W2.pu_cnt[3] : 0);
-        if (mine) ring_finish(sink, a.cnt);
-        const int ovf = mine & (sink.ovf != 0);
-        if (WAVE_ANY(ovf)) {                            // practically never: the ring overflowed — the winning lane's bytes again on the safe path (scratch contexts: the owner's are final already)
-            if (ovf) { a = SM.entry_a[2]; ctx_copy(X.cx[ll], SM.entry_cx[2]); }
-            Sink ss; ss.base = gbuf; ss.off = (u32)(0 - a.cnt);
-            stream_seg_safe(a, X.cx[ll], ss, hdr, ovf ? nh : 0);
-            stream_seg_safe(a, X.cx[ll], ss, kept, ovf ? n012 : 0);
-            stream_seg_safe(a, X.cx[ll], ss, kept + 3 * NXN_KEEP_STRIDE, ovf ? W2.pu_cnt[3] : 0);
-        }
+        stream_seg_L(a, sink, qn, q, l, blk, mine ? W2.pu_cnt[3] : 0);
+        trial_finish(a, a0, sink, qn, mine);
         split_await(&q.rdone, q);
         if (mine) {
             a.range = q.range_out[l];
@@ -957,13 +932,17 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
         const int pk = (kind == 3) && F.pipe;             // the NxN trial ran on the pipe wave: its result sits in that wave's slice, lane nxn_lane
         const int ww = pk ? PIPE_WAVE : (kind == 3) ? 2 : kind - 1, wl = pk ? SM.nxn_lane : (kind == 3) ? 0 : mode, fl = pk ? 0 : wl;
         const WaveMem &WW = pk ? PM : WM(ww);
-        const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WW.fin[fl].w2 >> 16);
         const u8 *src = lane_bytes(F.sc, ww, wl);
+        const FinState fe = WW.fin[fl];                     // (the coder state the winner's trial ended in: read before the rebuild below reuses wave 0's buffers)
+        const int as_bytes = NXN_UNI && kind == 3 && !pk;      // (the NxN trial on the scalar unit, stream_run_uni, leaves bytes; every other trial leaves the leads of its bytes)
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
-            for (int i = tid; i < cnt1 - cnt0; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(src + i));
             if (tid < CTX_STRIDE) SM.cx[tid] = WW.u.p2.cx[wl][tid];
-            if (tid == 64) SM.live = unpack_arith(WW.fin[fl]);
+            if (as_bytes) {
+                const int cnt0 = SM.entry_a[depth].cnt, cnt1 = (int)(WW.fin[fl].w2 >> 16);
+                for (int i = tid; i < cnt1 - cnt0; i += WG_THREADS) g_st8(live_sink + cnt0 + i, g_ld8(src + i));
+                if (tid == 64) SM.live = unpack_arith(WW.fin[fl]);
+            }
             if (tid >= 128 && tid < 128 + 64) {             // neighbour maps (:1444-1445, :1549-1553)
                 const int n = N >> 2, i = (tid - 128) >> 3, j = (tid - 128) & 7;
                 if (i < n && j < n) {
@@ -975,7 +954,18 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
         }
         wg_sync_p();
         const long long ptr_ = prof_now();
-        if (kind != 3) rebuild_winner(kind, mode, N, y0, x0, avm);     // the winner's reconstruction into the tile
+        if (kind != 3) rebuild_winner(kind, mode, N, y0, x0, avm);     // the winner's reconstruction into the tile (wave 0)
+        if (!as_bytes) {                                    // meanwhile wave 1: the winner's leads -> bytes, straight into the frame's stream, and the byte-level state they leave (hevc_core.h resolve_leads)
+            WAVES(w) LANES(l) {
+                if (w == 1) {
+                    const Arith e = unpack_arith(fe);
+                    Arith a = SM.entry_a[depth];
+                    a.low = e.low; a.range = e.range; a.nbits = e.nbits;
+                    resolve_leads(a, src, (int)g_ld32(src + TRIAL_BYTES - 4), live_sink);
+                    if (l == 0) SM.live = a;
+                }
+            }
+        }
         prof_add(PF_RECON, ptr_);
         wg_sync_p();
     }
@@ -1275,30 +1265,43 @@ HDN void serve_request(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m
     }
     wg_sync();
     const int kind = SM.win_kind, mode = SM.win_mode;
-    {   // the winner's coder state, contexts and bytes (the rebuild below reuses wave 0's pass buffer, where the contexts live)
+    {   // the winner's contexts (the rebuild below reuses wave 0's pass buffer, where they live); then its reconstruction (wave 0) and, meanwhile, its
+        // leads -> bytes (wave 1, hevc_core.h resolve_leads: into the buffer of a candidate that lost); then bytes, coder state and reconstruction to the mailbox
         const int ww = kind - 1;
-        const FinState fin = WM(ww).fin[mode];
-        const int nbytes = (int)(fin.w2 >> 16) - SM.entry_a[depth].cnt;
         const u8 *src = lane_bytes(F.sc, ww, mode);
+        u8 *tmp = lane_bytes(F.sc, ww ^ 1, 0);
+        const int cnt0 = SM.entry_a[depth].cnt;
         WAVES(w) LANES(l) {
             const int tid = w * 64 + l;
-            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) m_st32(R->bytes + 4 * i, g_ld32(src + 4 * i));
             if (tid < CTX_STRIDE / 4) m_st32(R->ctx + 4 * tid, *(const u32a *)&WM(ww).u.p2.cx[mode][4 * tid]);
+        }
+        const FinState fe = WM(ww).fin[mode];
+        wg_sync();
+        rebuild_winner(kind, mode, N, y0, x0, avm);
+        WAVES(w) LANES(l) {
+            if (w == 1) {
+                const Arith e = unpack_arith(fe);
+                Arith a = SM.entry_a[depth];
+                a.low = e.low; a.range = e.range; a.nbits = e.nbits;
+                resolve_leads(a, src, (int)g_ld32(src + TRIAL_BYTES - 4), tmp - cnt0);
+                if (l == 0) SM.live = a;
+            }
+        }
+        wg_sync();
+        const FinState fin = pack_arith(SM.live);
+        const int nbytes = SM.live.cnt - cnt0;
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) m_st32(R->bytes + 4 * i, g_ld32(tmp + 4 * i));
             if (tid == 64) {
                 m_st32(&R->cost, (u32)SM.red[0]); m_st32(&R->kind, (u32)kind); m_st32(&R->mode, (u32)mode); m_st32(&R->nbytes, (u32)nbytes);
                 m_st32(&R->fin.w0, fin.w0); m_st32(&R->fin.w1, fin.w1); m_st32(&R->fin.w2, fin.w2);
             }
-        }
-    }
-    wg_sync();
-    rebuild_winner(kind, mode, N, y0, x0, avm);
-    wg_sync();
-    WAVES(w) LANES(l) {
-        const int tid = w * 64 + l;
-        for (int i = tid; i < N * N / 4; i += WG_THREADS) {
-            const int y = i / (N / 4), x4 = (i % (N / 4)) * 4;
-            const u8 *sp = &SM.rec[y0 + y + 1][x0 + x4 + 1];
-            m_st32(R->rec + y * N + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
+            for (int i = tid; i < N * N / 4; i += WG_THREADS) {
+                const int y = i / (N / 4), x4 = (i % (N / 4)) * 4;
+                const u8 *sp = &SM.rec[y0 + y + 1][x0 + x4 + 1];
+                m_st32(R->rec + y * N + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
+            }
         }
     }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { m_st32(&m->pad0_[3], (u32)wd_now()); hb_beat(); } }

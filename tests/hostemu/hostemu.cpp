@@ -228,6 +228,20 @@ extern "C" long hostemu_mfma_calls(int kind) { return g_mfma_calls[kind & 1]; }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
 extern "C" int hostemu_pipe_lds_bytes(void) { return (int)PIPE_LDS_BYTES; }
 
+// The device's resolve_leads (hevc_core.h) on one emulated wavefront: leads -> bytes at dst[st[3] ..), byte-level state in / out in st = { nbytes, bufbyte, zeros, cnt }
+static struct { const unsigned char *list; int n; Arith a; unsigned char *dst; } g_rl;
+static void emu_entry_resolve() { Arith a = g_rl.a; resolve_leads(a, g_rl.list, g_rl.n, g_rl.dst); if (emu_lane() == 0) g_rl.a = a; }
+extern "C" int hostemu_resolve_leads(const unsigned short *leads, int n, int *st, unsigned char *dst) {
+    static Shm *shm = (Shm *)calloc(1, sizeof(Shm));
+    g_shm_of[0] = shm; g_pipe_of[0] = nullptr;
+    Arith a; arith_reset(a); a.nbytes = st[0]; a.bufbyte = st[1]; a.zeros = st[2]; a.cnt = st[3];
+    g_rl.list = (const unsigned char *)leads; g_rl.n = n; g_rl.a = a; g_rl.dst = dst;
+    g_nfib = 64; g_spins = 0;
+    emu_run(emu_entry_resolve);
+    st[0] = g_rl.a.nbytes; st[1] = g_rl.a.bufbyte; st[2] = g_rl.a.zeros; st[3] = g_rl.a.cnt;
+    return 0;
+}
+
 // The device's RDOQ (rdoq_group, hevc_core.h) on a sz x sz block of transform coefficients, group by group, with the thresholds
 // the host derives for qpd6 (hevc_tables.h) staged as a frame stages them.  dst: signed levels; groups the weak-group test
 // clears come back as zeros, like the reference's quantize().

@@ -375,3 +375,77 @@ def test_pu_pricing_length_rule_leads_equal_bytes_unless_guard_fires():
             quiet += 1
             assert n == len(leads), leads
     assert fired > 1000 and quiet > 1000 and inserted > 100          # both sides exercised, and insertions do happen behind the guard
+
+
+def _byte_logic(leads, nbytes, buf, zeros, cnt, out):
+    """The byte-level logic of the coder (:863-878, :820-831) over a list of 9-bit leads; bytes go to out[cnt ..]."""
+    def emit(v):
+        nonlocal zeros, cnt
+        v &= 0xFF
+        if zeros >= 2 and v <= 3:
+            out[cnt] = 3; cnt += 1; zeros = 0
+        out[cnt] = v; cnt += 1
+        zeros = 0 if v else zeros + 1
+    for lead in leads:
+        if lead == 0xFF:
+            nbytes += 1
+        elif nbytes > 0:
+            carry = lead >> 8
+            v = buf + carry
+            buf = lead & 0xFF
+            emit(v)
+            v = (0xFF + carry) & 0xFF
+            while nbytes > 1:
+                emit(v); nbytes -= 1
+        else:
+            nbytes, buf = 1, lead
+    return nbytes, buf, zeros, cnt
+
+
+def test_winner_leads_to_bytes_matches_the_byte_level_logic(hostemu):
+    """hevc_core.h resolve_leads (the winner's leads -> bytes, by one wavefront: carry look-ahead over ballots, emulation prevention checked on the
+    result, lane 0's walk when it would strike) against the byte-level logic itself: random lists, lists full of 0xFF runs and carries, lists that
+    force emulation prevention, lists longer than a wavefront, every kind of entry state."""
+    import random
+    rng = random.Random(11)
+    lib = hostemu
+    lib.hostemu_resolve_leads.restype = C.c_int
+    lib.hostemu_resolve_leads.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.POINTER(C.c_int), u8p]
+    pools = [list(range(512)), [0xFF] * 6 + [0x1FF, 0x100, 0x00, 0x01, 0xFE, 0x1FE, 0x80, 0x17F], [0x00, 0x100, 0xFF, 0x01, 0x02, 0x03, 0x04, 0x1FF, 0x55]]
+    ep_runs = 0
+    for it in range(1500):
+        pool = pools[it % 3]
+        n = rng.choice([0, 1, 2, 5, 30, 63, 64, 65, 130, 200]) if it % 5 else rng.randint(0, 300)
+        leads = [rng.choice(pool) for _ in range(n)]
+        fresh = it % 7 == 0
+        st = (0, 0xFF, 0, 0) if fresh else (rng.choice([1, 1, 1, 2, 3, 5]), rng.choice([0, 0xFF, 0x7F, 3, 0xFE]), rng.choice([0, 0, 1, 2, 3]), rng.randint(0, 40))
+        # a carry can only be absorbed by a byte below 0xFF somewhere in the buffer: the coder guarantees it, random lists must too
+        chk, ok = ([] if fresh else [st[1]] + [0xFF] * (st[0] - 1)), True
+        for i, lead in enumerate(leads):
+            v = lead & 0xFF
+            if lead >> 8:
+                if fresh and i == 0:
+                    pass                                    # (the first lead's carry is dropped)
+                else:
+                    j = len(chk) - 1
+                    while j >= 0 and chk[j] == 0xFF:
+                        j -= 1
+                    if j < 0 and not (fresh and i == 0):
+                        ok = False; break
+                    chk[j] += 1
+                    for t in range(j + 1, len(chk)):
+                        chk[t] = 0
+            chk.append(v)
+        if not ok:
+            continue
+        want = np.zeros(800, np.uint8)
+        wst = _byte_logic(leads, st[0], st[1], st[2], st[3], want)
+        ep_runs += wst[0] + wst[3] != st[0] + st[3] + len(leads)
+        got = np.zeros(800, np.uint8)
+        arr = (C.c_ushort * max(n, 1))(*leads)
+        gst = (C.c_int * 4)(*st)
+        lib.hostemu_resolve_leads(arr, n, gst, got.ctypes.data_as(u8p))
+        g = tuple(gst)
+        assert (g[0], g[1] & 0xFF, min(g[2], 2), g[3]) == (wst[0], wst[1] & 0xFF, min(wst[2], 2), wst[3]), (it, st, leads[:20], g, wst)
+        assert bytes(got[st[3]:wst[3]]) == bytes(want[st[3]:wst[3]]), (it, st, leads[:20])
+    assert ep_runs > 20                                     # emulation prevention did strike in some of them (lane 0's walk)
