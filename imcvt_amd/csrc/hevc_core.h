@@ -564,6 +564,7 @@ HD void prof_add_row(int, int, long long) {}
 HD void prof_cnt(int, int) {}
 HD void tl_start() { if (threadIdx.x == 0) { SM.tl_t0 = (unsigned long long)clock64(); ((unsigned long long *)SM.prof)[0] += 1; } }
 HD void tl_mark(int ev) { if ((threadIdx.x & 63u) == 0) ((unsigned long long *)SM.prof)[ev] += (unsigned long long)clock64() - SM.tl_t0; }
+HD void tl_count(int ev) { if ((threadIdx.x & 63u) == 0) ((unsigned long long *)SM.prof)[ev] += 1; }
 #elif defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
 HD long long prof_now() { return clock64(); }
 HD int threadIdx_wave() { return (int)(threadIdx.x >> 6); }
@@ -572,6 +573,7 @@ HD void prof_add_row(int row, int cat, long long t0) { if ((threadIdx.x & 63u) =
 HD void prof_cnt(int cat, int n) { if ((threadIdx.x & 63u) == 0 && threadIdx.x < WG_THREADS) SM.prof[threadIdx.x >> 6][cat] += (unsigned long long)n; }
 HD void tl_start() {}
 HD void tl_mark(int) {}
+HD void tl_count(int) {}
 #else
 HD long long prof_now() { return 0; }
 HD int threadIdx_wave() { return 0; }
@@ -580,6 +582,7 @@ HD void prof_add_row(int, int, long long) {}
 HD void prof_cnt(int, int) {}
 HD void tl_start() {}
 HD void tl_mark(int) {}
+HD void tl_count(int) {}
 #endif
 // Wave collectives for the decisions: the reference's "last minimum wins" scan (`best >= cost` accepts, :1439, :1475, :1520)
 // over a wave's lanes = the minimum over the valid lanes, then the highest valid lane that holds it.
@@ -633,38 +636,73 @@ HD int sink_room(CountSinkT &, int) { return 1; }
 //   with low byte 0x00 / 0xFF and then one with 0xFF / 0x00..0x03.  The flush looks for that pattern (`hit`; the bytes still buffered on
 //   entry count as leads: lsink_begin); a lane that shows it gets its byte-level state by the real logic over its list (leads_exact) —
 //   a few lanes per frame.  The winner's list is turned into bytes once, by a whole wavefront (resolve_leads).
-#ifndef EP_GUARD_MASK
-#define EP_GUARD_MASK 0xFEu                      // (lead + 1) & mask == 0  <=>  low byte 0xFF or 0x00 (tests widen both nets with a smaller mask: many lanes on the exact path)
-#endif
-#define EP_GUARD_MASK3 ((EP_GUARD_MASK << 2 | 3u) & 0xF8u & (EP_GUARD_MASK | 7u))      // ... low byte 0xFF or 0x00..0x06 (a superset of "at most 3 with a carry")
 #define LRING 16
-struct LeadSink { u16 *ring; u8 *gbuf; int fl; u32 zp; int hit; };     // lead i: ring[i % 16] until flushed (fl leads, a multiple of 8), then ((u16 *)gbuf)[i]; zp: zero-capable bits of the last two leads (bit 0 the last)
-HD u32 lead_zt(u32 lead) { const u32 u = lead + 1u; return ((u & EP_GUARD_MASK) == 0u ? 1u : 0u) | ((u & EP_GUARD_MASK3) == 0u ? 2u : 0u); }      // bit 0: may become a zero byte; bit 1: may become a byte of 3 or less
+// What the flush remembers of a lead: its low byte is 0x00 (o) / 0xFF (f), it carries into the lead before it (c); d: an emitted zero byte.
+// With the carry INTO a byte known — from the lead behind it, or through a run of 0xFF behind it: CI — the byte is zero iff o & !CI | f & CI
+// (| d), and at most 3 only if its low byte is at most 3 or f & CI.  A flush knows the eight leads it takes and the two before them; the
+// carry into its last lead is the only unknown (it comes with the next flush) and is taken as set.  (Tests build with -DEP_GUARD_WIDE: every
+// low byte up to 0x1F counts as zero, which puts many lanes on the exact path.)
+#ifdef IMCVT_HOSTEMU
+HD u32 brev32(u32 x) { u32 r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+#else
+HD u32 brev32(u32 x) { return __builtin_bitreverse32(x); }
+#endif
+#define LH_O 1u
+#define LH_F 2u
+#define LH_C 4u
+#define LH_D 8u
+struct LeadSink { u16 *ring; u8 *gbuf; int fl; u32 hist; int hit; };     // lead i: ring[i % 16] until flushed (fl leads, a multiple of 8), then ((u16 *)gbuf)[i]; hist: the last lead's LH_ bits, << 4 the one before it
+#ifdef EP_GUARD_WIDE
+HD u32 lead_lh(u32 lead) { const u32 v = lead & 0xFFu; return (v < 0x20u ? LH_O : 0u) | (v == 0xFFu ? LH_F : 0u) | (lead >> 8 & 1u) << 2; }
+#else
+HD u32 lead_lh(u32 lead) { const u32 v = lead & 0xFFu; return (v == 0u ? LH_O : 0u) | (v == 0xFFu ? LH_F : 0u) | (lead >> 8 & 1u) << 2; }
+#endif
+#if defined(IMCVT_HOSTEMU) && defined(IMCVT_DBGCNT)
+static long g_dbg[8];      // (test builds: leads flushed, flushes with the pattern, seeds with it, sinks opened)
+#define DBGCNT(i, n) (g_dbg[i] += (n))
+#else
+#define DBGCNT(i, n) ((void)0)
+#endif
 HD void lsink_begin(LeadSink &s, const Arith &a0, u16 *ring, u8 *gbuf) {
     s.ring = ring; s.gbuf = gbuf; s.fl = 0;
-    const u32 zh = a0.zeros >= 2 ? 3u : a0.zeros == 1 ? 1u : 0u;              // emitted zero bytes before the buffered ones
-    const int r = a0.nbytes - 1;                                               // 0xFF bytes buffered behind bufbyte (zero- and small-capable, all of them)
-    const u32 b = lead_zt((u32)a0.bufbyte & 0xFFu), zb = b & 1u, tb = b >> 1;
-    const int hb = (int)(tb & (zh >> 1) & zh) | (r >= 1 ? (int)(zb & zh) : 0) | (r >= 2 ? (int)zb : 0) | (r >= 3);
-    s.hit = a0.nbytes >= 1 ? (hb & 1) : 0;
-    s.zp = a0.nbytes < 1 ? zh : r >= 2 ? 3u : r == 1 ? (1u | zb << 1) : (zb | (zh & 1u) << 1);
+    const u32 d1 = a0.zeros >= 1 ? LH_D : 0u, d2 = a0.zeros >= 2 ? LH_D : 0u;      // emitted zero bytes before the buffered ones
+    const int r = a0.nbytes - 1;                                                   // 0xFF bytes buffered behind bufbyte
+    const u32 vb = (u32)a0.bufbyte & 0xFFu, b = lead_lh(vb);
+    const int hb = (d2 != 0u) & (vb <= 3u || vb == 0xFFu);                         // two zeros emitted and a buffered byte that may come out small
+    if (a0.nbytes < 1) { s.hist = d1 | d2 << 4; s.hit = 0; }
+    else if (r == 0) { s.hist = b | d1 << 4; s.hit = hb; }
+    else if (r == 1) { s.hist = LH_F | b << 4; s.hit = hb | ((d1 != 0u) & ((b & (LH_O | LH_F)) != 0u)); }      // (... or a zero, a buffered byte that may come out zero, and the 0xFF behind it)
+    else { s.hist = LH_F | LH_F << 4; s.hit = 1; }                                 // (a longer run of 0xFF buffered on entry: practically never — the exact path)
+    DBGCNT(2, s.hit); DBGCNT(3, 1);
 }
 HD void lsink_flush8(LeadSink &s, int valid) {           // the ring is only 4-byte aligned (odd dword stride between lanes); `valid` of the 8 leads are real
     const u32a *r = (const u32a *)(s.ring + (s.fl & (LRING - 1)));
     U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
     g_st128(s.gbuf + 2 * s.fl, b); s.fl += 8;
-    u32 z = 0, t = 0;                                    // bit k: lead k of the eight
+    // bit j + 2: lead j of the eight; bits 1, 0: the two leads before them
+    u32 O = (s.hist & LH_O ? 2u : 0u) | (s.hist >> 4 & LH_O ? 1u : 0u), Fm = (s.hist & LH_F ? 2u : 0u) | (s.hist >> 4 & LH_F ? 1u : 0u);
+    u32 Cm = (s.hist & LH_C ? 2u : 0u), D = (s.hist & LH_D ? 2u : 0u) | (s.hist >> 4 & LH_D ? 1u : 0u), S3 = 0;
     const u32 w[4] = { b.x, b.y, b.z, b.w };
-    for (int d = 0; d < 4; d++) {
-        const u32 lo = lead_zt(w[d] & 0xFFFFu), hi = lead_zt(w[d] >> 16);
-        z |= (lo & 1u) << (2 * d) | (hi & 1u) << (2 * d + 1);
-        t |= (lo >> 1) << (2 * d) | (hi >> 1) << (2 * d + 1);
+    u32 lh[8];
+    for (int d = 0; d < 4; d++) { lh[2 * d] = lead_lh(w[d] & 0xFFFFu); lh[2 * d + 1] = lead_lh(w[d] >> 16); }
+    for (int j = 0; j < 8; j++) {
+        const u32 live = j < valid ? 1u : 0u, lead = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xFFFFu;
+        O |= (lh[j] & LH_O ? live : 0u) << (j + 2); Fm |= (lh[j] & LH_F ? live : 0u) << (j + 2); Cm |= (lh[j] & LH_C ? live : 0u) << (j + 2);
+        S3 |= ((lead & 0xFCu) == 0u ? live : 0u) << (j + 2);
     }
-    const u32 live = valid >= 8 ? 0xFFu : (1u << valid) - 1u;
-    z &= live; t &= live;
-    const u32 ze = z << 2 | (s.zp & 1u) << 1 | (s.zp >> 1);               // bit k + 2: lead k; bits 1, 0: the two leads before
-    s.hit |= (t & (ze >> 1) & ze) != 0u;                                  // lead k small-capable, leads k - 1 and k - 2 zero-capable
-    s.zp = (ze >> (valid >= 8 ? 9 : valid + 1) & 1u) | (ze >> (valid >= 8 ? 8 : valid) & 1u) << 1;
+    const int top = (valid >= 8 ? 8 : valid) + 1;         // bit of the last real lead
+    // CO_j = C_j | F_j & CO_{j+1} (CO above the last lead: 1), CI_j = CO_{j+1}: a carry look-ahead, by an addition over the bit-reversed masks
+    const u32 keep = (2u << top) - 1u;
+    const u32 Cr = brev32(Cm & keep) >> (31 - top), Fr = brev32(Fm & keep) >> (31 - top);
+    const u32 A = Cr | Fr, S = A + Cr + 1u;
+    const u32 CI = brev32((S ^ A ^ Cr) << (31 - top)) & keep;
+    const u32 Z = D | (O & ~CI) | (Fm & CI), T = S3 | (Fm & CI);
+    const int hitn = (T & (Z << 1) & (Z << 2) & keep & ~3u) != 0u;      // a lead of this flush that may come out at most 3 behind two bytes that come out zero
+    DBGCNT(0, valid >= 8 ? 8 : valid); DBGCNT(1, hitn);
+    s.hit |= hitn;
+    const u32 l1 = valid >= 8 ? lh[7] : valid >= 1 ? lh[valid - 1] : (s.hist & 15u);
+    const u32 l2 = valid >= 8 ? lh[6] : valid >= 2 ? lh[valid - 2] : valid == 1 ? (s.hist & 15u) : (s.hist >> 4 & 15u);
+    s.hist = l1 | l2 << 4;
 }
 HD void lsink_sync(LeadSink &s, int qn) { NOUNROLL while (qn - s.fl >= 8) lsink_flush8(s, 8); }             // between token blocks: < 8 leads stay pending
 HD void lsink_finish(LeadSink &s, int qn) { NOUNROLL while (qn > s.fl) lsink_flush8(s, qn - s.fl); }       // tail: the leads beyond qn are never read
@@ -2683,28 +2721,18 @@ HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
     for (int k = 0; WAVE_ANY(k < n); k++)
         if (k < n) code_token(a, cx, cs, (u32)p[k]);
 }
-// Byte half when only the LENGTH of the stream is wanted (the pricing of a PU's candidates, :1504-1518: the bytes are never read).  low and
-// the bit position go token by token as in token_L; of the byte-level logic (:863-878, :820-831) only this matters for the length: every
-// lead becomes exactly one byte sooner or later (buffered, part of a run of 0xFF, or emitted), so bytes emitted + bytes buffered = leads
-// taken — unless an emulation-prevention byte was inserted, which takes two emitted zero bytes in a row and then a byte of 3 or less.  An
-// emitted byte is its lead's low byte plus a carry: zero only if the low byte is 0x00 or 0xFF, at most 3 only if it is 0xFF or 0x00..0x03.
-// `zt` keeps those two bits per lead (zero-capable in the low half-word, small-capable in the high one; last lead in bit 0 of each); a lane
-// that ever shows two zero-capable leads and then a small-capable one is priced again by the plain coder (the caller's safe path) — a
-// handful of lanes per frame.
-HD void len_step(Arith &a, int &qn, u32 &zt, int nb_, int v) {
+// Byte half of the pricing of a PU's candidates (:1504-1518) over the lean records of stream_seg_R_lds: low and the bit position token by token,
+// the leads into the lane's lead sink as everywhere (the bytes are never wanted: the sink's count and its guard give the length).
+HD void lead_take(Arith &a, u16 *ring, int &qn, int nb_, int v) {
     a.low = (a.low << nb_) + v;
     a.nbits -= nb_;
     const int need = a.nbits < 12;                                                // :858-862
-    const u32 u = ((u32)a.low >> ((24 - a.nbits) & 31)) + 1u;                     // the lead, plus one
-    const u32 zb = ((u & EP_GUARD_MASK) == 0u ? 1u : 0u) | ((u & EP_GUARD_MASK3) == 0u ? 0x10000u : 0u);
-    zt = need ? ((zt << 1) & 0xFFFEFFFEu) | zb : zt;                              // (15 leads of history per half-word: checked every token block, eight leads at most apart)
+    ring[qn & (LRING - 1)] = (u16)((u32)a.low >> ((24 - a.nbits) & 31));          // always written; only kept when `need`
     qn += need;
     a.nbits += need ? 8 : 0;
     a.low = need ? (i32)((u32)a.low & (0xFFFFFFFFu >> a.nbits)) : a.low;
 }
-HD int ep_guard(u32 zt) { return ((zt >> 16) & (zt >> 1) & (zt >> 2) & 0x3FFFu) != 0u; }       // a small-capable lead right after two zero-capable ones
-HD int arith_len_leads(const Arith &a, int qn) { return 8 * qn + 23 - a.nbits; }      // arith_len with bytes emitted + buffered = qn
-HD void stream_seg_L1(Arith &a, int &qn, u32 &zz, int &slow, SplitQ &q, int lane, int &blk, int n) {
+HD void stream_seg_L1(Arith &a, LeadSink &sink, int &qn, SplitQ &q, int lane, int &blk, int n) {
     const int ql = lane < NMODE ? lane : 0;
     const u32 *const row = q.rec[ql];
     int prod_seen = 0;
@@ -2724,28 +2752,28 @@ HD void stream_seg_L1(Arith &a, int &qn, u32 &zz, int &slow, SplitQ &q, int lane
 #endif
             blk++;
             lds_st_i32(&q.cons[ql], blk);
+            lsink_sync(sink, qn);
             UNROLL_FULL
-            for (int j = 0; j < 8; j++) len_step(a, qn, zz, (int)(rec[j] >> 17), (int)(rec[j] & 0x1FFFFu));      // (token_R_res2's records)
-            slow |= ep_guard(zz);
+            for (int j = 0; j < 8; j++) lead_take(a, sink.ring, qn, (int)(rec[j] >> 17), (int)(rec[j] & 0x1FFFFu));      // (token_R_res2's records)
         }
     }
 }
 // The same over tokens that are ALL bypass chunks (the remaining-level rows a partner makes, pu_part_b): a bypass chunk leaves the range as it
 // is (:898-910), so the range half has nothing to do there — the byte half takes the chunks from the row itself, with the range the first
 // part ended on.  (An idle token is a chunk of no bins.)
-HD void stream_seg_L1_byp(Arith &a, int &qn, u32 &zz, int &slow, const u16 *p, int n, int range) {
+HD void stream_seg_L1_byp(Arith &a, LeadSink &sink, int &qn, const u16 *p, int n, int range) {
     const u32a *pw = (const u32a *)p;
     NOUNROLL
     for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
         if (k0 < n) {
             const u32a *pb = pw + (k0 >> 1);
             U4 cur; cur.x = pb[0]; cur.y = pb[1]; cur.z = pb[2]; cur.w = pb[3];
+            lsink_sync(sink, qn);
             UNROLL_FULL
             for (int j = 0; j < 8; j++) {
                 const u32 tok = tok_of(cur, j);
-                len_step(a, qn, zz, (int)((tok >> 8) & 15u), mul24(range, (int)(tok & 255u)));
+                lead_take(a, sink.ring, qn, (int)((tok >> 8) & 15u), mul24(range, (int)(tok & 255u)));
             }
-            slow |= ep_guard(zz);
         }
     }
 }
@@ -2795,7 +2823,9 @@ HD void trial_finish(Arith &a, const Arith &a0, LeadSink &sink, int qn, int on) 
         a.cnt = a0.cnt + qn; a.nbytes = a0.nbytes; a.bufbyte = a0.bufbyte; a.zeros = a0.zeros;
     }
     const int ex = on & sink.hit;
+    tl_count(66);                                           // (timeline builds: 66 trials finished, 65 of them with lanes on the exact path)
     if (WAVE_ANY(ex)) {
+        tl_count(65);
         drain_stores();                                     // (the list is read back from memory)
         leads_exact(a, a0, sink.gbuf, qn, ex);
     }
@@ -2817,7 +2847,11 @@ HD void resolve_leads(Arith &a, const u8 *list, int n, u8 *dst) {
     const Arith a0 = a;
     const int nb0 = a0.nbytes, m = nb0 + n;                 // digits: nb0 buffered bytes (bufbyte, then 0xFF), then the leads
     const int nch = (m + 63) >> 6;
+#ifdef IMCVT_RESOLVE_SERIAL          // (test builds)
+    int fallback = 1;
+#else
     int fallback = 0;
+#endif
     LANES(l) {
         // pass 1, last round first: carries; the resolved digits go to dst as if all were emitted (the buffered tail is overwritten later or never read)
         u32 cin = 0;

@@ -154,6 +154,7 @@ HD void pu_price(int k) {
     PuX &U = PUX;
     const RdW rw = rd_weights(F.job.q);
     const u32 seq = pu_seq_of(k);
+    u8 *const ubytes = uniform_ptr(F.sc.bytes);
     long long tq = prof_now();
     while ((u32)lds_ld_i32((const i32 *)&U.pu_seq) != seq) pipe_pause();      // (the step's generation has started: q.go is this step's)
     while (lds_ld_i32(&q.go) == lds_ld_i32(&q.done)) pipe_pause();
@@ -163,8 +164,10 @@ HD void pu_price(int k) {
         const int on = l < NMODE, ll = on ? l : 0;
         Arith a; arith_reset(a);
         const int na = on ? U.na[ll] : 0;
-        int blk = 0, qn = 0, slow = 0; u32 zz = 0;
-        stream_seg_L1(a, qn, zz, slow, q, l, blk, na);
+        const Arith a0 = a;
+        LeadSink sink; lsink_begin(sink, a0, (u16 *)X.lm[ll].ring, ubytes + (size_t)(2 * NMODE + ll) * TRIAL_BYTES);
+        int blk = 0, qn = 0;
+        stream_seg_L1(a, sink, qn, q, l, blk, na);
         tl_mark(44 + k);                                 // 44 .. 47: byte half through the first part of PU k
         prof_add_row(2, PF_P2_8, tq); tq = prof_now();
         while ((u32)lds_ld_i32((const i32 *)&U.b_seq) != seq) pipe_pause();
@@ -172,16 +175,11 @@ HD void pu_price(int k) {
         const int nb = on ? U.bcnt[ll] : 0;
         split_await(&q.rdone, q);                                       // the range half is through the first part: the range it ended on (the rest is bypass chunks, which this half takes from the rows itself)
         prof_add_row(2, PF_P2_NXN, tq); tq = prof_now();
-        stream_seg_L1_byp(a, qn, zz, slow, U.brow[ll], nb, on ? q.range_out[ll] : 510);
+        stream_seg_L1_byp(a, sink, qn, U.brow[ll], nb, on ? q.range_out[ll] : 510);
         tl_mark(48 + k);                                 // 48 .. 51: ... and through its rows
         prof_add_row(2, PF_P1_16, tq); tq = prof_now();
-        int len = arith_len_leads(a, qn);                               // (the bytes themselves are never read, :1518)
-        if (WAVE_ANY(slow)) {                                           // two leads in a row that may have become zero bytes — an emulation-prevention byte may follow: that lane again, by the plain coder on a scratch copy of the fresh contexts
-            if (slow) { arith_reset(a); ctx_copy(X.cx[ll], SM.cx0); }
-            stream_seg_safe_lds(a, X.cx[ll], lane_row(W, ll) + 8, slow ? na : 0);
-            stream_seg_safe_lds(a, X.cx[ll], U.brow[ll], slow ? nb : 0);
-            if (slow) len = arith_len(a);
-        }
+        trial_finish(a, a0, sink, qn, on);                              // (the bytes themselves are never read, :1518)
+        const int len = arith_len(a);
         if (k == 1) tl_mark(58);                         // 58: PU 1: guard checked
         while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // SSE and reconstructions of this PU's candidates are in place (long since)
         wave_sync_lds();

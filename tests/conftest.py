@@ -96,9 +96,15 @@ def hostemu_wide_ovf(built):
 
 @pytest.fixture(scope="session")
 def hostemu_wide_ep(built):
-    """Wide workgroups with a wide net for the emulation-prevention guard of the PU pricing (low bytes 0xFF and 0x00..0x1E count as possible zero
-    bytes): many PU candidates are priced a second time, on the safe path."""
-    return _hostemu_lib("libhostemu_wide_ep.so", ["-DEMU_DEFAULT_WIDE", "-DEP_GUARD_MASK=0xE0u"])
+    """Wide workgroups with a wide net for the trial coders' emulation-prevention guard (low bytes up to 0x1F count as zero bytes): many
+    candidates get their byte count on the exact path (hevc_core.h leads_exact)."""
+    return _hostemu_lib("libhostemu_wide_ep.so", ["-DEMU_DEFAULT_WIDE", "-DEP_GUARD_WIDE"])
+
+
+@pytest.fixture(scope="session")
+def hostemu_ep(built):
+    """192-thread workgroups with the wide net for the emulation-prevention guard, and the winner's leads turned into bytes by lane 0's walk."""
+    return _hostemu_lib("libhostemu_ep.so", ["-DEP_GUARD_WIDE", "-DIMCVT_RESOLVE_SERIAL"])
 
 
 @pytest.fixture(scope="session")

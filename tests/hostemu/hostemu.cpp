@@ -228,6 +228,9 @@ extern "C" long hostemu_mfma_calls(int kind) { return g_mfma_calls[kind & 1]; }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
 extern "C" int hostemu_pipe_lds_bytes(void) { return (int)PIPE_LDS_BYTES; }
 
+#ifdef IMCVT_DBGCNT
+extern "C" void hostemu_dbg(long *o) { for (int i = 0; i < 8; i++) o[i] = g_dbg[i]; }
+#endif
 // The device's resolve_leads (hevc_core.h) on one emulated wavefront: leads -> bytes at dst[st[3] ..), byte-level state in / out in st = { nbytes, bufbyte, zeros, cnt }
 static struct { const unsigned char *list; int n; Arith a; unsigned char *dst; } g_rl;
 static void emu_entry_resolve() { Arith a = g_rl.a; resolve_leads(a, g_rl.list, g_rl.n, g_rl.dst); if (emu_lane() == 0) g_rl.a = a; }

@@ -29,6 +29,7 @@ for k in range(4):
 names[56] = "PU 1: step begins"; names[57] = "PU 1: borders made"; names[58] = "PU 1: pricing: guard checked"; names[59] = "PU 1: pricing: reconstructions seen"; names[60] = "PU 1: pricing: costs stored"; names[61] = "PU 1: mode picked"
 names[62] = "PU 1: predicted"; names[63] = "PU 1: transformed"; names[64] = "PU 1: quantised"
 names[40] = "wave 0: first pass item done"; names[41] = "wave 0: second pass item done"; names[42] = "one-TU set: tokens complete"
+print(f"trials finished {flat[66]}, with lanes on the exact path {flat[65]}")
 print(f"1 x {w}x{h} q{q}: kernel {ms:.1f} ms, wide {enc.last_wide()}, {n} 8x8 CUs; average cycles since the CU was entered:")
 for ev, t in sorted(((ev, flat[ev] / max(n, 1)) for ev in names if flat[ev]), key=lambda x: x[1]):
     print(f"  {t:9.0f}  {names[ev]}")
