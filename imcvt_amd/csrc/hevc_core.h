@@ -637,26 +637,28 @@ HD int sink_room(CountSinkT &, int) { return 1; }
 //   entry count as leads: lsink_begin); a lane that shows it gets its byte-level state by the real logic over its list (leads_exact) —
 //   a few lanes per frame.  The winner's list is turned into bytes once, by a whole wavefront (resolve_leads).
 #define LRING 16
-// What the flush remembers of a lead: its low byte is 0x00 (o) / 0xFF (f), it carries into the lead before it (c); d: an emitted zero byte.
-// With the carry INTO a byte known — from the lead behind it, or through a run of 0xFF behind it: CI — the byte is zero iff o & !CI | f & CI
-// (| d), and at most 3 only if its low byte is at most 3 or f & CI.  A flush knows the eight leads it takes and the two before them; the
-// carry into its last lead is the only unknown (it comes with the next flush) and is taken as set.  (Tests build with -DEP_GUARD_WIDE: every
-// low byte up to 0x1F counts as zero, which puts many lanes on the exact path.)
 #ifdef IMCVT_HOSTEMU
 HD u32 brev32(u32 x) { u32 r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+HD u32 lperm(u32 hi, u32 lo, u32 sel) { const u64 v = (u64)hi << 32 | lo; u32 r = 0; for (int k = 0; k < 4; k++) r |= (u32)((v >> (8 * ((sel >> (8 * k)) & 7))) & 255) << (8 * k); return r; }
+HD u32 udot4(u32 a, u32 b, u32 c) { for (int k = 0; k < 4; k++) c += ((a >> (8 * k)) & 255u) * ((b >> (8 * k)) & 255u); return c; }
 #else
 HD u32 brev32(u32 x) { return __builtin_bitreverse32(x); }
+HD u32 lperm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+HD u32 udot4(u32 a, u32 b, u32 c) { return __builtin_amdgcn_udot4(a, b, c, false); }      // v_dot4_u32_u8: four byte products and an addend
 #endif
-#define LH_O 1u
-#define LH_F 2u
-#define LH_C 4u
-#define LH_D 8u
-struct LeadSink { u16 *ring; u8 *gbuf; int fl; u32 hist; int hit; };     // lead i: ring[i % 16] until flushed (fl leads, a multiple of 8), then ((u16 *)gbuf)[i]; hist: the last lead's LH_ bits, << 4 the one before it
+// What the flush looks at in a lead: its low byte is 0x00 (O) / 0xFF (F) / at most 3 (S), it carries into the lead before it (C); D: an emitted
+// zero byte.  With the carry INTO a byte known — from the lead behind it, or through a run of 0xFF behind it: CI — the byte is zero iff
+// O & !CI | F & CI (| D), and at most 3 only if S or F & CI.  A flush knows the eight leads it takes and the two before them; the carry into
+// its last lead is the only unknown (it comes with the next flush) and is taken as set.  (Tests build with -DEP_GUARD_WIDE: every low byte up
+// to 0x1F counts as zero, which puts many lanes on the exact path.)
+struct LeadSink { u16 *ring; u8 *gbuf; int fl; u32 hist; int hit; };     // lead i: ring[i % 16] until flushed (fl leads, a multiple of 8), then ((u16 *)gbuf)[i]; hist: O | F << 2 | C << 4 | D << 6 of the last two leads (bit 1 of a field: the last, bit 0: the one before it)
 #ifdef EP_GUARD_WIDE
-HD u32 lead_lh(u32 lead) { const u32 v = lead & 0xFFu; return (v < 0x20u ? LH_O : 0u) | (v == 0xFFu ? LH_F : 0u) | (lead >> 8 & 1u) << 2; }
+#define LEAD_O_MASK 0xE0E0E0E0u
 #else
-HD u32 lead_lh(u32 lead) { const u32 v = lead & 0xFFu; return (v == 0u ? LH_O : 0u) | (v == 0xFFu ? LH_F : 0u) | (lead >> 8 & 1u) << 2; }
+#define LEAD_O_MASK 0xFFFFFFFFu
 #endif
+HD u32 bytes_nz(u32 v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) >> 7 & 0x01010101u; }      // byte k: 1 if byte k of v is not zero
+HD u32 bytes_mask8(u32 f0, u32 f1) { return udot4(f1, 0x80402010u, udot4(f0, 0x08040201u, 0u)); }  // eight 0 / 1 bytes -> eight bits (byte k of f0: bit k, of f1: bit 4 + k)
 #if defined(IMCVT_HOSTEMU) && defined(IMCVT_DBGCNT)
 static long g_dbg[8];      // (test builds: leads flushed, flushes with the pattern, seeds with it, sinks opened)
 #define DBGCNT(i, n) (g_dbg[i] += (n))
@@ -665,44 +667,36 @@ static long g_dbg[8];      // (test builds: leads flushed, flushes with the patt
 #endif
 HD void lsink_begin(LeadSink &s, const Arith &a0, u16 *ring, u8 *gbuf) {
     s.ring = ring; s.gbuf = gbuf; s.fl = 0;
-    const u32 d1 = a0.zeros >= 1 ? LH_D : 0u, d2 = a0.zeros >= 2 ? LH_D : 0u;      // emitted zero bytes before the buffered ones
+    const u32 d1 = a0.zeros >= 1, d2 = a0.zeros >= 2;                              // emitted zero bytes before the buffered ones
     const int r = a0.nbytes - 1;                                                   // 0xFF bytes buffered behind bufbyte
-    const u32 vb = (u32)a0.bufbyte & 0xFFu, b = lead_lh(vb);
-    const int hb = (d2 != 0u) & (vb <= 3u || vb == 0xFFu);                         // two zeros emitted and a buffered byte that may come out small
-    if (a0.nbytes < 1) { s.hist = d1 | d2 << 4; s.hit = 0; }
-    else if (r == 0) { s.hist = b | d1 << 4; s.hit = hb; }
-    else if (r == 1) { s.hist = LH_F | b << 4; s.hit = hb | ((d1 != 0u) & ((b & (LH_O | LH_F)) != 0u)); }      // (... or a zero, a buffered byte that may come out zero, and the 0xFF behind it)
-    else { s.hist = LH_F | LH_F << 4; s.hit = 1; }                                 // (a longer run of 0xFF buffered on entry: practically never — the exact path)
+    const u32 vb = (u32)a0.bufbyte & 0xFFu, bo = (vb & (LEAD_O_MASK & 0xFFu)) == 0u, bf = vb == 0xFFu;
+    const int hb = (int)d2 & (vb <= 3u || bf);                                     // two zeros emitted and a buffered byte that may come out small
+    if (a0.nbytes < 1) { s.hist = (d1 << 1 | d2) << 6; s.hit = 0; }
+    else if (r == 0) { s.hist = bo << 1 | bf << 3 | d1 << 6; s.hit = hb; }
+    else if (r == 1) { s.hist = bo | (2u | bf) << 2; s.hit = hb | (int)(d1 & (bo | bf)); }      // (... or a zero, a buffered byte that may come out zero, and the 0xFF behind it)
+    else { s.hist = 3u << 2; s.hit = 1; }                                          // (a longer run of 0xFF buffered on entry: practically never — the exact path)
     DBGCNT(2, s.hit); DBGCNT(3, 1);
 }
 HD void lsink_flush8(LeadSink &s, int valid) {           // the ring is only 4-byte aligned (odd dword stride between lanes); `valid` of the 8 leads are real
     const u32a *r = (const u32a *)(s.ring + (s.fl & (LRING - 1)));
     U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
     g_st128(s.gbuf + 2 * s.fl, b); s.fl += 8;
-    // bit j + 2: lead j of the eight; bits 1, 0: the two leads before them
-    u32 O = (s.hist & LH_O ? 2u : 0u) | (s.hist >> 4 & LH_O ? 1u : 0u), Fm = (s.hist & LH_F ? 2u : 0u) | (s.hist >> 4 & LH_F ? 1u : 0u);
-    u32 Cm = (s.hist & LH_C ? 2u : 0u), D = (s.hist & LH_D ? 2u : 0u) | (s.hist >> 4 & LH_D ? 1u : 0u), S3 = 0;
-    const u32 w[4] = { b.x, b.y, b.z, b.w };
-    u32 lh[8];
-    for (int d = 0; d < 4; d++) { lh[2 * d] = lead_lh(w[d] & 0xFFFFu); lh[2 * d + 1] = lead_lh(w[d] >> 16); }
-    for (int j = 0; j < 8; j++) {
-        const u32 live = j < valid ? 1u : 0u, lead = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xFFFFu;
-        O |= (lh[j] & LH_O ? live : 0u) << (j + 2); Fm |= (lh[j] & LH_F ? live : 0u) << (j + 2); Cm |= (lh[j] & LH_C ? live : 0u) << (j + 2);
-        S3 |= ((lead & 0xFCu) == 0u ? live : 0u) << (j + 2);
-    }
-    const int top = (valid >= 8 ? 8 : valid) + 1;         // bit of the last real lead
+    // the eight low bytes as two dwords, the eight carry bits as two more; then one 8-bit mask per predicate (bit j: lead j)
+    const u32 L0 = lperm(b.y, b.x, 0x06040200u), L1 = lperm(b.w, b.z, 0x06040200u), H0 = lperm(b.y, b.x, 0x07050301u), H1 = lperm(b.w, b.z, 0x07050301u);
+    const int top = (valid >= 8 ? 8 : valid) + 1;         // bit of the last real lead once the two leads before the eight sit in bits 1, 0
+    const u32 keep = (2u << top) - 1u, live8 = keep >> 2;
+    const u32 O8 = ~bytes_mask8(bytes_nz(L0 & LEAD_O_MASK), bytes_nz(L1 & LEAD_O_MASK)) & live8, F8 = ~bytes_mask8(bytes_nz(~L0), bytes_nz(~L1)) & live8;
+    const u32 S8 = ~bytes_mask8(bytes_nz(L0 & 0xFCFCFCFCu), bytes_nz(L1 & 0xFCFCFCFCu)) & live8, C8 = bytes_mask8(H0 & 0x01010101u, H1 & 0x01010101u) & live8;
+    const u32 O = O8 << 2 | (s.hist & 3u), Fm = F8 << 2 | (s.hist >> 2 & 3u), Cm = C8 << 2 | (s.hist >> 4 & 3u), D = s.hist >> 6 & 3u, S3 = S8 << 2;
     // CO_j = C_j | F_j & CO_{j+1} (CO above the last lead: 1), CI_j = CO_{j+1}: a carry look-ahead, by an addition over the bit-reversed masks
-    const u32 keep = (2u << top) - 1u;
-    const u32 Cr = brev32(Cm & keep) >> (31 - top), Fr = brev32(Fm & keep) >> (31 - top);
+    const u32 Cr = brev32(Cm) >> (31 - top), Fr = brev32(Fm) >> (31 - top);
     const u32 A = Cr | Fr, S = A + Cr + 1u;
     const u32 CI = brev32((S ^ A ^ Cr) << (31 - top)) & keep;
     const u32 Z = D | (O & ~CI) | (Fm & CI), T = S3 | (Fm & CI);
     const int hitn = (T & (Z << 1) & (Z << 2) & keep & ~3u) != 0u;      // a lead of this flush that may come out at most 3 behind two bytes that come out zero
     DBGCNT(0, valid >= 8 ? 8 : valid); DBGCNT(1, hitn);
     s.hit |= hitn;
-    const u32 l1 = valid >= 8 ? lh[7] : valid >= 1 ? lh[valid - 1] : (s.hist & 15u);
-    const u32 l2 = valid >= 8 ? lh[6] : valid >= 2 ? lh[valid - 2] : valid == 1 ? (s.hist & 15u) : (s.hist >> 4 & 15u);
-    s.hist = l1 | l2 << 4;
+    s.hist = (O >> (top - 1) & 3u) | (Fm >> (top - 1) & 3u) << 2 | (Cm >> (top - 1) & 3u) << 4 | (D >> (top - 1) & 3u) << 6;
 }
 HD void lsink_sync(LeadSink &s, int qn) { NOUNROLL while (qn - s.fl >= 8) lsink_flush8(s, 8); }             // between token blocks: < 8 leads stay pending
 HD void lsink_finish(LeadSink &s, int qn) { NOUNROLL while (qn > s.fl) lsink_flush8(s, qn - s.fl); }       // tail: the leads beyond qn are never read

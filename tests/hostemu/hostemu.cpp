@@ -228,6 +228,22 @@ extern "C" long hostemu_mfma_calls(int kind) { return g_mfma_calls[kind & 1]; }
 extern "C" int hostemu_shm_bytes(void) { return (int)sizeof(Shm); }
 extern "C" int hostemu_pipe_lds_bytes(void) { return (int)PIPE_LDS_BYTES; }
 
+// The device's lead sink (hevc_core.h lsink_begin / lsink_flush8) fed a list of leads the way a trial coder feeds it (ring of 16, a flush per
+// eight leads, the rest at the end); returns its `hit` flag.  st = { nbytes, bufbyte, zeros } of the entry state.
+extern "C" int hostemu_lsink_guard(const unsigned short *leads, int n, const int *st) {
+    static unsigned char gbuf[TRIAL_BYTES];
+    alignas(4) unsigned short ring[LRING];
+    Arith a; arith_reset(a); a.nbytes = st[0]; a.bufbyte = st[1]; a.zeros = st[2];
+    LeadSink s; lsink_begin(s, a, ring, gbuf);
+    int qn = 0;
+    for (int i = 0; i < n; i++) {
+        if ((i & 7) == 0) lsink_sync(s, qn);                 // (as between token blocks: at most eight leads join between two syncs)
+        ring[qn & (LRING - 1)] = leads[i]; qn++;
+    }
+    lsink_finish(s, qn);
+    for (int i = 0; i < n; i++) if (((unsigned short *)gbuf)[i] != leads[i]) return -1;      // (the list in memory is the list)
+    return s.hit;
+}
 #ifdef IMCVT_DBGCNT
 extern "C" void hostemu_dbg(long *o) { for (int i = 0; i < 8; i++) o[i] = g_dbg[i]; }
 #endif

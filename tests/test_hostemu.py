@@ -397,12 +397,15 @@ def test_winner_leads_to_bytes_matches_the_byte_level_logic(hostemu):
     assert ep_runs > 20                                     # emulation prevention did strike in some of them (lane 0's walk)
 
 
-def test_lead_sink_guard_no_hit_means_bytes_equal_leads():
+def test_lead_sink_guard_no_hit_means_bytes_equal_leads(hostemu):
     """hevc_core.h lsink_begin / lsink_flush8: a trial's byte count is taken as its lead count unless the flushes see a lead that may come out
     at most 3 behind two bytes that come out zero (local carry look-ahead, the carry into a flush's last lead taken as set).  A model of that
     guard against the byte-level logic: whenever it stays quiet, emitted + buffered bytes have grown by exactly the number of leads."""
     import random
     rng = random.Random(7)
+    lib = hostemu
+    lib.hostemu_lsink_guard.restype = C.c_int
+    lib.hostemu_lsink_guard.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.POINTER(C.c_int)]
     O, Fb, Cb, D = 1, 2, 4, 8
 
     def lh(lead):
@@ -467,7 +470,10 @@ def test_lead_sink_guard_no_hit_means_bytes_equal_leads():
         out = np.zeros(200, np.uint8)
         nb, _, _, cnt = _byte_logic(leads, st[0], st[1], st[2], st[3], out)
         grown = nb + cnt - st[0] - st[3]
-        if guard(leads, st[0], st[1], st[2]):
+        arr = (C.c_ushort * len(leads))(*leads)
+        dev = lib.hostemu_lsink_guard(arr, len(leads), (C.c_int * 3)(st[0], st[1], st[2]))
+        assert dev == guard(leads, st[0], st[1], st[2]), (st, leads)      # the device source's sink and the model agree
+        if dev:
             fired += 1; inserted += grown != len(leads)
         else:
             quiet += 1
