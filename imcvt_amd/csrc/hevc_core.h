@@ -273,17 +273,11 @@ HD Arith unpack_arith(const FinState &f) {
     a.bufbyte = (i32)(f.w1 >> 18); a.nbytes = (i32)(f.w2 & 0xFFFF); a.cnt = (i32)(f.w2 >> 16); return a;
 }
 
-#ifndef RING_BYTES
-#define RING_BYTES 32      // per-lane byte ring of the trial coders (RingSink)
-#endif
-#ifndef DRAIN_REGS
-#define DRAIN_REGS 1
-#endif
-#define LEADQ 10           // per-lane queue of byte leads: at most one per token of an 8-token block, plus the slot the idle write lands in
-struct LaneMem { u8 ring[RING_BYTES]; u16 lq[LEADQ]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
+#define LRING 16           // per-lane ring of byte leads of the trial coders (LeadSink): at most 8 leads join between two flushes of 8
+struct LaneMem { u16 ring[LRING]; u16 pad_[10]; };   // 52 bytes = 13 dwords: odd stride, lanes hit different LDS banks
 #define LSTRIDE_DW 33       // dwords per lane row of the lane-private token staging (LSTRIDE below)
 #define P1_RES_BYTES 2304   // 16 tiles of 8x8 + 4 or 4 tiles of 16x16 + 16 i16 (padded against LDS bank conflicts), 16-byte multiple
-#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (RING_BYTES + 2 * LEADQ) + 15) & ~15))      // p2's extent
+#define W2_PAD (((NMODE * CTX_STRIDE + 15) & ~15) + ((NMODE * (int)sizeof(LaneMem) + 15) & ~15))      // p2's extent
 struct alignas(16) WaveMem {
     Border  bsh;                 // border shared by all modes of a block
     i32 tokn[NMODE + 1];         // tokens written so far to each candidate's stream (slot NMODE: the NxN stream)
@@ -297,7 +291,7 @@ struct alignas(16) WaveMem {
     union alignas(16) {          // MUST stay last: the 4x4-only wave's slice is truncated after `w2`
         struct { i16 res[P1_RES_BYTES / 2]; i32 tmp[(7168 - P1_RES_BYTES) / 4]; } p1;                    // one pipeline pass: residual / dequantised tiles, stage outputs (tile strides: p1_run_t)
         u32 raw[1792];                                                                                // per-lane token staging (4x4 blocks, CU headers): lane l at raw + 33 l
-        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, byte rings + lead queues
+        struct { u8 cx[NMODE][CTX_STRIDE]; alignas(16) LaneMem lm[NMODE]; } p2;                          // trial coders: context copies, lead rings
         struct { u8 pad_[W2_PAD]; u8 rec4[NMODE][16]; } w2;                                             // 4x4 PU candidates' reconstructions (beside p2)
     } u;
 };
@@ -502,7 +496,7 @@ struct alignas(16) SplitQ {
 };
 struct alignas(16) PartnerMem {
     SplitQ q;
-    alignas(16) LaneMem lm[NMODE];               // byte rings + lead queues of the byte half
+    alignas(16) LaneMem lm[NMODE];               // lead rings of the byte half
     alignas(4) u8 cx[NMODE][CTX_STRIDE];         // context scratch of its safe path (ring overflow)
 };
 // Control words of a wide workgroup's 8x8 CUs, and the LDS slices of the two partner wavefronts that LEND themselves for pipeline passes
@@ -623,10 +617,8 @@ HD void wg_sync_p() { const long long t = prof_now(); wg_sync(); prof_add(PF_SYN
 //              pending 0xFF bytes resolving at once) raises `ovf`; the caller then repeats the trial on the safe path.
 struct Sink { u8 *base; u32 off; };          // byte i of the lane's run lives at base[off + i]; base is wave-uniform
 HD void sink_put(Sink &s, int i, int v) { g_st8(s.base + (u32)(s.off + (u32)i), v); }
-HD int sink_room(Sink &, int) { return 1; }
 struct CountSinkT { int dummy; };             // bytes are counted (a.cnt), not kept
 HD void sink_put(CountSinkT &, int, int) {}
-HD int sink_room(CountSinkT &, int) { return 1; }
 // LeadSink — the trial coders.  A trial's BYTES are wanted only if it wins; its cost needs their NUMBER.  So a trial coder does not run the
 //   byte-level logic (:863-878, :820-831: carry into the buffered byte, runs of 0xFF, emulation prevention) at all: it leaves the 9-bit lead
 //   (carry + byte) of every byte that leaves `low` (:858-862) in a 16-entry LDS ring per lane, flushed as aligned 16-byte global stores
@@ -636,7 +628,6 @@ HD int sink_room(CountSinkT &, int) { return 1; }
 //   with low byte 0x00 / 0xFF and then one with 0xFF / 0x00..0x03.  The flush looks for that pattern (`hit`; the bytes still buffered on
 //   entry count as leads: lsink_begin); a lane that shows it gets its byte-level state by the real logic over its list (leads_exact) —
 //   a few lanes per frame.  The winner's list is turned into bytes once, by a whole wavefront (resolve_leads).
-#define LRING 16
 #ifdef IMCVT_HOSTEMU
 HD u32 brev32(u32 x) { u32 r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
 HD u32 lperm(u32 hi, u32 lo, u32 sel) { const u64 v = (u64)hi << 32 | lo; u32 r = 0; for (int k = 0; k < 4; k++) r |= (u32)((v >> (8 * ((sel >> (8 * k)) & 7))) & 255) << (8 * k); return r; }
@@ -675,6 +666,9 @@ HD void lsink_begin(LeadSink &s, const Arith &a0, u16 *ring, u8 *gbuf) {
     else if (r == 0) { s.hist = bo << 1 | bf << 3 | d1 << 6; s.hit = hb; }
     else if (r == 1) { s.hist = bo | (2u | bf) << 2; s.hit = hb | (int)(d1 & (bo | bf)); }      // (... or a zero, a buffered byte that may come out zero, and the 0xFF behind it)
     else { s.hist = 3u << 2; s.hit = 1; }                                          // (a longer run of 0xFF buffered on entry: practically never — the exact path)
+#ifdef IMCVT_FORCE_OVF          // (test builds: every lane takes the exact path)
+    s.hit = 1;
+#endif
     DBGCNT(2, s.hit); DBGCNT(3, 1);
 }
 HD void lsink_flush8(LeadSink &s, int valid) {           // the ring is only 4-byte aligned (odd dword stride between lanes); `valid` of the 8 leads are real
@@ -703,8 +697,8 @@ HD void lsink_finish(LeadSink &s, int qn) { NOUNROLL while (qn > s.fl) lsink_flu
 template <class S>
 HD void emit_byte(Arith &a, S &sink, int v) {                                                     // :820-831
     v &= 0xFF;
-    if (a.zeros >= 2 && v <= 3) { if (sink_room(sink, a.cnt)) sink_put(sink, a.cnt, 3); a.cnt++; a.zeros = 0; }
-    if (sink_room(sink, a.cnt)) sink_put(sink, a.cnt, v);
+    if (a.zeros >= 2 && v <= 3) { sink_put(sink, a.cnt, 3); a.cnt++; a.zeros = 0; }
+    sink_put(sink, a.cnt, v);
     a.cnt++;
     a.zeros = v ? 0 : a.zeros + 1;
 }
@@ -2708,13 +2702,6 @@ HD void stream_seg_R_lds(int &range, SplitQ &q, int lane, int &blk, const u16 *p
         cur = nxt;
     }
 }
-// the plain coder over tokens in LDS, bytes counted only (the safe path of a PU candidate whose lead list overflowed)
-HD void stream_seg_safe_lds(Arith &a, u8 *cx, const u16 *p, int n) {
-    CountSinkT cs; cs.dummy = 0;
-    NOUNROLL
-    for (int k = 0; WAVE_ANY(k < n); k++)
-        if (k < n) code_token(a, cx, cs, (u32)p[k]);
-}
 // Byte half of the pricing of a PU's candidates (:1504-1518) over the lean records of stream_seg_R_lds: low and the bit position token by token,
 // the leads into the lane's lead sink as everywhere (the bytes are never wanted: the sink's count and its guard give the length).
 HD void lead_take(Arith &a, u16 *ring, int &qn, int nb_, int v) {
@@ -2841,7 +2828,7 @@ HD void resolve_leads(Arith &a, const u8 *list, int n, u8 *dst) {
     const Arith a0 = a;
     const int nb0 = a0.nbytes, m = nb0 + n;                 // digits: nb0 buffered bytes (bufbyte, then 0xFF), then the leads
     const int nch = (m + 63) >> 6;
-#ifdef IMCVT_RESOLVE_SERIAL          // (test builds)
+#if defined(IMCVT_RESOLVE_SERIAL) || defined(IMCVT_FORCE_OVF)          // (test builds: lane 0 walks every winner's list)
     int fallback = 1;
 #else
     int fallback = 0;
@@ -2906,22 +2893,12 @@ HD void resolve_leads(Arith &a, const u8 *list, int n, u8 *dst) {
 template <bool RES = false>
 HD void stream_run(Arith &a, u8 *cx, LaneMem *lm, u8 *gbuf, const u16 *p, int n, int on) {
     const Arith a0 = a;
-    LeadSink sink; lsink_begin(sink, a0, (u16 *)lm->ring, gbuf);
+    LeadSink sink; lsink_begin(sink, a0, lm->ring, gbuf);
     int qn = 0;
     stream_seg_t<RES>(a, cx, sink, qn, p, n);
     const long long tx3 = prof_now();
     trial_finish(a, a0, sink, qn, on);
     prof_add(PF_X3, tx3);
-}
-// the same on the safe path: bytes go straight to memory, one token load per step
-HD void stream_seg_safe(Arith &a, u8 *cx, Sink &sink, const u16 *p, int n) {
-    NOUNROLL
-    for (int k = 0; WAVE_ANY(k < n); k++)
-        if (k < n) code_token(a, cx, sink, (u32)(u16)g_ld16((const i16 *)(p + k)));
-}
-HD void stream_run_safe(Arith &a, u8 *cx, u8 *gbuf, const u16 *p, int n) {
-    Sink sink; sink.base = gbuf; sink.off = (u32)(0 - a.cnt);
-    stream_seg_safe(a, cx, sink, p, n);
 }
 // One trial: contexts copied from cx_src, coder state `a` in/out.  Wave collective (`on` = this lane has a stream).
 #ifdef IMCVT_TOKSTAT
@@ -2965,7 +2942,6 @@ HD void run_trial_r(Arith &a, const u8 *cx_fresh, u8 *cx, LaneMem *lm, u8 *gbuf,
 #endif
 struct UniSink { u8 *base; u32 off; int st; };            // as Sink; st: this lane performs the stores
 HD void sink_put(UniSink &s, int i, int v) { if (s.st) g_st8(s.base + (u32)(s.off + (u32)i), v); }
-HD int sink_room(UniSink &, int) { return 1; }
 HD void code_token_uni(Arith &a, u8 *cx, UniSink &sink, u32 tok) {
     if (tok & 0x8000u) {                                                            // bypass chunk, :898-910
         const int nb_ = (int)((tok >> 8) & 15u);

@@ -122,7 +122,7 @@ HDN void partner_trial(int own_, int depth_) {
         const Arith a0 = a;
         const int len0 = arith_len(a), n = on ? W.tokn[ll] : 0;
         u8 *gbuf = ubytes + (size_t)(own * NMODE + ll) * TRIAL_BYTES;
-        LeadSink sink; lsink_begin(sink, a0, (u16 *)X.lm[ll].ring, gbuf);
+        LeadSink sink; lsink_begin(sink, a0, X.lm[ll].ring, gbuf);
         int blk = 0, qn = 0;
         stream_seg_L(a, sink, qn, q, l, blk, n);
         trial_finish(a, a0, sink, qn, on);
@@ -165,7 +165,7 @@ HD void pu_price(int k) {
         Arith a; arith_reset(a);
         const int na = on ? U.na[ll] : 0;
         const Arith a0 = a;
-        LeadSink sink; lsink_begin(sink, a0, (u16 *)X.lm[ll].ring, ubytes + (size_t)(2 * NMODE + ll) * TRIAL_BYTES);
+        LeadSink sink; lsink_begin(sink, a0, X.lm[ll].ring, ubytes + (size_t)(2 * NMODE + ll) * TRIAL_BYTES);
         int blk = 0, qn = 0;
         stream_seg_L1(a, sink, qn, q, l, blk, na);
         tl_mark(44 + k);                                 // 44 .. 47: byte half through the first part of PU k
@@ -281,7 +281,7 @@ HDN void partner_fourtu(int depth_) {
         const u16 *ts = tok + (size_t)ll * TOK_CAP;
         if (on) ctx_copy(cx, SM.entry_cx[depth]);
         const Arith a0 = a;
-        LeadSink sink; lsink_begin(sink, a0, (u16 *)lm->ring, gbuf);
+        LeadSink sink; lsink_begin(sink, a0, lm->ring, gbuf);
         int from = 0, qn = 0;
         for (int k = 0; k < 3; k++) {
             while (lds_ld_i32(&C.b_seg) - base <= k) pipe_pause();
@@ -785,7 +785,7 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
         const int len0 = arith_len(a);
         if (on) for (int i = 0; i < CTX_STRIDE; i += 4) *(u32a *)(cx + i) = *(const u32a *)(SM.entry_cx[2] + i);
         const Arith a0 = a;
-        LeadSink sink; lsink_begin(sink, a0, (u16 *)lm->ring, gbuf);
+        LeadSink sink; lsink_begin(sink, a0, lm->ring, gbuf);
         int qn = 0;
         stream_seg(a, cx, sink, qn, hdr, on ? nh : 0);
         const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
@@ -827,7 +827,7 @@ HDN void partner_pipe() {
         Arith a = SM.entry_a[2];
         const int len0 = arith_len(a);
         const Arith a0 = a;
-        LeadSink sink; lsink_begin(sink, a0, (u16 *)X.lm[ll].ring, gbuf);
+        LeadSink sink; lsink_begin(sink, a0, X.lm[ll].ring, gbuf);
         int blk = 0, qn = 0;
         stream_seg_L(a, sink, qn, q, l, blk, on ? nh : 0);
         const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];

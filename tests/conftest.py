@@ -46,7 +46,8 @@ def hostemu(built):
 
 @pytest.fixture(scope="session")
 def hostemu_ovf(built):
-    """Same, built so that every rare-path byte of a trial coder overflows its ring: exercises the safe re-run path."""
+    """Same, built so that every trial coder's lead sink reports the emulation-prevention pattern and every winner's leads are turned into bytes by
+    lane 0's walk (-DIMCVT_FORCE_OVF): the exact paths of hevc_core.h leads_exact / resolve_leads on every candidate."""
     return _hostemu_lib("libhostemu_ovf.so", ["-DIMCVT_FORCE_OVF"])
 
 
@@ -77,7 +78,7 @@ def hostemu_pipe(built):
 
 @pytest.fixture(scope="session")
 def hostemu_pipe_ovf(built):
-    """Pipe wave + every rare-path byte overflows the trial coders' rings: the pipe wave's safe-path repeat of its stream."""
+    """Pipe wave + the exact paths of the lead sinks on every candidate (the pipe wave's three-segment stream included)."""
     return _hostemu_lib("libhostemu_pipe_ovf.so", ["-DEMU_DEFAULT_PIPE", "-DIMCVT_FORCE_OVF"])
 
 
@@ -90,7 +91,7 @@ def hostemu_wide(built):
 
 @pytest.fixture(scope="session")
 def hostemu_wide_ovf(built):
-    """Wide workgroups + every rare-path byte overflows the byte rings: the partners' safe-path repeats."""
+    """Wide workgroups + the exact paths of the lead sinks on every candidate (the partners' byte halves, PU pricing)."""
     return _hostemu_lib("libhostemu_wide_ovf.so", ["-DEMU_DEFAULT_WIDE", "-DIMCVT_FORCE_OVF"])
 
 
@@ -99,12 +100,6 @@ def hostemu_wide_ep(built):
     """Wide workgroups with a wide net for the trial coders' emulation-prevention guard (low bytes up to 0x1F count as zero bytes): many
     candidates get their byte count on the exact path (hevc_core.h leads_exact)."""
     return _hostemu_lib("libhostemu_wide_ep.so", ["-DEMU_DEFAULT_WIDE", "-DEP_GUARD_WIDE"])
-
-
-@pytest.fixture(scope="session")
-def hostemu_ep(built):
-    """192-thread workgroups with the wide net for the emulation-prevention guard, and the winner's leads turned into bytes by lane 0's walk."""
-    return _hostemu_lib("libhostemu_ep.so", ["-DEP_GUARD_WIDE", "-DIMCVT_RESOLVE_SERIAL"])
 
 
 @pytest.fixture(scope="session")

@@ -41,8 +41,8 @@ OVF = [e for e in PICK if e["input"].get("w", 999) <= 100 or e["input"].get("fil
 
 
 @pytest.mark.parametrize("e", OVF, ids=kat_id)
-def test_ring_overflow_path_matches_golden(hostemu_ovf, e):
-    # trial coders whose byte ring overflows are repeated on the safe path (hevc_core.h run_trial): same streams
+def test_lead_sink_exact_paths_match_golden(hostemu_ovf, e):
+    # every trial's byte-level state from the real logic over its lead list, every winner's bytes by lane 0's walk (hevc_core.h leads_exact, resolve_leads): same streams
     stream, rcon = emu_encode(hostemu_ovf, kat_input(e["input"]), e["qpd6"])
     assert hashlib.sha256(stream).hexdigest() == e["sha256"]
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
@@ -87,8 +87,8 @@ def test_pipe_wave_matches_golden(hostemu_pipe, e):
 
 
 @pytest.mark.parametrize("e", OVF, ids=kat_id)
-def test_pipe_wave_ring_overflow_path_matches_golden(hostemu_pipe_ovf, e):
-    # the lane that holds the NxN result repeats header + four PU segments on the safe path when its byte ring overflowed
+def test_pipe_wave_lead_sink_exact_paths_match_golden(hostemu_pipe_ovf, e):
+    # the same with a pipe wave: the lane that holds the NxN result counts header + four PU segments exactly
     stream, rcon = emu_encode(hostemu_pipe_ovf, kat_input(e["input"]), e["qpd6"])
     assert hashlib.sha256(stream).hexdigest() == e["sha256"]
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
@@ -105,8 +105,8 @@ def test_wide_workgroup_matches_golden(hostemu_wide, e):
 
 
 @pytest.mark.parametrize("e", OVF, ids=kat_id)
-def test_wide_workgroup_ring_overflow_path_matches_golden(hostemu_wide_ovf, e):
-    # a byte half whose ring overflowed repeats its lane's stream with the plain coder on scratch contexts (the owner's contexts are final)
+def test_wide_workgroup_lead_sink_exact_paths_match_golden(hostemu_wide_ovf, e):
+    # the same in wide workgroups: the byte halves on partner wavefronts, PU pricing
     stream, rcon = emu_encode(hostemu_wide_ovf, kat_input(e["input"]), e["qpd6"])
     assert hashlib.sha256(stream).hexdigest() == e["sha256"]
     assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"]
@@ -315,12 +315,6 @@ def test_lds_budget(hostemu):
     assert 3 * (hostemu.hostemu_shm_bytes() + hostemu.hostemu_pipe_lds_bytes()) <= 160 * 1024
     # one 512-thread wide workgroup per CU with the partner wavefronts' record queues
     assert hostemu.hostemu_shm_bytes() + hostemu.hostemu_wide_lds_bytes() <= 160 * 1024
-
-
-def test_ep_guard_safe_path_192_threads_and_serial_resolve_match_golden(hostemu_ep):
-    for e in [x for x in PICK if x["input"].get("w", 999) <= 100 or x["input"].get("file") == "p4_gray.pgm"]:
-        stream, rcon = emu_encode(hostemu_ep, kat_input(e["input"]), e["qpd6"])
-        assert hashlib.sha256(stream).hexdigest() == e["sha256"] and hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], e["input"]
 
 
 def _byte_logic(leads, nbytes, buf, zeros, cnt, out):
