@@ -117,6 +117,13 @@ static int census(imcvt_hevc_ctx *c, int grid, int pipe) {
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(v, c->d_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return v[1];
 }
+// ... taken twice when the first count is far below the grid (under three quarters: another process or stream held compute units at that
+// moment): the plans of the context's whole life should not rest on one bad millisecond; the better of the two counts
+static int census_checked(imcvt_hevc_ctx *c, int grid, int pipe) {
+    int v = census(c, grid, pipe);
+    if (v > 0 && 4 * v < 3 * grid) { const int v2 = census(c, grid, pipe); if (v2 > v) v = v2; }
+    return v;
+}
 extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     if (!have_device()) return nullptr;
     imcvt_hevc_ctx *c = new imcvt_hevc_ctx();
@@ -192,8 +199,8 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
         if (!prewarm()) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
         // census: a launch of max_wg (pipe_wg) workgroups that only count themselves — what is resident at once is what the plans may use
         if (max_workgroups <= 0 && !getenv("IMCVT_HEVC_NO_CENSUS")) {
-            if (c->wide_wg > 0 && c->wide != 0) { const int cw = census(c, c->wide_wg, 2); if (cw > 0 && cw < c->wide_wg) { fprintf(stderr, "imcvt_hevc: %d of %d wide workgroups resident - planning with %d\n", cw, c->wide_wg, cw); c->wide_wg = cw; } }
-            c->census_pipe = census(c, c->pipe_wg, 1); c->census_wg = census(c, c->max_wg, 0);
+            if (c->wide_wg > 0 && c->wide != 0) { const int cw = census_checked(c, c->wide_wg, 2); if (cw > 0 && cw < c->wide_wg) { fprintf(stderr, "imcvt_hevc: %d of %d wide workgroups resident - planning with %d\n", cw, c->wide_wg, cw); c->wide_wg = cw; } }
+            c->census_pipe = census_checked(c, c->pipe_wg, 1); c->census_wg = census_checked(c, c->max_wg, 0);
             if (c->census_wg > 0 && c->census_wg < c->max_wg) { fprintf(stderr, "imcvt_hevc: %d of %d workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_wg, c->max_wg, c->occ_wg, c->census_wg); c->max_wg = c->census_wg; }
             if (c->census_pipe > 0 && c->census_pipe < c->pipe_wg) { fprintf(stderr, "imcvt_hevc: %d of %d pipe-wave workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_pipe, c->pipe_wg, c->occ_pipe, c->census_pipe); c->pipe_wg = c->census_pipe; }
             if (c->pipe_wg > c->max_wg) c->pipe_wg = c->max_wg;
@@ -647,6 +654,9 @@ static std::vector<Submission *> g_pending;
 static bool g_leader = false;
 static batch_backend_t g_backend = encode_batch_on_devices;
 static long g_q_calls = 0, g_q_batches = 0, g_q_max_batch = 0;
+#ifndef MERGE_MAX_FRAMES
+#define MERGE_MAX_FRAMES 2048      // frames one merged round takes at most (whole submissions; a single larger call still goes through alone)
+#endif
 static int coalesce_window_us() {
     static int us = -1;
     if (us < 0) { const char *e = getenv("IMCVT_HEVC_COALESCE_US"); us = e ? atoi(e) : 300; if (us < 0) us = 0; if (us > 1000000) us = 1000000; }
@@ -670,11 +680,18 @@ static void lead_one_round(std::unique_lock<std::mutex> &lk) {       // called w
     const bool crowd = g_pending.size() > 1 || (g_last_crowd.time_since_epoch().count() != 0 && now - g_last_crowd < std::chrono::milliseconds(100));
     if (win > 0 && crowd) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(win)); lk.lock(); }
     if (g_pending.size() > 1) g_last_crowd = std::chrono::steady_clock::now();
-    std::vector<Submission *> take; take.swap(g_pending);
+    // one round takes whole submissions up to MERGE_MAX_FRAMES frames (always the first one): what is left waits for the next leader, so
+    // the slab a round needs is bounded by what its callers asked for, not by how many callers happened to arrive together
+    std::vector<Submission *> take;
+    size_t total = 0;
+    {
+        size_t k = 0;
+        while (k < g_pending.size() && (k == 0 || total + (size_t)g_pending[k]->n <= (size_t)MERGE_MAX_FRAMES)) { total += (size_t)g_pending[k]->n; k++; }
+        take.assign(g_pending.begin(), g_pending.begin() + (long)k);
+        g_pending.erase(g_pending.begin(), g_pending.begin() + (long)k);
+    }
     const batch_backend_t backend = g_backend;
     lk.unlock();
-    size_t total = 0;
-    for (const Submission *u : take) total += (size_t)u->n;
     try {                                               // (whatever happens in here, every caller of this round is released with a return code)
         std::vector<unsigned char *> pb(total), rc_(total); std::vector<const unsigned char *> im(total);
         std::vector<int> ys(total), xs(total), q(total), len(total, 0);
@@ -683,6 +700,13 @@ static void lead_one_round(std::unique_lock<std::mutex> &lk) {       // called w
         const int rc = total ? backend((int)total, pb.data(), im.data(), rc_.data(), ys.data(), xs.data(), q.data(), len.data()) : 0;
         k = 0;
         for (Submission *u : take) { for (int i = 0; i < u->n; i++, k++) if (rc == 0) { u->ysz[i] = ys[k]; u->xsz[i] = xs[k]; u->out_len[i] = len[k]; } u->rc = rc; }
+        if (rc != 0 && take.size() > 1) {               // a merged batch failed: every submission again on its own, so that only the caller whose frames cannot be encoded sees the error
+            for (Submission *u : take) {
+                std::vector<int> y1(u->ysz, u->ysz + u->n), x1(u->xsz, u->xsz + u->n), l1((size_t)u->n, 0);
+                u->rc = u->n ? backend(u->n, u->pbuffers, u->imgs, u->rcons, y1.data(), x1.data(), u->qpd6, l1.data()) : 0;
+                if (u->rc == 0) for (int i = 0; i < u->n; i++) { u->ysz[i] = y1[(size_t)i]; u->xsz[i] = x1[(size_t)i]; u->out_len[i] = l1[(size_t)i]; }
+            }
+        }
     } catch (...) {
         fprintf(stderr, "imcvt_hevc: out of host memory while merging %zu frames of %zu callers\n", total, take.size());
         for (Submission *u : take) u->rc = IMCVT_ERR_HIP;

@@ -219,5 +219,29 @@ def test_submission_queue_merges_concurrent_callers(built):
         ys = (C.c_int * 3)(8, 8, 8); xs = (C.c_int * 3)(8, 8, 8); qv = (C.c_int * 3)(0, 1, 2); lens = (C.c_int * 3)()
         assert lib.HEVCImageEncoderBatch(3, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]), P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, qv, lens) == 0
         assert list(lens) == [140, 142, 144] and seen[-1] == 3
+        # a merged batch that fails is retried submission by submission: only the caller whose frame cannot be encoded sees the error
+        failing = {"on": True}
+
+        @C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(u8p), C.POINTER(u8p), ip, ip, ip, ip)
+        def picky(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len):
+            time.sleep(0.02)
+            if any(imgs[i][0] == 7 for i in range(n)):
+                return -5
+            for i in range(n):
+                out_len[i] = 200 + imgs[i][0]
+            return 0
+
+        lib.imcvt_hevc_debug_set_backend(C.cast(picky, C.c_void_p))
+        res2 = {}
+
+        def call2(t):
+            img = np.full(64, t, np.uint8); out = np.zeros(16, np.uint8); rc = np.zeros(16, np.uint8)
+            ys, xs = C.c_int(8), C.c_int(8)
+            res2[t] = lib.HEVCImageEncoder(out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), rc.ctypes.data_as(u8p), C.byref(ys), C.byref(xs), 0)
+
+        th = [threading.Thread(target=call2, args=(t,)) for t in range(12)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert res2[7] == -5 and all(res2[t] == 200 + t for t in range(12) if t != 7), res2
     finally:
         lib.imcvt_hevc_debug_set_backend(None)
