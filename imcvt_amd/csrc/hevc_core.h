@@ -497,7 +497,7 @@ struct alignas(16) SplitQ {
 struct alignas(16) PartnerMem {
     SplitQ q;
     alignas(16) LaneMem lm[NMODE];               // lead rings of the byte half
-    alignas(4) u8 cx[NMODE][CTX_STRIDE];         // context scratch of its safe path (ring overflow)
+    alignas(4) u8 cx[NMODE][CTX_STRIDE];         // context copies of coders that run on the partner wavefront itself (the four-TU set's, hevc_frame.h partner_fourtu)
 };
 // Control words of a wide workgroup's 8x8 CUs, and the LDS slices of the two partner wavefronts that LEND themselves for pipeline passes
 // (hevc_frame.h lend_passes: the one-TU candidate set's three passes of an 8x8 CU run on three wavefronts at once).
@@ -512,8 +512,9 @@ struct alignas(16) WideCtl {
 // A PU step of an 8x8 CU in a wide workgroup (hevc_frame.h pu_step_wide): the PU wave predicts, transforms and quantises the 35 candidates,
 // leaves levels and prediction here, makes the FIRST part of every candidate's tokens (cbf, last position, significance / greater-1 /
 // greater-2 flags, full sign chunks) in its lane rows and runs the range half of the pricing over them straight from LDS; one partner
-// (pu_part_b) makes the REST (remaining levels: rows `brow`), which the range half goes on with; another (pu_recon_price) makes the
-// reconstructions and SSE and runs the byte half of the pricing.  Tokens reach global memory only where someone needs them there.
+// (pu_part_b) makes the REST (remaining levels: rows `brow` — bypass chunks only, which the byte half of the pricing takes from the rows itself);
+// another (pu_recon_k, pu_price) makes the reconstructions and SSE and runs the byte half of the pricing.  Tokens reach global memory only
+// where someone needs them there.
 #define BROW_CAP 72                              // tokens of a partner row: 16 levels x 32 bins at most + 7 pending sign bins = 519 bins <= 65 chunks
 #define BROW_STRIDE (BROW_CAP + 10)              // u16 per lane (41 dwords: odd): room for the 8 idle tokens that pad the last token block
 struct alignas(16) PuX {
@@ -2446,10 +2447,9 @@ HD void lead_step(Arith &a, S &sink, int lead) {                                
 }
 HD u32 tok_of(const U4 &b, int j) { const u32 w = (j < 2) ? b.x : (j < 4) ? b.y : (j < 6) ? b.z : b.w; return (j & 1) ? (w >> 16) : (w & 0xFFFFu); }
 
-// Code tokens p[0..n) (global memory, 16-byte aligned) and leave the emitted bytes in gbuf[0..a.cnt - cnt_on_entry).
+// Code tokens p[0..n) (global memory, 16-byte aligned); the leads of the bytes that leave `low` go to the lane's lead sink (LeadSink), `qn` counts them.
 // Wave collective: every lane calls it, idle lanes with n == 0.  All lanes are in the same phase of their streams, so
-// the token loads (one 16-byte block per lane per 8 steps, issued one block ahead) and the byte flushes are wave-synchronous.
-// Returns non-zero if the lane's ring overflowed (the result is then void, see RingSink).
+// the token loads (one 16-byte block per lane per 8 steps, issued one block ahead) and the lead flushes are wave-synchronous.
 // (stream_seg: one segment of a stream on a sink that outlives it — the pipe wave codes a CU's stream in pieces as they become known)
 // RES: the tokens are resolved (code_token_r); cx is not used
 template <bool RES>

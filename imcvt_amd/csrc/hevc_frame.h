@@ -454,9 +454,9 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 #define NXN_KEEP 1024
 #define NXN_KEEP_STRIDE 160
 // One PU step of the NxN chain in a wide workgroup, on the PU wave: pass and pricing of the 35 candidates of PU k (hevc_core.h "A PU step ...").
-//   here      prediction, DST, RDOQ -> levels published; first part of the tokens into the lane rows; range half of the pricing over them from LDS;
-//             then, once wave 7 has made them, over the remaining-level rows; PU 0 only: the complete streams to memory (the four-TU wave's TU 0)
-//   wave 7    remaining-level tokens (pu_part_b)          wave 6 (wave 7 for PU 3)    reconstructions, SSE, byte half of the pricing, costs (pu_recon_price)
+//   here      prediction, DST, RDOQ -> levels published; first part of the tokens into the lane rows; range half of the pricing over them from LDS
+//             (the remaining-level rows are bypass chunks: the byte half prices them alone); PU 0 only: the complete streams to memory (the four-TU wave's TU 0)
+//   wave 7    remaining-level rows (pu_part_b)          pipe wave (wave 7 for PU 3)    reconstructions and SSE (pu_recon_k; PU 3: this wave itself), byte half of the pricing, costs (pu_price)
 // Same tokens in the same order as p1_run_4 writes, same coder arithmetic as run_trial_r.
 HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out of line: inlined, its registers would be eval_NxN's — and the 192- / 256-thread shapes' — to pay for)
     const int wave = uni_i(wave_); const int k = uni_i(k_);

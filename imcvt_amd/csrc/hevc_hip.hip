@@ -71,7 +71,7 @@ static bool have_device() {
     return true;
 }
 
-extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r5 (wg=192; 256 with a pipe wave when the launch leaves room; 512 - pipe wave + four partner wavefronts, trial coders and PU steps split over wavefronts - when every workgroup gets a compute unit; a frame per workgroup, or main workgroups + a pool of helper workgroups when the batch leaves room; N = 16 / 32 transforms on the matrix cores)"; }
+extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r5 (wg=192; 256 with a pipe wave when the launch leaves room; 512 - pipe wave + four partner wavefronts, trial coders and PU steps split over wavefronts - when every workgroup gets a compute unit; a frame per workgroup, or main workgroups + a pool of helper workgroups when the batch leaves room; N = 16 / 32 transforms on the matrix cores; trial coders leave the leads of their bytes, the winner's become bytes by a carry look-ahead over ballots)"; }
 extern "C" int imcvt_hevc_padded(int v) { return ((v < 8192 ? v : 8192) + 31) / 32 * 32; }
 extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 32) * (h + 32) + 65536; }
 
