@@ -97,11 +97,11 @@ def golden_digests(qpd6):
     if os.path.exists(p):
         d = json.load(open(p))
         if d.get("qpd6") == qpd6 and d["input"] == {"kind": "syn", "w": W, "h": H}:
-            g.update({int(k): (v["bytes"], v["sha256"]) for k, v in d["frames"].items()})
+            g.update({int(k): (v["bytes"], v["sha256"], v.get("rcon_sha256")) for k, v in d["frames"].items()})
     for e in json.load(open(os.path.join(ROOT, "tests", "golden", "hevc_kat.json"))):
         i = e["input"]
         if i.get("kind") == "syn" and (i.get("w"), i.get("h")) == (W, H) and e["qpd6"] == qpd6:
-            g[int(i["arg"])] = (e["bytes"], e["sha256"])
+            g[int(i["arg"])] = (e["bytes"], e["sha256"], e.get("rcon_sha256"))
     return g
 
 
@@ -226,10 +226,19 @@ def main():
         for s, d, n in zip(all_seeds, all_dig, all_len):
             if s in gold:
                 checked += 1
-                ok += (gold[s] == (n, d))
+                ok += (gold[s][:2] == (n, d))
         if checked and ok != checked:
             raise SystemExit(f"{checked - ok} of {checked} streams differ from the reference digests — result invalid")
         verified = f"{ok}/{len(all_seeds)} streams sha256-equal to reference digests"
+        # the reconstructions of this rank's frames (they stay on the GPU that made them: the gather moves streams only) against the same table
+        rc_checked = rc_ok = 0
+        for i, sd in enumerate(seeds):
+            if sd in gold and gold[sd][2]:
+                rc_checked += 1
+                rc_ok += hashlib.sha256(batch["rcons"][i].cpu().numpy().tobytes()).hexdigest() == gold[sd][2]
+        if rc_checked and rc_ok != rc_checked:
+            raise SystemExit(f"{rc_checked - rc_ok} of {rc_checked} reconstructions differ from the reference digests — result invalid")
+        verified += f"; {rc_ok}/{F} reconstructions of rank 0 sha256-equal to reference digests"
         if checked < len(all_seeds):                      # no golden digest for some frames: check a sample against the CPU checker
             from oracle import oracle                     # (checker only, outside the timed region)
             todo = [i for i, s in enumerate(seeds) if s not in gold][:2]
@@ -250,7 +259,7 @@ def main():
         traffic, traffic_src = None, "not collected in this run (rocprofv3 --pmc passes: tools/pmc_traffic.py)"
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")            # calibrated FETCH_SIZE / WRITE_SIZE of a counter run
         lib_hash = _lib_srchash()
-        stale = lambda rec: "" if rec.get("lib_srchash") == lib_hash else "STALE (counters were taken on a different build of the library than the one timed here) - "
+        stale = lambda rec: "" if (lib_hash is not None and rec.get("lib_srchash") == lib_hash) else "STALE (counters were taken on a different build of the library than the one timed here) - "
         if os.path.exists(tp):
             t = json.load(open(tp))
             if t.get("qpd6") == args.qpd6 and t.get("hbm_bytes_per_launch") and t.get("ctus"):
@@ -303,7 +312,11 @@ def main():
             line["latency_view"] = latency_view(enc, dev, args.qpd6)
             line["qpd6_4_view"] = qpd6_view(enc, big, 4) if args.qpd6 != 4 else None
             line["solo_1000f"] = solo_view(enc, big, last, args.qpd6)
-            line["host_abi_view"] = host_abi_view(big, last, args.qpd6)
+            line["host_abi_view"] = hv = host_abi_view(big, last, args.qpd6, gold={i: gold[s] for i, s in enumerate(seeds) if s in gold})
+            # wall time of the reference-shaped entry point, H2D and D2H included, beside the kernel-only figure
+            line["t_wall_incl_transfers"] = {"ms": hv["wall_ms"], "mpx_s": hv["mpx_s"], "frac_of_value": round(hv["mpx_s"] / value, 4) if hv["frames"] == F else None,
+                                             "what": f"HEVCImageEncoderBatch over the {hv['frames']} bench frames from and to pageable host memory, one call (host_abi_view)"}
+            line["job_seconds_by_share"] = share_view(enc, big, args.qpd6, k_avg)
             line["jls_view"] = jls_view(dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.qpd6)
@@ -333,6 +346,22 @@ def solo_view(enc, big, digests, qpd6, n=1000):
         raise SystemExit("solo_1000f: streams differ from the timed batch's")
     return {"frames": n, "kernel_ms": round(ms, 1), "mpx_s": round(n * W * H / ms / 1e3, 3), "shape": list(enc.last_shape()),
             "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
+
+
+def share_view(enc, big, qpd6, k512):
+    """One GPU's share of BASELINE configs[3] at N = 1 / 2 / 4 / 8 as seconds of kernel time (the first 512 / 256 / 128 / 64 bench frames in one
+    launch each): what the strong-scaling job costs per N, read in seconds rather than as a ratio."""
+    import torch
+    F = big.shape[0]
+    out = {str(F): {"kernel_s": round(k512, 3), "what": "the timed batch"}}
+    for n in (256, 128, 64):
+        if n >= F:
+            continue
+        b = enc.make_batch([big[i] for i in range(n)], qpd6)
+        enc.encode(b); torch.cuda.synchronize()
+        out[str(n)] = {"kernel_s": round(enc.last_kernel_ms() / 1e3, 3), "shape": list(enc.last_shape()), "pipe_wave": enc.last_pipe(), "wide_workgroups": enc.last_wide()}
+        del b
+    return out
 
 
 def qpd6_view(enc, big, q):
@@ -397,24 +426,32 @@ def jls_view(dev):
     return out
 
 
-def host_abi_view(big, digests, qpd6, n=512):
+def host_abi_view(big, digests, qpd6, n=512, gold=None):
     """The reference-shaped entry point (HOST pointers in and out): wall time of HEVCImageEncoderBatch over the
     bench frames, PCIe copies in both directions, slab management and the launch included — next to `value`, which is measured
     with inputs resident in HBM (BASELINE.md §3 asks for both)."""
     import imcvt_amd
     n = min(n, big.shape[0])
+    from imcvt_amd import hevc
     imgs = [big[i].cpu().numpy() for i in range(n)]
-    imcvt_amd.HEVCImageEncoderBatch(imgs[:2], qpd6)              # creates the per-device context and slab outside the timed call
+    imcvt_amd.HEVCImageEncoderBatch(imgs[:32], qpd6)             # creates the per-device context, slab and staging buffers outside the timed call
     t0 = time.perf_counter()
-    res = imcvt_amd.HEVCImageEncoderBatch(imgs, qpd6)
+    res = imcvt_amd.HEVCImageEncoderBatch(imgs, qpd6, copy=False)      # (streams as views of the caller-owned buffers, as a C caller has them)
     dt = time.perf_counter() - t0
+    xs = hevc.transfer_stats()
     same = all(hashlib.sha256(s).hexdigest() == d for (s, _, _), d in zip(res, digests[:n]))
     if not same:
         raise SystemExit("host_abi_view: host-pointer batch differs from the device-resident batch")
+    if gold:                                                     # the reconstructions that came back over the link, against the reference's digests
+        bad = [i for i in range(n) if i in gold and gold[i][2] and hashlib.sha256(res[i][1].tobytes()).hexdigest() != gold[i][2]]
+        if bad:
+            raise SystemExit(f"host_abi_view: {len(bad)} reconstructions differ from the reference digests (first: frame {bad[0]})")
     lib = imcvt_amd.load_library()
     out = {"frames": n, "wall_ms": round(dt * 1e3, 1), "mpx_s": round(n * W * H / dt / 1e6, 3), "devices": int(lib.imcvt_hevc_batch_devices()),
            "bytes_h2d": n * W * H, "bytes_d2h": int(sum(len(s) for s, _, _ in res)) + n * imcvt_amd.padded(H) * imcvt_amd.padded(W),
-           "streams_equal_to_resident_run": True}
+           "upload_ms": round(xs["upload_s"] * 1e3, 1), "followed_launch_ms": round(xs["follow_s"] * 1e3, 1), "tail_ms": round(xs["tail_s"] * 1e3, 1),
+           "bytes_copied_out_while_the_launch_ran": int(xs["bytes_during"]), "bytes_copied_out_after_it": int(xs["bytes_after"]),
+           "streams_equal_to_resident_run": True, "reconstructions_equal_to_reference_digests": bool(gold)}
     lib.imcvt_hevc_shutdown()
     return out
 

@@ -69,6 +69,8 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD int wg_is_wide() { return emu_wide_on(); }
   HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
   HD void drain_stores() {}
+  HD void sys_release() {}
+  HD void sys_st32(void *p, u32 v) { *(volatile u32 *)p = v; }
 #else
   #define HD __device__ __forceinline__
   // Out-of-line device functions.  not_tail_called keeps LLVM's `tail` marker off their call sites; with the marker on any call site
@@ -110,6 +112,10 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   // an idle helper backs off (round r of an unsuccessful poll): ~0.9 us doubling to ~7 us, so that hundreds of idle helpers do not hammer the queue words
   HD void mail_idle_pause(int r) { const int n = r < 3 ? 1 << r : 8; for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(MAIL_POLL_SLEEP); }
   HD void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  // what this compute unit's waves stored so far becomes visible OUTSIDE the device's caches (a copy engine reading HBM while the kernel runs): a
+  // system-scope release writes the XCD's L2 back.  Used once per CTU row of a frame whose progress the host follows, never on the mail path.
+  HD void sys_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+  HD void sys_st32(void *p, u32 v) { __hip_atomic_store((u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   HD unsigned long long wd_now() { return wall_clock64(); }
   // flags between the wavefronts of one workgroup (pipe wave): LDS words, polled.  The wavefronts of a workgroup share a compute
   // unit and its vector L1, so a producer's global stores are visible to the consumer once they have been issued and waited for
@@ -308,7 +314,10 @@ struct FrameJob {
     i32 h, w, hp, wp, q;
     i32 hdr_len;     // header bytes already placed at out[0..hdr_len)
     i32 *out_len;    // result
+    u32 *prog;       // optional progress record of this frame, two words the host may read WHILE the launch runs (imcvt_hevc_set_progress; pinned host or device memory), or null:
+                     // [0] CTU rows whose reconstruction is final in rcon (| PROG_DONE once the frame is finished), [1] stream bytes that are final in out
 };
+#define PROG_DONE 0x80000000u
 #define TOK_CAP 7040             // u16 per candidate stream: 18 (CU header) + 4 x 25 (cbf + last position per TU) + 64 groups x 108, rounded to 16 bytes
 #define TOK_SLOTS (NMODE + 1)
 struct Scratch {

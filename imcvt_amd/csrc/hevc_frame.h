@@ -1394,8 +1394,17 @@ HD void encode_ctu() {
     wg_sync();
 }
 
+// A frame whose progress the host follows (FrameJob::prog; the host-pointer entry points copy finished CTU rows and stream bytes out WHILE the
+// launch runs): every wave's stores have reached L2, the workgroup's L2 is written back, then the two words go out at system scope.  All threads call this.
+HD void publish_progress(u32 *prog, u32 rows) {
+    drain_stores();
+    wg_sync();
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { sys_release(); sys_st32(prog + 1, (u32)F.out_pos); sys_st32(prog, rows); } }
+}
+
 // Encode one frame with one workgroup.  `hdr` = the stream headers, prepared on the host (:664-690).
 HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job, const Scratch sc, const u8 *hdr) {
+    u32 *const prog = uni_p(job.prog);                  // (wave-uniform: the branches on it hold workgroup barriers)
     WAVES(w) LANES(l) {
         const int tid = w * 64 + l;
         const u32 *src = (const u32 *)gT; u32 *dst = (u32 *)&SM.T;
@@ -1441,6 +1450,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
             if (F.mail) { if (F.prio_base) SETPRIO(2); else SETPRIO(0); }
 #endif
             encode_ctu();
+            if (prog && cx + 32 >= job.wp && cy + 32 < job.hp) publish_progress(prog, (u32)(cy / 32 + 1));      // a CTU row is complete (the last one goes out with the frame, below)
         }
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if (sc.prof && threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(threadIdx.x >> 6) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);   // role 0's slice
@@ -1451,9 +1461,11 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
             Sink ls; ls.base = job.out + F.out_pos; ls.off = 0;
             arith_finish(a, ls);                                      // :1639-1640
             *job.out_len = F.out_pos + a.cnt;
+            F.out_pos += a.cnt;
         }
     }
     wg_sync();
+    if (prog) publish_progress(prog, (u32)(job.hp / 32) | PROG_DONE);
 }
 
 // ---- helper workgroup: serve requests until every slot it listens on has been closed ----------------------------------
@@ -1595,7 +1607,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; WCTL.lend_done[0] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; for (int i = 0; i < NLEND; i++) WCTL.lend_done[i] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide() && PU_HINTS; SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;

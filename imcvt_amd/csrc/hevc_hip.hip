@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -58,6 +59,7 @@ struct imcvt_hevc_ctx {
     int census_wg = 0, census_pipe = 0;     // workgroups of a max_wg / pipe_wg launch that were resident at once when the context was created (0: not measured)
     int wide = -1, wide_wg = 0, occ_wide = 0, last_wide = 0;   // wide workgroups (512 threads: pipe wave + four partner wavefronts, one workgroup per compute unit): < 0 whenever a pipe-wave launch fits wide_wg workgroups, 0 never, 1 as -1
     int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
+    u32 *prog = nullptr;                    // progress records of the next launches' frames, two words each (imcvt_hevc_set_progress), or null
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "imcvt_hevc: %s failed: %s\n", #x, hipGetErrorString(e_)); return IMCVT_ERR_HIP; } } while (0)
@@ -199,7 +201,8 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
         if (!prewarm()) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
         // census: a launch of max_wg (pipe_wg) workgroups that only count themselves — what is resident at once is what the plans may use
         if (max_workgroups <= 0 && !getenv("IMCVT_HEVC_NO_CENSUS")) {
-            if (c->wide_wg > 0 && c->wide != 0) { const int cw = census_checked(c, c->wide_wg, 2); if (cw > 0 && cw < c->wide_wg) { fprintf(stderr, "imcvt_hevc: %d of %d wide workgroups resident - planning with %d\n", cw, c->wide_wg, cw); c->wide_wg = cw; } }
+            if (c->wide_wg > 0) { const int cw = census_checked(c, c->wide_wg, 2);      // (whatever IMCVT_HEVC_WIDE says now: imcvt_hevc_set_wide may turn them on later)
+                if (cw > 0 && cw < c->wide_wg) { fprintf(stderr, "imcvt_hevc: %d of %d wide workgroups resident - planning with %d\n", cw, c->wide_wg, cw); c->wide_wg = cw; } }
             c->census_pipe = census_checked(c, c->pipe_wg, 1); c->census_wg = census_checked(c, c->max_wg, 0);
             if (c->census_wg > 0 && c->census_wg < c->max_wg) { fprintf(stderr, "imcvt_hevc: %d of %d workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_wg, c->max_wg, c->occ_wg, c->census_wg); c->max_wg = c->census_wg; }
             if (c->census_pipe > 0 && c->census_pipe < c->pipe_wg) { fprintf(stderr, "imcvt_hevc: %d of %d pipe-wave workgroups resident (occupancy API: %d per compute unit) - planning with %d\n", c->census_pipe, c->pipe_wg, c->occ_pipe, c->census_pipe); c->pipe_wg = c->census_pipe; }
@@ -226,6 +229,7 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
 }
 
 extern "C" void imcvt_hevc_set_frame_clock(imcvt_hevc_ctx *c, unsigned long long *d_buf) { if (c) c->d_fclk = d_buf; }
+extern "C" void imcvt_hevc_set_progress(imcvt_hevc_ctx *c, unsigned int *words) { if (c) c->prog = (u32 *)words; }
 extern "C" void imcvt_hevc_set_trace(imcvt_hevc_ctx *c, int *d_trace, int cap) { if (c) { c->d_trace = d_trace; c->trace_cap = cap; } }
 extern "C" void imcvt_hevc_set_pipe(imcvt_hevc_ctx *c, int mode) { if (c) c->pipe = mode; }
 extern "C" int imcvt_hevc_last_pipe(imcvt_hevc_ctx *c) { return c ? c->last_pipe : IMCVT_ERR_ARG; }
@@ -245,7 +249,7 @@ extern "C" int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shap
     if (!nmains || !nhelp) return 0;
     if (imcvt_hevc_plan_wide(use_pipe, *nmains + *nhelp, wide_wg, forced_shape)) return 1;
     if (!use_pipe || forced_shape || mode < 2 || *nmains < 1 || 2 * *nmains > wide_wg) return 0;
-    *nhelp = wide_wg - *nmains;
+    if (*nhelp > wide_wg - *nmains) *nhelp = wide_wg - *nmains;      // (cut, never raised: a plan that already fits the compute units keeps its helper count)
     return 1;
 }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
@@ -381,6 +385,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         FrameJob &j = c->h_jobs[i];
         j.img = f.d_img; j.out = f.d_out; j.rcon = f.d_rcon; j.out_len = f.d_len;
         j.h = f.h; j.w = f.w; j.hp = imcvt_hevc_padded(f.h); j.wp = imcvt_hevc_padded(f.w); j.q = f.qpd6;
+        j.prog = c->prog ? c->prog + 2 * (size_t)i : nullptr;
         j.hdr_len = imcvt::build_headers(c->h_hdrs + (size_t)HDR_MAX * i, f.qpd6, j.hp, j.wp);
     }
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
@@ -520,22 +525,53 @@ extern "C" float imcvt_hevc_last_kernel_ms(imcvt_hevc_ctx *c) {
 
 // ---------------------------------------------------------------------------------------------------
 // Host-pointer entry points (the reference's own interface).  A batch fans out over every visible device: frame i goes
-// to device i mod D; each device has its own context, stream and a grow-only slab that is reused from call to call.
+// to device i mod D; each device has its own context, streams and a grow-only slab that is reused from call to call.
+//
+// Transfers (round 6).  The caller's buffers are pageable; a pageable copy runs at ~4 GB/s on this platform, and in round 5 all of them sat
+// before (512 inputs) and after (1024 outputs) the launch: 0.63 s beside 5.0 s of kernel.  Now
+//   in   large batches go through a few pinned staging buffers filled by worker threads (memcpy + asynchronous copy per 8 MB chunk, two
+//        buffers per thread), so the link, not the page tables, sets the pace;
+//   out  every frame carries a progress record in pinned host memory (FrameJob::prog, hevc_frame.h publish_progress: CTU rows whose
+//        reconstruction is final, stream bytes that are final), and the calling thread copies finished rows and bytes to the caller's buffers
+//        WHILE the launch runs; what is left when the kernel ends is the last rows of the last frames.
+// Small batches (the reference's one-picture calls) keep the plain path: copies, launch, copies.
 // ---------------------------------------------------------------------------------------------------
+#ifndef UP_CHUNK
+#define UP_CHUNK ((size_t)8 << 20)      // bytes per staging buffer
+#endif
+#ifndef UP_LANES
+#define UP_LANES 3                      // upload threads per device, two staging buffers each (streams per device stay at four: kernel, copy-out / lane 0, lanes 1 and 2)
+#endif
+#ifndef STAGE_MIN_BYTES
+#define STAGE_MIN_BYTES ((size_t)32 << 20)      // batches with less input than this are copied as before
+#endif
+#ifndef FOLLOW_MIN_BYTES
+#define FOLLOW_MIN_BYTES ((size_t)16 << 20)     // batches with less output than this are collected after the launch, as before
+#endif
+#ifndef FOLLOW_ROWS
+#define FOLLOW_ROWS 2                   // CTU rows of a frame that are worth a copy of their own while the launch runs
+#endif
+struct UpLane { hipStream_t st = nullptr; bool own_stream = false; u8 *buf[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; bool busy[2] = { false, false }; };
 struct DevState {
     int dev = 0;
     imcvt_hevc_ctx *ctx = nullptr;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st_copy = nullptr;
     u8 *slab = nullptr; size_t slab_cap = 0;
     std::vector<int> idx;                       // frames of the current call
     std::vector<size_t> off_img, off_out, off_rc;
     size_t off_len = 0;
     std::vector<imcvt_hevc_frame> fr;
     std::vector<int> lens;
+    UpLane up[UP_LANES];                        // staging (created by the first batch that is large enough)
+    u32 *h_prog = nullptr; int prog_cap = 0;    // pinned progress records of the running launch, two words per frame
+    std::vector<u32> got_rows, got_pos;         // CTU rows / stream bytes of each frame that have reached the caller's buffers
+    int rc = 0; bool launched = false;
+    double t_up = 0, t_follow = 0, t_tail = 0; size_t followed = 0, tail = 0;      // statistics of the last call (imcvt_hevc_batch_transfer_stats)
 };
 static std::mutex g_lock;
 static std::vector<DevState> g_devs;
 static int g_last_devices = 0;
+static double g_xfer[5];                        // last batch: seconds uploading, following, collecting the tail; bytes copied while the launch ran / after it
 
 static int dev_init(DevState &d) {
     if (d.ctx) return 0;
@@ -543,22 +579,195 @@ static int dev_init(DevState &d) {
     d.ctx = imcvt_hevc_create(0);
     if (!d.ctx) return IMCVT_ERR_NO_DEVICE;
     HIPCHK(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&d.st_copy, hipStreamNonBlocking));
     return 0;
+}
+static void dev_release(DevState &d) {
+    if (!d.ctx) return;
+    (void)hipSetDevice(d.dev);
+    (void)hipStreamSynchronize(d.st);
+    imcvt_hevc_destroy(d.ctx); d.ctx = nullptr;
+    for (UpLane &u : d.up) {
+        for (int k = 0; k < 2; k++) { if (u.buf[k]) (void)hipHostFree(u.buf[k]); if (u.ev[k]) (void)hipEventDestroy(u.ev[k]); u.buf[k] = nullptr; u.ev[k] = nullptr; u.busy[k] = false; }
+        if (u.own_stream && u.st) (void)hipStreamDestroy(u.st);
+        u.st = nullptr; u.own_stream = false;
+    }
+    if (d.h_prog) (void)hipHostFree(d.h_prog);
+    d.h_prog = nullptr; d.prog_cap = 0;
+    (void)hipStreamDestroy(d.st); d.st = nullptr;
+    (void)hipStreamDestroy(d.st_copy); d.st_copy = nullptr;
+    (void)hipFree(d.slab); d.slab = nullptr; d.slab_cap = 0;
 }
 
 extern "C" int imcvt_hevc_batch_devices(void) { return g_last_devices; }
+extern "C" void imcvt_hevc_batch_transfer_stats(double *upload_s, double *follow_s, double *tail_s, double *bytes_during, double *bytes_after) {
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (upload_s) *upload_s = g_xfer[0];
+    if (follow_s) *follow_s = g_xfer[1];
+    if (tail_s) *tail_s = g_xfer[2];
+    if (bytes_during) *bytes_during = g_xfer[3];
+    if (bytes_after) *bytes_after = g_xfer[4];
+}
 
 extern "C" void imcvt_hevc_shutdown(void) {
     std::lock_guard<std::mutex> guard(g_lock);
-    for (DevState &d : g_devs) {
-        if (!d.ctx) continue;
-        (void)hipSetDevice(d.dev);
-        (void)hipStreamSynchronize(d.st);
-        imcvt_hevc_destroy(d.ctx); d.ctx = nullptr;
-        (void)hipStreamDestroy(d.st); d.st = nullptr;
-        (void)hipFree(d.slab); d.slab = nullptr; d.slab_cap = 0;
-    }
+    for (DevState &d : g_devs) dev_release(d);
     g_devs.clear();
+}
+
+struct BatchArgs { unsigned char *const *pbuffers; const unsigned char *const *imgs; unsigned char *const *rcons; int *ysz, *xsz; const int *qpd6; int *out_len; };
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// inputs of one device's frames through the staging buffers: the chunks of all frames are one list, the lanes take them in turn
+static int upload_staged(DevState &d, const BatchArgs &A) {
+    struct Item { const u8 *src; u8 *dst; size_t len; };
+    std::vector<Item> items;
+    for (size_t j = 0; j < d.idx.size(); j++) {
+        const int i = d.idx[j];
+        const size_t n = (size_t)A.ysz[i] * A.xsz[i];
+        for (size_t o = 0; o < n; o += UP_CHUNK) items.push_back({ A.imgs[i] + o, d.slab + d.off_img[j] + o, n - o < UP_CHUNK ? n - o : UP_CHUNK });
+    }
+    for (int k = 0; k < UP_LANES; k++) {
+        UpLane &u = d.up[k];
+        if (!u.st) { if (k == 0) u.st = d.st_copy; else { if (hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking) != hipSuccess) return IMCVT_ERR_HIP; u.own_stream = true; } }
+        for (int b = 0; b < 2; b++) {
+            if (!u.buf[b] && hipHostMalloc((void **)&u.buf[b], UP_CHUNK, hipHostMallocDefault) != hipSuccess) return IMCVT_ERR_HIP;
+            if (!u.ev[b] && hipEventCreateWithFlags(&u.ev[b], hipEventDisableTiming) != hipSuccess) return IMCVT_ERR_HIP;
+        }
+    }
+    std::atomic<size_t> next(0);
+    std::atomic<int> err(0);
+    auto lane = [&](int k) {
+        UpLane &u = d.up[k];
+        if (hipSetDevice(d.dev) != hipSuccess) { err = IMCVT_ERR_HIP; return; }
+        for (int turn = 0; err == 0; turn ^= 1) {
+            const size_t it = next++;
+            if (it >= items.size()) break;
+            if (u.busy[turn] && hipEventSynchronize(u.ev[turn]) != hipSuccess) { err = IMCVT_ERR_HIP; break; }
+            memcpy(u.buf[turn], items[it].src, items[it].len);
+            if (hipMemcpyAsync(items[it].dst, u.buf[turn], items[it].len, hipMemcpyHostToDevice, u.st) != hipSuccess || hipEventRecord(u.ev[turn], u.st) != hipSuccess) { err = IMCVT_ERR_HIP; break; }
+            u.busy[turn] = true;
+        }
+        if (hipStreamSynchronize(u.st) != hipSuccess) err = IMCVT_ERR_HIP;
+        u.busy[0] = u.busy[1] = false;
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < UP_LANES; k++) th.emplace_back(lane, k);
+    lane(0);
+    for (std::thread &t : th) t.join();
+    return err;
+}
+
+// what the device has finished of frame j -> the caller's buffers.  fin: the launch is over (everything that is left); otherwise only what the
+// frame's progress record says is final, and only in pieces worth a copy.  Asynchronous on st_copy; *bytes counts what was queued.
+static int collect_frame(DevState &d, const BatchArgs &A, int j, bool fin, size_t *bytes) {
+    const int i = d.idx[(size_t)j], hp = imcvt_hevc_padded(A.ysz[i]), wp = imcvt_hevc_padded(A.xsz[i]);
+    u32 rows, pos;
+    if (fin) { rows = (u32)(hp / 32); pos = (u32)d.lens[(size_t)j]; }
+    else {
+        const volatile u32 *pr = d.h_prog + 2 * (size_t)j;
+        const u32 r = pr[0]; pos = pr[1]; rows = r & ~PROG_DONE;
+        if (rows > (u32)(hp / 32) || pos > (u32)imcvt_hevc_stream_bound(A.ysz[i], A.xsz[i])) return 0;      // (never: a record that makes no sense is ignored, the final pass collects the frame)
+        if (!(r & PROG_DONE)) {
+            if (rows < d.got_rows[(size_t)j] + FOLLOW_ROWS) rows = d.got_rows[(size_t)j];
+            if (pos < d.got_pos[(size_t)j] + 65536u) pos = d.got_pos[(size_t)j];
+        }
+    }
+    if (rows > d.got_rows[(size_t)j]) {
+        const size_t o = (size_t)d.got_rows[(size_t)j] * 32 * wp, n = (size_t)(rows - d.got_rows[(size_t)j]) * 32 * wp;
+        if (hipMemcpyAsync(A.rcons[i] + o, d.fr[(size_t)j].d_rcon + o, n, hipMemcpyDeviceToHost, d.st_copy) != hipSuccess) return IMCVT_ERR_HIP;
+        d.got_rows[(size_t)j] = rows; *bytes += n;
+    }
+    if (pos > d.got_pos[(size_t)j]) {
+        const size_t o = d.got_pos[(size_t)j], n = (size_t)pos - o;
+        if (hipMemcpyAsync(A.pbuffers[i] + o, d.fr[(size_t)j].d_out + o, n, hipMemcpyDeviceToHost, d.st_copy) != hipSuccess) return IMCVT_ERR_HIP;
+        d.got_pos[(size_t)j] = pos; *bytes += n;
+    }
+    return 0;
+}
+
+// one device's share of a batch, start to finish (its own thread when the batch spans several devices)
+static void run_device(DevState &d, const BatchArgs &A) {
+    d.rc = 0; d.launched = false; d.t_up = d.t_follow = d.t_tail = 0; d.followed = d.tail = 0;
+    const int m = (int)d.idx.size();
+    auto fail = [&](int e) { if (d.rc == 0) d.rc = e; };
+    if (hipSetDevice(d.dev) != hipSuccess) { fail(IMCVT_ERR_HIP); return; }
+    if (int e = dev_init(d)) { fail(e); return; }
+    d.off_img.resize((size_t)m); d.off_out.resize((size_t)m); d.off_rc.resize((size_t)m); d.fr.resize((size_t)m); d.lens.assign((size_t)m, 0);
+    d.got_rows.assign((size_t)m, 0u); d.got_pos.assign((size_t)m, 0u);
+    size_t total = 0, bytes_in = 0, bytes_out = 0;       // one device slab: [img | out | rcon] per frame, then the lengths
+    for (int j = 0; j < m; j++) {
+        // the reference indexes img with the ORIGINAL stride but only up to the padded (<=8192) extent (:1621)
+        const int i = d.idx[(size_t)j], hp = imcvt_hevc_padded(A.ysz[i]), wp = imcvt_hevc_padded(A.xsz[i]);
+        d.off_img[(size_t)j] = total; total += align256((size_t)A.ysz[i] * A.xsz[i]); bytes_in += (size_t)A.ysz[i] * A.xsz[i];
+        d.off_out[(size_t)j] = total; total += align256((size_t)imcvt_hevc_stream_bound(A.ysz[i], A.xsz[i]));
+        d.off_rc[(size_t)j] = total;  total += align256((size_t)hp * wp); bytes_out += (size_t)hp * wp;
+    }
+    d.off_len = total; total += align256(sizeof(int) * (size_t)m);
+    if (total > d.slab_cap) {
+        (void)hipFree(d.slab); d.slab = nullptr; d.slab_cap = 0;
+        if (hipMalloc(&d.slab, total) != hipSuccess) { fprintf(stderr, "imcvt_hevc: cannot allocate %zu bytes on device %d\n", total, d.dev); fail(IMCVT_ERR_HIP); return; }
+        d.slab_cap = total;
+    }
+    for (int j = 0; j < m; j++) {
+        const int i = d.idx[(size_t)j];
+        imcvt_hevc_frame &f = d.fr[(size_t)j];
+        f.d_img = d.slab + d.off_img[(size_t)j]; f.d_out = d.slab + d.off_out[(size_t)j]; f.d_rcon = d.slab + d.off_rc[(size_t)j];
+        f.d_len = (int *)(d.slab + d.off_len) + j; f.h = A.ysz[i]; f.w = A.xsz[i]; f.qpd6 = A.qpd6[i];
+    }
+    const bool plain = getenv("IMCVT_HEVC_PLAIN_COPIES") != nullptr;      // (A/B and tests: the round-5 path for every batch)
+    double t0 = now_s();
+    if (!plain && bytes_in >= STAGE_MIN_BYTES) { if (int e = upload_staged(d, A)) { fail(e); return; } }
+    else for (int j = 0; j < m; j++) {
+        const int i = d.idx[(size_t)j];
+        if (hipMemcpyAsync(d.slab + d.off_img[(size_t)j], A.imgs[i], (size_t)A.ysz[i] * A.xsz[i], hipMemcpyHostToDevice, d.st) != hipSuccess) { fail(IMCVT_ERR_HIP); return; }
+    }
+    d.t_up = now_s() - t0;
+    const bool follow = !plain && bytes_out >= FOLLOW_MIN_BYTES;
+    if (follow) {
+        if (m > d.prog_cap) {
+            if (d.h_prog) (void)hipHostFree(d.h_prog);
+            d.h_prog = nullptr; d.prog_cap = 0;
+            if (hipHostMalloc((void **)&d.h_prog, sizeof(u32) * 2 * (size_t)m, hipHostMallocDefault) != hipSuccess) { fail(IMCVT_ERR_HIP); return; }
+            d.prog_cap = m;
+        }
+        memset(d.h_prog, 0, sizeof(u32) * 2 * (size_t)m);
+    }
+    imcvt_hevc_set_progress(d.ctx, follow ? d.h_prog : nullptr);
+    if (int e = imcvt_hevc_encode_device(d.ctx, m, d.fr.data(), d.st)) { fail(e); return; }       // asynchronous
+    d.launched = true;
+    t0 = now_s();
+    if (follow) {
+        for (;;) {
+            const hipError_t q = hipEventQuery(d.ctx->ev1);
+            if (q != hipErrorNotReady) { if (q != hipSuccess) { (void)hipGetLastError(); fail(IMCVT_ERR_HIP); } break; }
+            size_t got = 0;
+            for (int j = 0; j < m && d.rc == 0; j++) if (int e = collect_frame(d, A, j, false, &got)) fail(e);
+            if (d.rc) break;
+            d.followed += got;
+            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    d.t_follow = now_s() - t0;
+}
+static void finish_device(DevState &d, const BatchArgs &A) {      // the launch is drained even after an error; then whatever has not been copied yet
+    if (!d.ctx || d.idx.empty()) return;
+    const int m = (int)d.idx.size();
+    auto fail = [&](int e) { if (d.rc == 0) d.rc = e; };
+    const double t0 = now_s();
+    if (hipSetDevice(d.dev) != hipSuccess) { fail(IMCVT_ERR_HIP); return; }
+    if (hipStreamSynchronize(d.st) != hipSuccess) fail(IMCVT_ERR_HIP);
+    if (hipStreamSynchronize(d.st_copy) != hipSuccess) fail(IMCVT_ERR_HIP);
+    if (!d.launched) return;
+    if (d.rc == 0) d.rc = imcvt_hevc_last_status(d.ctx);
+    if (d.rc == 0 && hipMemcpy(d.lens.data(), d.slab + d.off_len, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) fail(IMCVT_ERR_HIP);
+    for (int j = 0; j < m && d.rc == 0; j++) {
+        const int i = d.idx[(size_t)j];
+        if (d.lens[(size_t)j] < 1 || (long long)d.lens[(size_t)j] > imcvt_hevc_stream_bound(A.ysz[i], A.xsz[i]) || (u32)d.lens[(size_t)j] < d.got_pos[(size_t)j]) { fail(IMCVT_ERR_HIP); break; }
+        if (int e = collect_frame(d, A, j, true, &d.tail)) fail(e);
+    }
+    if (hipStreamSynchronize(d.st_copy) != hipSuccess) fail(IMCVT_ERR_HIP);
+    d.t_tail = now_s() - t0;
 }
 
 // One merged batch on the devices (called by one thread at a time: the submission queue's leader, below).
@@ -583,52 +792,24 @@ static int encode_batch_on_devices(int n, unsigned char *const *pbuffers, const 
     // a device joins when it gets at least one frame; with one frame the caller's current device does the work
     const int D = n < (int)g_devs.size() ? n : (int)g_devs.size();
     const int first = (D == 1 && prev_dev < (int)g_devs.size()) ? prev_dev : 0;
-    int rc = 0;
-    for (int k = 0; k < D && rc == 0; k++) {
-        DevState &d = g_devs[(first + k) % g_devs.size()];
-        rc = dev_init(d);
-        if (rc) break;
-        d.idx.clear();
-        for (int i = k; i < n; i += D) d.idx.push_back(i);
-        const int m = (int)d.idx.size();
-        d.off_img.resize(m); d.off_out.resize(m); d.off_rc.resize(m); d.fr.resize(m); d.lens.resize(m);
-        size_t total = 0;                           // one device slab: [img | out | rcon] per frame, then the lengths
-        for (int j = 0; j < m; j++) {
-            // the reference indexes img with the ORIGINAL stride but only up to the padded (<=8192) extent (:1621)
-            const int i = d.idx[j], hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
-            d.off_img[j] = total; total += align256((size_t)ysz[i] * xsz[i]);
-            d.off_out[j] = total; total += align256((size_t)imcvt_hevc_stream_bound(ysz[i], xsz[i]));
-            d.off_rc[j] = total;  total += align256((size_t)hp * wp);
-        }
-        d.off_len = total; total += align256(sizeof(int) * (size_t)m);
-        if (hipSetDevice(d.dev) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
-        if (total > d.slab_cap) {
-            (void)hipFree(d.slab); d.slab = nullptr; d.slab_cap = 0;
-            if (hipMalloc(&d.slab, total) != hipSuccess) { fprintf(stderr, "imcvt_hevc: cannot allocate %zu bytes on device %d\n", total, d.dev); rc = IMCVT_ERR_HIP; break; }
-            d.slab_cap = total;
-        }
-        for (int j = 0; j < m && rc == 0; j++) {
-            const int i = d.idx[j];
-            if (hipMemcpyAsync(d.slab + d.off_img[j], imgs[i], (size_t)ysz[i] * xsz[i], hipMemcpyHostToDevice, d.st) != hipSuccess) rc = IMCVT_ERR_HIP;
-            d.fr[j].d_img = d.slab + d.off_img[j]; d.fr[j].d_out = d.slab + d.off_out[j]; d.fr[j].d_rcon = d.slab + d.off_rc[j];
-            d.fr[j].d_len = (int *)(d.slab + d.off_len) + j; d.fr[j].h = ysz[i]; d.fr[j].w = xsz[i]; d.fr[j].qpd6 = qpd6[i];
-        }
-        if (rc == 0) rc = imcvt_hevc_encode_device(d.ctx, m, d.fr.data(), d.st);       // asynchronous: the next device is fed meanwhile
+    const BatchArgs A = { pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len };
+    auto dev_of = [&](int k) -> DevState & { return g_devs[(size_t)((first + k) % (int)g_devs.size())]; };
+    for (int k = 0; k < D; k++) { DevState &d = dev_of(k); d.idx.clear(); for (int i = k; i < n; i += D) d.idx.push_back(i); }
+    {   // upload, launch and follow: one thread per device (this thread takes the first)
+        std::vector<std::thread> th;
+        for (int k = 1; k < D; k++) th.emplace_back([&, k]() { run_device(dev_of(k), A); });
+        run_device(dev_of(0), A);
+        for (std::thread &t : th) t.join();
     }
-    for (int k = 0; k < D; k++) {                   // collect, device by device (every launched stream is drained even after an error)
-        DevState &d = g_devs[(first + k) % g_devs.size()];
-        if (!d.ctx || d.idx.empty()) continue;
-        const int m = (int)d.idx.size();
-        if (hipSetDevice(d.dev) != hipSuccess || hipStreamSynchronize(d.st) != hipSuccess) { rc = rc ? rc : IMCVT_ERR_HIP; d.idx.clear(); continue; }
-        if (rc == 0) rc = imcvt_hevc_last_status(d.ctx);
-        if (rc == 0 && hipMemcpy(d.lens.data(), d.slab + d.off_len, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) rc = IMCVT_ERR_HIP;
-        for (int j = 0; j < m && rc == 0; j++) {
-            const int i = d.idx[j], hp = imcvt_hevc_padded(ysz[i]), wp = imcvt_hevc_padded(xsz[i]);
-            if (hipMemcpyAsync(pbuffers[i], d.fr[j].d_out, (size_t)d.lens[j], hipMemcpyDeviceToHost, d.st) != hipSuccess
-                || hipMemcpyAsync(rcons[i], d.fr[j].d_rcon, (size_t)hp * wp, hipMemcpyDeviceToHost, d.st) != hipSuccess) { rc = IMCVT_ERR_HIP; break; }
-            out_len[i] = d.lens[j]; ysz[i] = hp; xsz[i] = wp;
-        }
-        if (hipStreamSynchronize(d.st) != hipSuccess) rc = rc ? rc : IMCVT_ERR_HIP;
+    int rc = 0;
+    for (int k = 0; k < D; k++) if (rc == 0) rc = dev_of(k).rc;
+    for (int k = 0; k < D; k++) { DevState &d = dev_of(k); if (rc != 0 && d.rc == 0) d.rc = rc; finish_device(d, A); if (rc == 0) rc = d.rc; }      // (after an error nothing more is copied, but every stream is drained)
+    for (int k = 0; k < 5; k++) g_xfer[k] = 0;
+    for (int k = 0; k < D; k++) {
+        DevState &d = dev_of(k);
+        if (rc == 0) for (size_t j = 0; j < d.idx.size(); j++) { const int i = d.idx[j]; out_len[i] = d.lens[j]; ysz[i] = imcvt_hevc_padded(ysz[i]); xsz[i] = imcvt_hevc_padded(xsz[i]); }
+        g_xfer[0] = d.t_up > g_xfer[0] ? d.t_up : g_xfer[0]; g_xfer[1] = d.t_follow > g_xfer[1] ? d.t_follow : g_xfer[1]; g_xfer[2] += d.t_tail;
+        g_xfer[3] += (double)d.followed; g_xfer[4] += (double)d.tail;
         d.idx.clear();
     }
     g_last_devices = D;
@@ -700,7 +881,10 @@ static void lead_one_round(std::unique_lock<std::mutex> &lk) {       // called w
         const int rc = total ? backend((int)total, pb.data(), im.data(), rc_.data(), ys.data(), xs.data(), q.data(), len.data()) : 0;
         k = 0;
         for (Submission *u : take) { for (int i = 0; i < u->n; i++, k++) if (rc == 0) { u->ysz[i] = ys[k]; u->xsz[i] = xs[k]; u->out_len[i] = len[k]; } u->rc = rc; }
-        if (rc != 0 && take.size() > 1) {               // a merged batch failed: every submission again on its own, so that only the caller whose frames cannot be encoded sees the error
+        // a merged batch failed on its ARGUMENTS: every submission again on its own, so that only the caller whose frames cannot be encoded sees the
+        // error.  Device-wide failures (HIP error, watchdog, no device) go to every caller of the round as they are: relaunching on a broken device
+        // once per caller would multiply everybody's wait.
+        if (rc == IMCVT_ERR_ARG && take.size() > 1) {
             for (Submission *u : take) {
                 std::vector<int> y1(u->ysz, u->ysz + u->n), x1(u->xsz, u->xsz + u->n), l1((size_t)u->n, 0);
                 u->rc = u->n ? backend(u->n, u->pbuffers, u->imgs, u->rcons, y1.data(), x1.data(), u->qpd6, l1.data()) : 0;

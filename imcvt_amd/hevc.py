@@ -27,7 +27,8 @@ EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "i
            "imcvt_hevc_stream_bound", "imcvt_hevc_padded", "imcvt_hevc_encode_device", "imcvt_hevc_last_kernel_ms",
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
            "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_plan_wide_pool", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
-           "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats")
+           "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats",
+           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -129,6 +130,11 @@ def load_library():
         lib.imcvt_hevc_debug_set_backend.argtypes = [C.c_void_p]
         lib.imcvt_hevc_coalesce_stats.restype = None
         lib.imcvt_hevc_coalesce_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]
+    if hasattr(lib, "imcvt_hevc_set_progress"):          # (round 6 on)
+        lib.imcvt_hevc_set_progress.restype = None
+        lib.imcvt_hevc_set_progress.argtypes = [C.c_void_p, C.c_void_p]
+        lib.imcvt_hevc_batch_transfer_stats.restype = None
+        lib.imcvt_hevc_batch_transfer_stats.argtypes = [C.POINTER(C.c_double)] * 5
     _lib = lib
     return lib
 
@@ -170,9 +176,18 @@ def HEVCImageEncoder(img: np.ndarray, qpd6: int = 0):
     return out[:n].tobytes(), rcon.reshape(ys.value, xs.value), (ys.value, xs.value)
 
 
-def HEVCImageEncoderBatch(imgs, qpd6=0):
+def transfer_stats():
+    """How the last host-pointer batch moved its data: dict(upload_s, follow_s, tail_s, bytes_during, bytes_after) — see include/imcvt_hevc.h."""
+    lib = load_library()
+    v = [C.c_double(0) for _ in range(5)]
+    lib.imcvt_hevc_batch_transfer_stats(*[C.byref(x) for x in v])
+    return dict(zip(("upload_s", "follow_s", "tail_s", "bytes_during", "bytes_after"), (x.value for x in v)))
+
+
+def HEVCImageEncoderBatch(imgs, qpd6=0, copy=True):
     """Encode independent gray8 frames concurrently (one workgroup per frame).  qpd6: int or per-frame list.
-    Returns a list of (stream bytes, reconstruction, (yszn, xszn))."""
+    Returns a list of (stream bytes, reconstruction, (yszn, xszn)); with copy=False the streams are uint8 views of the buffers the
+    library wrote into (as a C caller sees them: it owns every buffer, src/imageio_hevc.c:14-16) instead of bytes objects."""
     lib = load_library()
     n = len(imgs)
     if n == 0:
@@ -190,7 +205,7 @@ def HEVCImageEncoderBatch(imgs, qpd6=0):
     lens = (C.c_int * n)()
     _check(lib.HEVCImageEncoderBatch(n, P(*[o.ctypes.data_as(_u8p) for o in outs]), P(*[a.ctypes.data_as(_u8p) for a in imgs]),
                                      P(*[r.ctypes.data_as(_u8p) for r in rcons]), ys, xs, qv, lens), "HEVCImageEncoderBatch")
-    return [(outs[i][:lens[i]].tobytes(), rcons[i].reshape(ys[i], xs[i]), (ys[i], xs[i])) for i in range(n)]
+    return [(outs[i][:lens[i]].tobytes() if copy else outs[i][:lens[i]], rcons[i].reshape(ys[i], xs[i]), (ys[i], xs[i])) for i in range(n)]
 
 
 def writeHEVCImageFile(filename: str, buf: np.ndarray, is_rgb: bool, height: int, width: int, qpd6: int = 0) -> int:

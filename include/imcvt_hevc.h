@@ -68,6 +68,12 @@ int HEVCImageEncoderBatch(int n, unsigned char *const *pbuffers, const unsigned 
 
 /* Number of devices the last HEVCImageEncoderBatch / HEVCImageEncoder call used. */
 int imcvt_hevc_batch_devices(void);
+/* How the last host-pointer batch moved its data (any pointer may be NULL): seconds spent uploading the inputs (large batches go through pinned
+ * staging buffers filled by worker threads), seconds the calling thread followed the running launch (copying finished CTU rows of the
+ * reconstructions and finished stream bytes to the caller's buffers while the kernel ran), seconds collecting what was left once the launch had
+ * ended; bytes copied out while the launch ran / after it.  The reference's writeHEVCImageFile (src/imageio_hevc.c:14-52) has no counterpart:
+ * its encoder works in the caller's memory. */
+void imcvt_hevc_batch_transfer_stats(double *upload_s, double *follow_s, double *tail_s, double *bytes_during, double *bytes_after);
 /* Releases the contexts, streams and device memory the host-pointer entry points hold (they are re-created on the next call). */
 void imcvt_hevc_shutdown(void);
 
@@ -101,6 +107,14 @@ int imcvt_hevc_padded(int v);
  * launch; use one context per stream for concurrent launches.  The call makes the context's device current.
  * Returns 0 or a negative IMCVT_ERR_*. */
 int imcvt_hevc_encode_device(imcvt_hevc_ctx *ctx, int n, const imcvt_hevc_frame *frames, void *stream);
+
+/* Progress records for the frames of the NEXT launches of this context: `words` points at 2 x n 32-bit words (pinned host memory or device
+ * memory, zeroed by the caller), NULL turns the records off (the default).  While a launch runs the device keeps frame i's record current:
+ * words[2 i] = CTU rows (32 picture rows each) whose reconstruction in d_rcon is final, with bit 31 set once the frame is finished;
+ * words[2 i + 1] = leading bytes of d_out that are final.  Everything a record names has been written back from the device's caches, so a
+ * copy engine may read it while the kernel is still running — this is how the host-pointer entry points overlap their device-to-host copies
+ * with the launch.  Costs one cache write-back per CTU row of every frame. */
+void imcvt_hevc_set_progress(imcvt_hevc_ctx *ctx, unsigned int *words);
 
 /* Helper workgroups: 0 = chosen per launch (a frame per workgroup when the batch fills the device, else main
  * workgroups that walk the 8x8 CUs of their frames plus a pool of helper workgroups that evaluate the 16x16 / 32x32

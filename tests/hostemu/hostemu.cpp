@@ -164,6 +164,9 @@ static void emu_run(void (*entry)(void)) {
 
 static void emu_set_shm(int wg) { g_shm_host = g_shm_of[wg]; g_pipe_host = g_pipe_of[wg]; }
 static KArgs g_args;
+static u32 *g_prog; static int g_prog_n;
+// the progress record frame i of the last emulated launch ended with: word 0 (CTU rows | PROG_DONE), word 1 (stream bytes)
+extern "C" unsigned hostemu_prog(int i, int k) { return (g_prog && i >= 0 && i < g_prog_n && (k == 0 || k == 1)) ? g_prog[2 * i + k] : 0u; }
 static void emu_entry() { kernel_main(g_args, emu_block()); }
 
 // nhelp 0: `nmains` workgroups encode the frames alone (frames pulled one after the other); > 0: they hand the 16x16 / 32x32 candidate
@@ -178,6 +181,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     if (nwg > EMU_MAX_WG) return -1;
     FrameJob *jobs = (FrameJob *)calloc(n, sizeof(FrameJob));
     u8 *hdrs = (u8 *)calloc(n, HDR_MAX);
+    free(g_prog); g_prog = (u32 *)calloc((size_t)n, 2 * sizeof(u32)); g_prog_n = n;      // every emulated frame reports its progress (hevc_frame.h publish_progress)
     for (int i = 0; i < n; i++) {
         const int h = ysz[i], w = xsz[i];
         FrameJob &job = jobs[i];
@@ -185,6 +189,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
         job.hp = ((h < 8192 ? h : 8192) + 31) / 32 * 32; job.wp = ((w < 8192 ? w : 8192) + 31) / 32 * 32;
         job.hdr_len = imcvt::build_headers(hdrs + (size_t)HDR_MAX * i, qpd6, job.hp, job.wp);
         out_len[i] = 0; job.out_len = &out_len[i];
+        job.prog = g_prog + 2 * i;
         ysz[i] = job.hp; xsz[i] = job.wp;
     }
     Scratch sc[EMU_MAX_WG]; void *pool[EMU_MAX_WG];

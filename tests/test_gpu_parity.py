@@ -398,9 +398,10 @@ def test_bench_frames_sample_against_reference_digests(amd):
     enc = amd.DeviceEncoder()
     batch = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, s)).cuda() for s in seeds], 0)
     enc.encode(batch)
-    for s, (stream, _) in zip(seeds, enc.results(batch)):
+    for s, (stream, rcon) in zip(seeds, enc.results(batch)):
         e = kat["frames"][str(s)]
         assert len(stream) == e["bytes"] and hashlib.sha256(stream).hexdigest() == e["sha256"], s
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], s      # the reconstruction too (the table holds both)
     enc.close()
 
 

@@ -168,6 +168,10 @@ def test_launch_shape_policy(built):
     assert wide_pool(100, 200) == (1, 156)
     assert wide_pool(129, 258) == (0, 258)           # more main workgroups than that: 256-thread workgroups as planned
     assert wide_pool(128, 256, forced=1) == (0, 256) # a forced shape is never changed
+    assert wide_pool(81, 162) == (1, 162)            # 243 workgroups miss the 15/16 cap but fit the compute units: helpers are cut, never raised (advisor, round 5)
+    for mm in range(1, 129):
+        use, hh = wide_pool(mm, 2 * mm)
+        assert use == 1 and hh <= 2 * mm and mm + hh <= 256 and hh >= min(2 * mm, 256 - mm)
 
 
 def test_submission_queue_merges_concurrent_callers(built):
@@ -219,14 +223,14 @@ def test_submission_queue_merges_concurrent_callers(built):
         ys = (C.c_int * 3)(8, 8, 8); xs = (C.c_int * 3)(8, 8, 8); qv = (C.c_int * 3)(0, 1, 2); lens = (C.c_int * 3)()
         assert lib.HEVCImageEncoderBatch(3, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]), P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, qv, lens) == 0
         assert list(lens) == [140, 142, 144] and seen[-1] == 3
-        # a merged batch that fails is retried submission by submission: only the caller whose frame cannot be encoded sees the error
+        # a merged batch that fails on its ARGUMENTS (-3) is retried submission by submission: only the caller whose frame cannot be encoded sees the error
         failing = {"on": True}
 
         @C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(u8p), C.POINTER(u8p), ip, ip, ip, ip)
         def picky(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len):
             time.sleep(0.02)
             if any(imgs[i][0] == 7 for i in range(n)):
-                return -5
+                return -3
             for i in range(n):
                 out_len[i] = 200 + imgs[i][0]
             return 0
@@ -242,6 +246,28 @@ def test_submission_queue_merges_concurrent_callers(built):
         th = [threading.Thread(target=call2, args=(t,)) for t in range(12)]
         for t in th: t.start()
         for t in th: t.join()
-        assert res2[7] == -5 and all(res2[t] == 200 + t for t in range(12) if t != 7), res2
+        assert res2[7] == -3 and all(res2[t] == 200 + t for t in range(12) if t != 7), res2
+        # a device-wide failure (HIP error, watchdog, no device) reaches every caller of the round as it is: no relaunch per caller on a broken device
+        broken_calls = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(u8p), C.POINTER(u8p), ip, ip, ip, ip)
+        def broken(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len):
+            broken_calls.append(n)
+            time.sleep(0.05)
+            return -2
+
+        lib.imcvt_hevc_debug_set_backend(C.cast(broken, C.c_void_p))
+        res3 = {}
+
+        def call3(t):
+            img = np.full(64, t, np.uint8); out = np.zeros(16, np.uint8); rc = np.zeros(16, np.uint8)
+            ys, xs = C.c_int(8), C.c_int(8)
+            res3[t] = lib.HEVCImageEncoder(out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), rc.ctypes.data_as(u8p), C.byref(ys), C.byref(xs), 0)
+
+        th = [threading.Thread(target=call3, args=(t,)) for t in range(12)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert all(res3[t] == -2 for t in range(12)), res3
+        assert sum(broken_calls) == 12 and len(broken_calls) <= 4, broken_calls      # every frame handed to the device once, in a few merged rounds
     finally:
         lib.imcvt_hevc_debug_set_backend(None)

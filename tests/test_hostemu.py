@@ -26,6 +26,9 @@ def emu_encode(lib, img, q):
     ys, xs = C.c_int(h), C.c_int(w)
     n = lib.hostemu_HEVCImageEncoder(out.ctypes.data_as(u8p), np.ascontiguousarray(img).ctypes.data_as(u8p), rc.ctypes.data_as(u8p),
                                      C.byref(ys), C.byref(xs), q, None, 0)
+    # the frame's progress record (hevc_frame.h publish_progress: what the host-pointer path follows while a launch runs) ends on "all CTU rows, done, n bytes"
+    lib.hostemu_prog.restype = C.c_uint
+    assert lib.hostemu_prog(0, 0) == (min(hp, 8192) // 32 | 0x80000000) and lib.hostemu_prog(0, 1) == n
     return out[:n].tobytes(), rc.reshape(hp, wp)
 
 
@@ -213,6 +216,9 @@ def emu_encode_pool(lib, imgs, q, nmains, nhelp):
     lib.hostemu_HEVCImageEncoderPool.restype = C.c_int
     assert lib.hostemu_HEVCImageEncoderPool(n, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]),
                                             P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, q, lens, nmains, nhelp) == 0
+    lib.hostemu_prog.restype = C.c_uint
+    for i in range(n):
+        assert lib.hostemu_prog(i, 0) == (ys[i] // 32 | 0x80000000) and lib.hostemu_prog(i, 1) == lens[i], i
     return [(outs[i][:lens[i]].tobytes(), rcs[i]) for i in range(n)]
 
 
