@@ -4,8 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SRC = ["hevc_hip.hip"]
-DEPS = ["hevc_hip.hip", "hevc_core.h", "hevc_frame.h", "hevc_tables.h", os.path.join("..", "..", "include", "imcvt_hevc.h")]
+SRC = ["hevc_hip.hip", "hevc_wide.hip"]      # one object each (different code generation flags, below), linked into one library
+DEPS = ["hevc_hip.hip", "hevc_wide.hip", "hevc_core.h", "hevc_frame.h", "hevc_tables.h", os.path.join("..", "..", "include", "imcvt_hevc.h")]
 OUT = os.path.join(CSRC, "libimcvt_hevc.so")
 
 
@@ -25,7 +25,10 @@ def _run_to(cmd, out):
 # 168 registers they are spilled at once and reloaded inside the loops.  Without it: private segment 1008 -> 720 B per lane, HBM traffic
 # 5.8 -> 4.5 MB per CTU, same speed (A/B on one box, profiles/r03w2_licm_ab.log).
 KERNEL_FLAGS = ["-mllvm", "-disable-machine-licm"]
-BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# The instantiation for wide launches (hevc_wide.hip: 512-thread workgroups, 256 registers per wavefront) keeps machine LICM: what it hoists fits.
+WIDE_FLAGS = [f for f in os.environ.get("IMCVT_WIDE_FLAGS", "").split() if f]
+SRC_FLAGS = {"hevc_hip.hip": KERNEL_FLAGS, "hevc_wide.hip": WIDE_FLAGS}
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
 def _hipcc() -> str:
@@ -35,7 +38,7 @@ def _hipcc() -> str:
 def _source_hash(deps, flags) -> str:
     """sha256 over the sources a library is built from and the flags it is built with."""
     import hashlib
-    h = hashlib.sha256(" ".join([_hipcc(), *BASE_FLAGS, *flags]).encode())      # the whole command line, compiler path included
+    h = hashlib.sha256(" ".join([_hipcc(), *BASE_FLAGS, "-shared", *flags]).encode())      # the whole command line, compiler path included
     for d in deps:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
@@ -62,7 +65,10 @@ def _write_stamp(out, digest):
 
 
 def needs_build() -> bool:
-    return not _is_current(OUT, DEPS, KERNEL_FLAGS)
+    return not _is_current(OUT, DEPS, ALL_FLAGS)
+
+
+ALL_FLAGS = [*KERNEL_FLAGS, "|", *WIDE_FLAGS]      # what the library's stamp covers: both objects' flags
 
 
 JLS_OUT = os.path.join(CSRC, "libimcvt_jls.so")   # JPEG-LS (BASELINE config 5)
@@ -72,7 +78,7 @@ JLS_DEPS = ["jls_hip.hip", "jls_core.h", "jls_par.h", os.path.join("..", "..", "
 def build_jls(force: bool = False) -> str:
     if force or not _is_current(JLS_OUT, JLS_DEPS, []):
         digest = _source_hash(JLS_DEPS, [])
-        _run_to([_hipcc(), *BASE_FLAGS, os.path.join(CSRC, "jls_hip.hip")], JLS_OUT)
+        _run_to([_hipcc(), *BASE_FLAGS, "-shared", os.path.join(CSRC, "jls_hip.hip")], JLS_OUT)
         _write_stamp(JLS_OUT, digest)
     return JLS_OUT
 
@@ -100,11 +106,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         build_host()
         return OUT
-    digest = _source_hash(DEPS, KERNEL_FLAGS)
-    cmd = [_hipcc(), *BASE_FLAGS, *KERNEL_FLAGS, *[os.path.join(CSRC, s) for s in SRC]]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    _run_to(cmd, OUT)
+    digest = _source_hash(DEPS, ALL_FLAGS)
+    objs = []
+    try:
+        procs = []
+        for src in SRC:                                  # the two objects compile side by side (half a minute each)
+            obj = os.path.join(CSRC, f"{os.path.splitext(src)[0]}.tmp.{os.getpid()}.o")
+            objs.append(obj)
+            cmd = [_hipcc(), *BASE_FLAGS, *SRC_FLAGS[src], "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        _run_to([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs], OUT)
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
     _write_stamp(OUT, digest)
     build_host(force=True)
     return OUT

@@ -1573,6 +1573,8 @@ struct KArgs {
     int post16, post32;                         // per mille of the 16x16 / 32x32 CUs a main workgroup offers to the helpers
     int lim16, lim32, prio, quota;              // quota: workgroups per compute unit that start as main workgroups                     // pool tuning: unclaimed requests per shard beyond which a main workgroup keeps a CU (16x16 / 32x32); wave priority of the main workgroups
     int team_size, nteams, nhelp;               // team_size 1: every workgroup encodes whole frames alone; > 1: `nteams` main workgroups + a pool of `nhelp` helper workgroups
+    int role;                                   // pool launches: 0 roles by placement (one launch holds main and helper workgroups); 1 / 2: this launch holds the main / the helper workgroups of a
+                                                // pool that is spread over two cooperating launches (different workgroup sizes on disjoint sets of compute units, hevc_hip.hip launch_split)
 };
 #ifdef IMCVT_HOSTEMU
 HD int next_job(int *counter) { return (*counter)++; }
@@ -1630,7 +1632,9 @@ HD void kernel_main(const KArgs &A, int block) {
                 const int key = hw_cu_key() % POOL_CU_KEYS;
 #endif
                 int mid = -1;
-                if ((int)m_add32(&A.pq->cu_count[key], 1u) < A.quota && m_ld32(&A.pq->mains_taken) < (u32)nm) { const u32 m = m_add32(&A.pq->mains_taken, 1u); if (m < (u32)nm) mid = (int)m; }
+                // (a launch of main workgroups only: every workgroup takes an index while they last; of helpers only: none does — an idle helper may still take one later, helper_loop)
+                const int want = A.role == 1 ? 1 : A.role == 2 ? 0 : (int)m_add32(&A.pq->cu_count[key], 1u) < A.quota;
+                if (want && m_ld32(&A.pq->mains_taken) < (u32)nm) { const u32 m = m_add32(&A.pq->mains_taken, 1u); if (m < (u32)nm) mid = (int)m; }
                 SM.red[0] = mid;
             }
         }

@@ -27,12 +27,19 @@
 #endif
 __global__ __launch_bounds__(KERNEL_MAX_THREADS, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk) {
+                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
     A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.post16 = post16; A.post32 = post32; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio; A.quota = quota; A.fclk = fclk;
-    kernel_main(A, (int)blockIdx.x);
+    A.role = role;
+    kernel_main(A, (int)blockIdx.x + block0);
 }
+// the same kernel instantiated for wide launches (hevc_wide.hip: 256 registers per wavefront, built with loop-invariant code motion).  Weak: a library
+// linked from this file alone (the A/B and test variants, tools/gpu_variant.sh) runs its wide launches on the instantiation above.
+extern "C" __attribute__((weak)) int imcvt_wide_kernel_prepare(int *blocks_per_cu, int *scratch_bytes_per_lane);
+extern "C" __attribute__((weak)) void imcvt_wide_kernel_launch(int grid, void *stream, const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
+                                         const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
+                                         TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0);
 
 // ---------------------------------------------------------------------------------------------------
 struct imcvt_hevc_ctx {
@@ -59,6 +66,10 @@ struct imcvt_hevc_ctx {
     int census_wg = 0, census_pipe = 0;     // workgroups of a max_wg / pipe_wg launch that were resident at once when the context was created (0: not measured)
     int wide = -1, wide_wg = 0, occ_wide = 0, last_wide = 0;   // wide workgroups (512 threads: pipe wave + four partner wavefronts, one workgroup per compute unit): < 0 whenever a pipe-wave launch fits wide_wg workgroups, 0 never, 1 as -1
     int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
+    int wide_kernel = 0, wide_scratch = 0;  // wide launches run hevc_encode_frames_wide (hevc_wide.hip; IMCVT_HEVC_WIDE_KERNEL=0: the common instantiation), its private segment per lane
+    int split = 0, split_hpc = 0, last_split = 0;      // a pool spread over two cooperating launches (launch_split): < 0 where planned, 0 never, 1 as < 0; helper workgroups per compute unit of the helpers' set (0: default)
+    hipStream_t st_split[2] = { nullptr, nullptr }; int split_cus[2] = { 0, 0 };      // streams bound to two disjoint sets of compute units, and how many each holds
+    hipEvent_t ev_split[3] = { nullptr, nullptr, nullptr };
     u32 *prog = nullptr;                    // progress records of the next launches' frames, two words each (imcvt_hevc_set_progress), or null
 };
 
@@ -104,11 +115,20 @@ static int pool_limit(int nmains, int nhelp, int kind) {
 }
 // pipe: the workgroups carry a fourth wavefront (hevc_frame.h nxn_pipe) and its LDS slice; three such workgroups fit a CU
 // pipe 2: wide workgroups (512 threads: pipe wave + four partner wavefronts and their record queues), one per compute unit
-static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0) {
+// role / block0: 0 / 0 for a launch that holds the whole pool; a pool spread over two launches (launch_split) passes 1 / 0 for the main workgroups' and 2 / nmains for the helpers'
+// (block0: where this launch's workgroups start in the scratch table and among the queue shards)
+static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0, int role = 0, int block0 = 0, int split16 = -1, int split32 = -1) {
+    const int p16 = c->post16 >= 0 ? c->post16 : split16 >= 0 ? split16 : pool_split(nmains, nhelp, 0), p32 = c->post32 >= 0 ? c->post32 : split32 >= 0 ? split32 : pool_split(nmains, nhelp, 1);
+    const int l16 = c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), l32 = c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1);
+    const int prio = c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), quota = (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1);
+    if (pipe >= 2 && c->wide_kernel) {
+        imcvt_wide_kernel_launch(grid, (void *)stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs, (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof,
+                                 c->d_mail, c->d_pq, team_size, nmains, nhelp, p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0);
+        return;
+    }
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(pipe >= 2 ? WG_THREADS_WIDE : pipe ? WG_THREADS_PIPE : WG_THREADS), pipe >= 2 ? WIDE_LDS_BYTES : pipe ? PIPE_LDS_BYTES : 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
                        (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
-                       c->post16 >= 0 ? c->post16 : pool_split(nmains, nhelp, 0), c->post32 >= 0 ? c->post32 : pool_split(nmains, nhelp, 1),
-                       c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1), c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1), c->d_fclk);
+                       p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0);
 }
 
 // residency census: `grid` workgroups that count themselves, wait ~1 ms and record how many had started by then (kernel_main, team_size < 0)
@@ -151,6 +171,22 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     // wide workgroups: static + dynamic LDS exceed the 64 KB a kernel gets without asking
     if (hipFuncSetAttribute((const void *)hevc_encode_frames, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) != hipSuccess
         || hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_wide, hevc_encode_frames, WG_THREADS_WIDE, WIDE_LDS_BYTES) != hipSuccess || c->occ_wide < 1) { (void)hipGetLastError(); c->occ_wide = 0; }
+    {   // wide launches have an instantiation of their own (hevc_wide.hip); IMCVT_HEVC_WIDE_KERNEL=0 keeps them on the common one (A/B)
+        const char *e = getenv("IMCVT_HEVC_WIDE_KERNEL");
+        int nb = 0, sb = 0;
+        if (c->occ_wide > 0 && !(e && atoi(e) == 0) && imcvt_wide_kernel_prepare && imcvt_wide_kernel_launch && imcvt_wide_kernel_prepare(&nb, &sb) == 0) {
+            c->wide_kernel = 1; c->wide_scratch = sb;
+            if (nb < c->occ_wide) c->occ_wide = nb;
+            size_t cur = 0, mx = 0;      // its private segment may be the larger one: the scratch ring is sized for whichever kernel needs more
+            if (hipDeviceGetLimit(&cur, hipExtLimitScratchCurrent) == hipSuccess && hipDeviceGetLimit(&mx, hipExtLimitScratchMax) == hipSuccess) {
+                const size_t need = (size_t)sb * 64 * 32 * prop.multiProcessorCount + (64u << 20);
+                if (cur < need) (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, need < mx ? need : mx);
+            } else (void)hipGetLastError();
+            if (getenv("IMCVT_HEVC_VERBOSE")) fprintf(stderr, "imcvt_hevc: wide kernel: %d per compute unit, %d B/lane private segment\n", nb, sb);
+        }
+    }
+    if (const char *e = getenv("IMCVT_HEVC_SPLIT")) c->split = atoi(e);
+    if (const char *e = getenv("IMCVT_HEVC_SPLIT_HPC")) c->split_hpc = atoi(e);
     c->wide_wg = max_workgroups > 0 ? 0 : c->occ_wide * prop.multiProcessorCount;      // (a context with an explicit workgroup budget plans without them)
     if (const char *e = getenv("IMCVT_HEVC_WIDE")) c->wide = atoi(e);
     c->max_wg = max_workgroups > 0 ? max_workgroups : c->occ_wg * prop.multiProcessorCount;
@@ -195,6 +231,11 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
             if (good) launch(c, c->max_wg, 0, 0, 1, 0, 0);
             good = good && hipDeviceSynchronize() == hipSuccess;
         }
+        if (good && c->wide_kernel && c->wide_wg > 0) {      // the wide instantiation's private segment too, before real work arrives
+            good = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;
+            if (good) launch(c, c->wide_wg, 0, 0, 1, 0, 0, 2);
+            good = good && hipDeviceSynchronize() == hipSuccess;
+        }
         return good;
     };
     if (!getenv("IMCVT_HEVC_NO_PREWARM")) {
@@ -225,6 +266,8 @@ extern "C" void imcvt_hevc_destroy(imcvt_hevc_ctx *c) {
     if (c->h_hdrs) hipHostFree(c->h_hdrs);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (int i = 0; i < 2; i++) if (c->st_split[i]) hipStreamDestroy(c->st_split[i]);
+    for (int i = 0; i < 3; i++) if (c->ev_split[i]) hipEventDestroy(c->ev_split[i]);
     delete c;
 }
 
@@ -252,6 +295,44 @@ extern "C" int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shap
     if (*nhelp > wide_wg - *nmains) *nhelp = wide_wg - *nmains;      // (cut, never raised: a plan that already fits the compute units keeps its helper count)
     return 1;
 }
+// A pool spread over TWO cooperating launches (round 6).  One launch has one workgroup size, so a pool whose main workgroups are wide (a compute unit
+// each) has wide helpers too — one per compute unit, and a pool of 81 .. 128 main workgroups is left with fewer than two helpers each: 128 frames, one
+// GPU's share of BASELINE configs[3] at N = 4, ran 128 + 128 wide workgroups, every main workgroup keeping a third of its 16x16 CUs for itself
+// (profiles/r05s_wide_128f_shapes.log).  The pool's protocol lives in global memory and does not care which launch a workgroup belongs to
+// (hevc_frame.h: roles, mail, queues), so such a pool runs as two launches on two streams bound to disjoint sets of compute units
+// (hipExtStreamCreateWithCUMask): `nmains` wide main workgroups on as many compute units, and 192-thread helper workgroups, `hpc` per compute unit,
+// on the others.  Nothing depends on a workgroup that is not running (a main workgroup posts requests only once a helper has reported in), so the
+// order in which the two launches become resident costs time at most.
+// pure: returns 1 and the helper count if a pool of nmains main workgroups (mode = what imcvt_hevc_plan returned) should run split on a device of
+// `cus` compute units that holds wide_wg wide and occ_wg 192-thread workgroups per compute unit; hpc: helper workgroups per compute unit (0: default)
+extern "C" int imcvt_hevc_plan_split(int mode, int nmains, int cus, int wide_wg, int occ_wg, int hpc, int *nhelp) {
+    if (mode != 2 || nmains < 1 || cus < 2 || wide_wg < cus - cus / 16 || occ_wg < 1) return 0;      // (nearly every compute unit must be able to hold a wide workgroup)
+    if (imcvt_hevc_plan_wide(1, 3 * nmains, wide_wg, 0)) return 0;       // two wide helpers per main workgroup fit: one launch
+    if (2 * nmains > cus) return 0;                                       // (beyond half of the compute units the helpers' half cannot keep up: 256-thread workgroups as planned)
+    if (hpc < 1) hpc = 3;
+    if (hpc > occ_wg) hpc = occ_wg;
+    int h = (cus - nmains) * hpc;
+    if (h > 4 * nmains) h = 4 * nmains;                                   // (a main workgroup has two requests out at most; the rest would only poll)
+    if (h < nmains) return 0;
+    if (nhelp) *nhelp = h;
+    return 1;
+}
+// streams bound to the first `cus_a` compute units and to the rest (cached: the masks only change with the number of main workgroups)
+static int split_streams(imcvt_hevc_ctx *c, int cus_a) {
+    if (c->st_split[0] && c->split_cus[0] == cus_a) return 0;
+    for (int i = 0; i < 2; i++) if (c->st_split[i]) { (void)hipStreamSynchronize(c->st_split[i]); (void)hipStreamDestroy(c->st_split[i]); c->st_split[i] = nullptr; }
+    const int words = (c->cus + 31) / 32;
+    std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
+    // (the driver deals the mask's bits out over XCDs, then shader engines, then arrays: a run of consecutive bits is spread evenly over the device)
+    for (int i = 0; i < c->cus; i++) (i < cus_a ? ma : mb)[(size_t)(i / 32)] |= 1u << (i % 32);
+    HIPCHK(hipExtStreamCreateWithCUMask(&c->st_split[0], (uint32_t)words, ma.data()));
+    HIPCHK(hipExtStreamCreateWithCUMask(&c->st_split[1], (uint32_t)words, mb.data()));
+    for (int i = 0; i < 3; i++) if (!c->ev_split[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_split[i], hipEventDisableTiming));
+    c->split_cus[0] = cus_a; c->split_cus[1] = c->cus - cus_a;
+    return 0;
+}
+extern "C" void imcvt_hevc_set_split(imcvt_hevc_ctx *c, int mode, int helpers_per_cu) { if (c) { c->split = mode; c->split_hpc = helpers_per_cu; } }
+extern "C" int imcvt_hevc_last_split(imcvt_hevc_ctx *c) { return c ? c->last_split : IMCVT_ERR_ARG; }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
 extern "C" int imcvt_hevc_last_team(imcvt_hevc_ctx *c, int *nteams) {
     if (!c) return IMCVT_ERR_ARG;
@@ -356,13 +437,18 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     }
     int nmains = 0, nhelp = 0, forced = 0;
     const int mode = pick_shape(c, n, &nmains, &nhelp, &forced);
+    int use_split = 0, split_help = 0;
+    if (mode == 2 && !forced && c->force_team == 0 && c->pipe != 0 && c->wide != 0 && c->split != 0)
+        use_split = imcvt_hevc_plan_split(mode, nmains, c->cus, c->wide_wg, c->occ_wg, c->split_hpc, &split_help) && nmains + split_help <= c->max_wg;
     int use_pipe = (mode > 0 && c->pipe != 0) ? plan_pipe_wg(mode, c->max_wg, c->pipe_wg, forced, &nmains, &nhelp) : 0;
     int use_wide = 0;
+    if (use_split) { nhelp = split_help; use_pipe = 1; }
     if (mode > 0 && c->pipe != 0 && c->wide != 0) {      // (a pool too large for 256-thread workgroups with its planned helpers may still fit wide ones with fewer)
         int h2 = nhelp;
-        use_wide = imcvt_hevc_plan_wide_pool(1, mode, forced, c->wide_wg, &nmains, &h2);
-        if (use_wide) { nhelp = h2; use_pipe = 1; }
+        use_wide = use_split ? 1 : imcvt_hevc_plan_wide_pool(1, mode, forced, c->wide_wg, &nmains, &h2);
+        if (use_wide && !use_split) { nhelp = h2; use_pipe = 1; }
     }
+    if (use_split && split_streams(c, nmains) != 0) { (void)hipGetLastError(); return IMCVT_ERR_HIP; }
     const int grid = nmains + nhelp;
     if (mode <= 0 || grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) {
         fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap);
@@ -400,10 +486,22 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     c->last_mains = nmains; c->last_help = nhelp;
     c->last_pipe = use_pipe;
     c->last_wide = use_wide;
+    c->last_split = use_split;
 
     HIPCHK(hipEventRecord(c->ev0, stream));
+    if (use_split) {          // the main workgroups (wide) on their compute units, the helpers (192 threads) on the others; both end before `stream` goes on
+        HIPCHK(hipEventRecord(c->ev_split[0], stream));
+        HIPCHK(hipStreamWaitEvent(c->st_split[0], c->ev_split[0], 0)); HIPCHK(hipStreamWaitEvent(c->st_split[1], c->ev_split[0], 0));
+        const int all = nhelp >= 2 * nmains ? 1000 : -1;      // two helpers per main workgroup: everything is offered
+        launch(c, nmains, c->st_split[0], n, mode, nmains, nhelp, 2, 1, 0, all, all);
+        launch(c, nhelp, c->st_split[1], n, mode, nmains, nhelp, 0, 2, nmains, all, all);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev_split[1], c->st_split[0])); HIPCHK(hipEventRecord(c->ev_split[2], c->st_split[1]));
+        HIPCHK(hipStreamWaitEvent(stream, c->ev_split[1], 0)); HIPCHK(hipStreamWaitEvent(stream, c->ev_split[2], 0));
+    } else {
     launch(c, grid, stream, n, mode, nmains, nhelp, c->last_wide ? 2 : c->last_pipe);
     HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return 0;

@@ -28,7 +28,7 @@ EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "i
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
            "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_plan_wide_pool", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
            "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats",
-           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats")
+           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats", "imcvt_hevc_set_split", "imcvt_hevc_last_split", "imcvt_hevc_plan_split")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -135,6 +135,12 @@ def load_library():
         lib.imcvt_hevc_set_progress.argtypes = [C.c_void_p, C.c_void_p]
         lib.imcvt_hevc_batch_transfer_stats.restype = None
         lib.imcvt_hevc_batch_transfer_stats.argtypes = [C.POINTER(C.c_double)] * 5
+        lib.imcvt_hevc_set_split.restype = None
+        lib.imcvt_hevc_set_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.imcvt_hevc_last_split.restype = C.c_int
+        lib.imcvt_hevc_last_split.argtypes = [C.c_void_p]
+        lib.imcvt_hevc_plan_split.restype = C.c_int
+        lib.imcvt_hevc_plan_split.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]
     _lib = lib
     return lib
 
@@ -247,6 +253,14 @@ class DeviceEncoder:
         """Wide workgroups (512 threads, split trial coders): -1 automatic, 0 never, 1 wherever they fit.  Results are identical."""
         if hasattr(self.lib, "imcvt_hevc_set_wide"):
             self.lib.imcvt_hevc_set_wide(self.ctx, int(mode))
+
+    def set_split(self, mode: int, helpers_per_cu: int = 0):
+        """A pool as two cooperating launches (wide main workgroups + 192-thread helpers on disjoint compute units): 0 never, 1 / -1 where planned."""
+        self.lib.imcvt_hevc_set_split(self.ctx, int(mode), int(helpers_per_cu))
+
+    def last_split(self) -> bool:
+        """True if the last launch was such a pair of launches."""
+        return int(self.lib.imcvt_hevc_last_split(self.ctx)) == 1
 
     def last_wide(self) -> bool:
         """True if the last launch ran wide workgroups."""

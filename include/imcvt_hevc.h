@@ -142,6 +142,16 @@ int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape);
  * returned): a pool that does not fit as planned still runs wide when its main workgroups take at most half of the `wide_wg`
  * workgroups — *nhelp is cut to the rest.  Returns 1 if the launch runs wide workgroups. */
 int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shape, int wide_wg, const int *nmains, int *nhelp);
+/* A pool spread over two cooperating launches: wide main workgroups (512 threads, a compute unit each) on one set of compute units, 192-thread
+ * helper workgroups, several per compute unit, on the others (streams with disjoint compute-unit masks) — for pools of 81 .. 128 main workgroups,
+ * whose wide shape in ONE launch leaves every main workgroup fewer than two (wide) helpers.  mode 0 (default): never; < 0 / 1: wherever
+ * imcvt_hevc_plan_split says; helpers_per_cu 0: default (3).  Results are identical.  Environment at context creation: IMCVT_HEVC_SPLIT, IMCVT_HEVC_SPLIT_HPC. */
+void imcvt_hevc_set_split(imcvt_hevc_ctx *ctx, int mode, int helpers_per_cu);
+/* 1 if the last launch was such a pair of launches, else 0. */
+int imcvt_hevc_last_split(imcvt_hevc_ctx *ctx);
+/* Pure: should a pool of nmains main workgroups (mode = what imcvt_hevc_plan returned) run as two launches on a device of `cus` compute units that
+ * holds wide_wg wide workgroups and occ_wg 192-thread workgroups per compute unit?  Returns 1 and the helper count in *nhelp. */
+int imcvt_hevc_plan_split(int mode, int nmains, int cus, int wide_wg, int occ_wg, int helpers_per_cu, int *nhelp);
 /* That choice as a pure function (no device needed), applied to the shape imcvt_hevc_plan returned (mode = its return value; *nmains,
  * *nhelp = its outputs): returns 1 if the launch runs 256-thread workgroups with the pipe wave — it does when it fits 15/16 of three
  * workgroups per compute unit (max_workgroups * 3 / 4), and a pool that misses that by little gives up helpers for it (*nhelp is

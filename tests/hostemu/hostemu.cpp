@@ -167,7 +167,9 @@ static KArgs g_args;
 static u32 *g_prog; static int g_prog_n;
 // the progress record frame i of the last emulated launch ended with: word 0 (CTU rows | PROG_DONE), word 1 (stream bytes)
 extern "C" unsigned hostemu_prog(int i, int k) { return (g_prog && i >= 0 && i < g_prog_n && (k == 0 || k == 1)) ? g_prog[2 * i + k] : 0u; }
-static void emu_entry() { kernel_main(g_args, emu_block()); }
+static int g_role_split;      // 1: the emulated pool is "two launches" — blocks below nteams are a launch of main workgroups (role 1), the others a launch of helpers (role 2)
+extern "C" void hostemu_set_role_split(int on) { g_role_split = on; }
+static void emu_entry() { KArgs a = g_args; if (g_role_split && a.nhelp > 0) a.role = emu_block() < a.nteams ? 1 : 2; kernel_main(a, emu_block()); }
 
 // nhelp 0: `nmains` workgroups encode the frames alone (frames pulled one after the other); > 0: they hand the 16x16 / 32x32 candidate
 // sets to a pool of `nhelp` helper workgroups (hevc_frame.h)
@@ -205,7 +207,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     memset(pq, 0, sizeof(PoolQ));
     int counter[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     g_args.gT = &T; g_args.gK = &K; g_args.jobs = jobs; g_args.hdrs = hdrs; g_args.njobs = n; g_args.scr = sc; g_args.counter = counter;
-    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.post16 = 750; g_args.post32 = 1000; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0; g_args.quota = getenv("HOSTEMU_QUOTA") ? atoi(getenv("HOSTEMU_QUOTA")) : 1; g_args.fclk = nullptr;      // (quota 0: no workgroup starts as a main one — idle helpers take the roles)
+    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.post16 = 750; g_args.post32 = 1000; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0; g_args.quota = getenv("HOSTEMU_QUOTA") ? atoi(getenv("HOSTEMU_QUOTA")) : 1; g_args.fclk = nullptr; g_args.role = 0;      // (quota 0: no workgroup starts as a main one — idle helpers take the roles)
     g_nfib = nwg * EMU_WG_THREADS; g_spins = 0;
     emu_run(emu_entry);
     for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); free(g_pipe_of[b]); }

@@ -543,3 +543,75 @@ def test_pool_launch_beside_a_co_tenant_kernel(amd):
     if os.path.isdir(out):
         open(os.path.join(out, "cotenant_test.log"), "w").write(f"512+448 workgroups, 512 x 160x96 q0: alone {base_ms:.1f} ms; beside 96 co-tenant workgroups (100 KB LDS each, 400 ms): {[round(v, 1) for v in ms]} ms; resident {enc.last_resident()}\n")
     enc.close()
+
+
+def test_pool_as_two_launches_gives_identical_streams(amd):
+    """A pool spread over TWO cooperating launches (hevc_hip.hip imcvt_hevc_plan_split: wide main workgroups on their own compute units, 192-thread
+    helper workgroups on the others, streams with disjoint compute-unit masks): 96 frames with two, three and four helpers per compute unit give what
+    one launch gives, and the CPU checker's bytes."""
+    import torch
+    from oracle import oracle, synth
+    imgs = [synth.syn(64 + 32 * (s % 3), 64 + 32 * (s % 2), 100 + s) for s in range(96)]
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch([torch.from_numpy(a).cuda() for a in imgs], 0)
+    enc.encode(batch); ref = enc.results(batch)
+    assert not enc.last_split()
+    for i in (0, 37, 95):
+        ws, wr, _ = oracle.cpu_encode(imgs[i], 0)
+        assert ref[i][0] == ws and (ref[i][1] == wr).all(), i
+    for hpc in (2, 3, 4):
+        enc.set_split(1, hpc)
+        enc.encode(batch); got = enc.results(batch)
+        assert enc.last_split() and enc.last_wide() and enc.last_shape() == (96, min(160 * hpc, 384)), (hpc, enc.last_shape())
+        for i, ((s, r), (s2, r2)) in enumerate(zip(got, ref)):
+            assert s == s2 and (r == r2).all(), (hpc, i)
+    enc.set_split(0)
+    enc.encode(batch)
+    assert not enc.last_split()
+    enc.close()
+
+
+def test_wide_kernel_instantiations_agree(amd, monkeypatch):
+    """Wide launches run hevc_wide.hip's instantiation of the kernel (256 registers per wavefront, loop-invariant code motion on); with
+    IMCVT_HEVC_WIDE_KERNEL=0 the common instantiation.  Same bytes: a natural picture alone (1 main + 2 helper workgroups, all wide)."""
+    import torch
+    e = next(e for e in SMALL if e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] == 0)
+    img = torch.from_numpy(kat_input(e["input"])).cuda()
+    out = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("IMCVT_HEVC_WIDE_KERNEL", knob)
+        enc = amd.DeviceEncoder()
+        b = enc.make_batch([img], 0)
+        enc.encode(b)
+        (s, r), = enc.results(b)
+        assert enc.last_wide()
+        out.append((s, r))
+        enc.close()
+    assert out[0][0] == out[1][0] and (out[0][1] == out[1][1]).all()
+    assert hashlib.sha256(out[0][0]).hexdigest() == e["sha256"] and hashlib.sha256(out[0][1].tobytes()).hexdigest() == e["rcon_sha256"]
+
+
+def test_host_batch_follows_the_running_launch(amd, monkeypatch):
+    """The host-pointer entry point with a batch large enough for its round-6 transfers: inputs through pinned staging buffers (>= 32 MB), finished CTU
+    rows of the reconstructions and finished stream bytes copied to the caller's buffers WHILE the launch runs (per-frame progress records,
+    hevc_frame.h publish_progress).  Same streams and reconstructions as the plain path (copies, launch, copies), most bytes moved during the launch."""
+    from imcvt_amd import hevc
+    from oracle import oracle, synth
+    lib = amd.load_library()
+    imgs = [synth.syn(1024, 1024 - 8 * (s % 3), 300 + s) for s in range(36)]
+    lib.imcvt_hevc_shutdown()
+    a = amd.HEVCImageEncoderBatch(imgs, 1)
+    xs = hevc.transfer_stats()
+    assert xs["bytes_during"] > 0.5 * (xs["bytes_during"] + xs["bytes_after"]), xs
+    total = sum(len(s) + r.size for s, r, _ in a)
+    assert xs["bytes_during"] + xs["bytes_after"] == total, (xs, total)
+    monkeypatch.setenv("IMCVT_HEVC_PLAIN_COPIES", "1")
+    b = amd.HEVCImageEncoderBatch(imgs, 1)
+    xs2 = hevc.transfer_stats()
+    assert xs2["bytes_during"] == 0 and xs2["bytes_after"] == total
+    monkeypatch.delenv("IMCVT_HEVC_PLAIN_COPIES")
+    for i in range(len(imgs)):
+        assert a[i][0] == b[i][0] and (a[i][1] == b[i][1]).all() and a[i][2] == b[i][2], i
+    ws, wr, dims = oracle.cpu_encode(imgs[7], 1)
+    assert a[7][0] == ws and (a[7][1] == wr).all() and a[7][2] == dims
+    lib.imcvt_hevc_shutdown()

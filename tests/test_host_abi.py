@@ -71,9 +71,15 @@ def test_shipped_kernel_uses_the_matrix_cores(built, tmp_path):
     so = tmp_path / "libimcvt_hevc.so"
     shutil.copy(os.path.join(ROOT, "imcvt_amd", "csrc", "libimcvt_hevc.so"), so)
     subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True)
-    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
-    assert len(co) == 1, os.listdir(tmp_path)
-    asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / co[0])], check=True, capture_output=True, text=True).stdout
+    co = sorted(f for f in os.listdir(tmp_path) if "gfx950" in f)
+    assert len(co) == 2, os.listdir(tmp_path)          # hevc_hip.hip's (every launch shape) and hevc_wide.hip's (wide launches: 256 registers per wavefront)
+    asms = [subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout for f in co]
+    assert sum("hevc_encode_frames_wide" in a for a in asms) == 1
+    for asm in asms:
+        _check_code_object(asm)
+
+
+def _check_code_object(asm):
     assert asm.count("v_mfma_i32_32x32x32_i8") >= 9 and asm.count("v_mfma_i32_16x16x32_i8") >= 36, (asm.count("v_mfma_i32_32x32x32_i8"), asm.count("v_mfma_i32_16x16x32_i8"))
     # The candidate-set functions are out of line and use every vector register; none of their callers keeps anything in a
     # callee-saved one, and the backend drops the saves once no call site carries LLVM's `tail` marker (HDN, hevc_core.h).
@@ -172,6 +178,26 @@ def test_launch_shape_policy(built):
     for mm in range(1, 129):
         use, hh = wide_pool(mm, 2 * mm)
         assert use == 1 and hh <= 2 * mm and mm + hh <= 256 and hh >= min(2 * mm, 256 - mm)
+
+
+def test_split_launch_policy(built):
+    """imcvt_hevc_plan_split is pure: a pool runs as two cooperating launches (wide main workgroups on their own compute units, 192-thread helpers on
+    the others) only where the one-launch wide shape would leave a main workgroup fewer than two helpers and the helpers' compute units can keep up."""
+    import imcvt_amd
+    lib = imcvt_amd.load_library()
+
+    def split(m, cus=256, wide_wg=256, occ=4, hpc=0, mode=2):
+        h = C.c_int(-1)
+        return lib.imcvt_hevc_plan_split(mode, m, cus, wide_wg, occ, hpc, C.byref(h)), h.value
+
+    assert split(64) == (0, -1) and split(80) == (0, -1)              # 3 x 80 = 240 wide workgroups fit one launch
+    assert split(81) == (1, 324) and split(128) == (1, 384)           # (256 - m) compute units x 3 helpers, at most four per main workgroup
+    assert split(128, hpc=2) == (1, 256) and split(128, hpc=4) == (1, 512) and split(128, hpc=9) == (1, 512)
+    assert split(129) == (0, -1)                                       # beyond half of the compute units: as planned
+    assert split(100, mode=1) == (0, -1) and split(100, wide_wg=200) == (0, -1) and split(100, wide_wg=250)[0] == 1      # no pool / fewer wide workgroups resident than compute units
+    for m in range(1, 300):
+        use, h = split(m)
+        assert use in (0, 1) and (not use or (m <= h <= 4 * m and m + (h + 2) // 3 <= 256))
 
 
 def test_submission_queue_merges_concurrent_callers(built):

@@ -236,6 +236,21 @@ def test_pool_modes_match_golden(hostemu, q, nmains, nhelp):
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
 
 
+@pytest.mark.parametrize("nmains,nhelp", [(1, 2), (3, 2), (2, 4)])
+def test_pool_as_two_launches_matches_golden(hostemu, nmains, nhelp):
+    """A pool spread over two cooperating launches (hevc_hip.hip launch of role 1 / role 2 workgroups: the main workgroups in one, the
+    helpers in the other): roles come from the launch, not from where a workgroup landed; same bytes."""
+    es = [e for e in OVF if e["qpd6"] == 0]
+    hostemu.hostemu_set_role_split(1)
+    try:
+        res = emu_encode_pool(hostemu, [kat_input(e["input"]) for e in es], 0, nmains, nhelp)
+    finally:
+        hostemu.hostemu_set_role_split(0)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
 @pytest.mark.parametrize("nmains,nhelp", [(1, 2), (2, 3), (1, 0), (3, 0)])
 @pytest.mark.parametrize("q", [0, 4])
 def test_pipe_wave_with_and_without_helpers(hostemu_pipe, q, nmains, nhelp):

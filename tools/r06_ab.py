@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Round-6 A/B probe on one box (interleaved launches, kernel ms from HIP events):
+  wide   one 1080p frame and 64 frames: wide launches on hevc_wide.hip's instantiation (256 registers per wavefront) vs the common one
+  split  128 frames: one launch (128 + 128 wide workgroups) vs two cooperating launches (128 wide mains + 192-thread helpers, 2 / 3 / 4 per compute unit)
+usage: python tools/r06_ab.py [wide] [split] [--reps 3]"""
+import hashlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import imcvt_amd
+from imcvt_amd import synth
+
+reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
+what = [a for a in sys.argv[1:] if not a.startswith("-") and not a.isdigit()] or ["wide", "split"]
+dev = torch.device("cuda", 0)
+gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bench512_kat.json")))["frames"]
+
+
+def frames(n):
+    return [torch.from_numpy(synth.syn(1920, 1080, s)).to(dev) for s in range(n)]
+
+
+def check(b, n):
+    lens = b["lens"].cpu().tolist()
+    for i in (0, n // 2, n - 1):
+        e = gold[str(i)]
+        assert lens[i] == e["bytes"] and hashlib.sha256(b["outs"][i][:lens[i]].cpu().numpy().tobytes()).hexdigest() == e["sha256"], i
+
+
+if "wide" in what:
+    encs = {}
+    for knob in ("1", "0"):
+        os.environ["IMCVT_HEVC_WIDE_KERNEL"] = knob
+        encs[knob] = imcvt_amd.DeviceEncoder()
+    del os.environ["IMCVT_HEVC_WIDE_KERNEL"]
+    for n in (1, 64):
+        imgs = frames(n)
+        bs = {k: e.make_batch(imgs, 0) for k, e in encs.items()}
+        res = {k: [] for k in encs}
+        for r in range(reps):
+            for k, e in encs.items():
+                e.encode(bs[k]); torch.cuda.synchronize(); res[k].append(round(e.last_kernel_ms(), 1))
+        for k in encs:
+            check(bs[k], n)
+        print(json.dumps({"probe": "wide_kernel", "frames": n, "wide_instantiation_ms": res["1"], "common_instantiation_ms": res["0"], "shape": list(encs["1"].last_shape()), "wide": encs["1"].last_wide()}), flush=True)
+        del bs, imgs
+    for e in encs.values():
+        e.close()
+
+if "split" in what:
+    enc = imcvt_amd.DeviceEncoder()
+    for n in (128, 96, 112):
+        imgs = frames(n)
+        b = enc.make_batch(imgs, 0)
+        res = {}
+        for r in range(reps):
+            for hpc in (0, 2, 3, 4):
+                enc.set_split(1 if hpc else 0, hpc)
+                enc.encode(b); torch.cuda.synchronize()
+                res.setdefault(hpc, []).append((round(enc.last_kernel_ms(), 1), enc.last_split(), enc.last_shape()))
+                check(b, n)
+        print(json.dumps({"probe": "split_launch", "frames": n, **{("one_launch" if h == 0 else f"split_{h}_per_cu"): {"ms": [v[0] for v in res[h]], "split": res[h][0][1], "shape": list(res[h][0][2])} for h in res}}), flush=True)
+        del b, imgs
+    enc.close()
