@@ -339,13 +339,14 @@ def solo_view(enc, big, digests, qpd6, n=1000):
     enc.encode(b); torch.cuda.synchronize()
     enc.encode(b); torch.cuda.synchronize()
     ms = enc.last_kernel_ms()
+    resident, spread = enc.last_resident(), enc.last_start_spread_us()      # (a launch that fills the device to 97 % has been seen to start a workgroup seconds late)
     enc.set_team(0)
     lens = b["lens"].cpu().tolist()
     same = all(hashlib.sha256(b["outs"][i][:lens[i]].cpu().numpy().tobytes()).hexdigest() == digests[i % F] for i in list(range(0, n, 37)) + [n - 1])
     if not same:
         raise SystemExit("solo_1000f: streams differ from the timed batch's")
     return {"frames": n, "kernel_ms": round(ms, 1), "mpx_s": round(n * W * H / ms / 1e3, 3), "shape": list(enc.last_shape()),
-            "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
+            "resident_at_once": resident, "start_spread_us": spread, "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
 
 
 def share_view(enc, big, qpd6, k512):

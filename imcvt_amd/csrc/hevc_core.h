@@ -345,7 +345,10 @@ static inline void scratch_carve(Scratch &sc, u8 *base) {
 // (:196-257), so they do not depend on the CU's children: helper workgroups evaluate them while the main workgroup walks
 // the 8x8 CUs.  Requests and results travel through one mailbox per request kind in global memory.
 // ---------------------------------------------------------------------------------------------------
-enum { SLOT_16 = 0, SLOT_32 = 1, MAIL_SLOTS = 2 };
+// SLOT_16 / SLOT_32: requests that go through the pool's queues (POOL_KINDS of them).  SLOT_8 (round 6, wide launches): the mailbox between a main workgroup and
+// its PARTNER workgroup — the two 2Nx2N candidate sets of every 8x8 CU on a second compute unit (hevc_frame.h "8x8 CUs with a partner workgroup"); no queue, the
+// partner serves one main workgroup.
+enum { SLOT_16 = 0, SLOT_32 = 1, POOL_KINDS = 2, SLOT_8 = 2, MAIL_SLOTS = 3 };
 enum { OP_WORK = 0, OP_EXIT = 1 };
 struct alignas(16) HelpReq {                     // main -> helper: everything the candidate sets of one CU start from
     i32 op, frame, cy, cx;                       // job index, CTU origin
@@ -393,9 +396,9 @@ struct TeamMail { MailSlot s[MAIL_SLOTS]; };
 #define POOL_CU_KEYS 4096     // XCC (4 bits) | shader engine (3) | shader array (1) | CU (4)
 #define POOL_QCAP 256        // per shard and kind: >= 2 x the main workgroups that share a shard (POOL_SHARDS x POOL_QCAP / 2 = 2048 mains)
 struct alignas(256) PoolShard {
-    u32 head[MAIL_SLOTS], tail[MAIL_SLOTS];      // tickets claimed / issued, per request kind
+    u32 head[POOL_KINDS], tail[POOL_KINDS];      // tickets claimed / issued, per request kind
     u32 pad_[60];
-    u32 ring[MAIL_SLOTS][POOL_QCAP];             // ticket -> (ticket mod 2^20) << 12 | main workgroup index + 1 (0: nothing published yet)
+    u32 ring[POOL_KINDS][POOL_QCAP];             // ticket -> (ticket mod 2^20) << 12 | main workgroup index + 1 (0: nothing published yet)
 };
 struct alignas(256) PoolQ {
     u32 frames_done;                             // frames finished: helpers leave when all are (no request can follow)
@@ -404,7 +407,9 @@ struct alignas(256) PoolQ {
     u32 progress;                                // sum over the main workgroups of the share of their frames they have finished, in 1/65536 frames (pace control)
     u32 abort;                                   // watchdog: a wait between workgroups exceeded WD_TICKS — every wait gives up, every workgroup leaves (host: IMCVT_ERR_WATCHDOG)
     u32 dbg[8];                                  // what the wait that gave up was waiting for
-    u32 pad_[51];
+    u32 pad_[8];                                 // (the watchdog's clocks, hevc_frame.h wd_poll)
+    u32 parts_taken;                             // partner-workgroup indices handed out so far (partner i serves main workgroup i)
+    u32 pad2_[42];
     PoolShard sh[POOL_SHARDS];
     u32 cu_count[POOL_CU_KEYS];                  // workgroups of this launch that have started on each compute unit (role choice, hevc_frame.h kernel_main)
 };
@@ -419,16 +424,18 @@ struct FrameCtx {
     PoolQ *pq;          // the launch's request queues
     i32 main_id;        // index of this main workgroup (= of its mailboxes)
     i32 prio_base;      // wave priority of this workgroup outside its critical sections (2: main workgroup of a team, 0 otherwise)
-    i32 lim[MAIL_SLOTS];   // a request of this kind is only posted while fewer than this many wait unclaimed in the workgroup's shard (else the CU is evaluated here)
-    i32 post_pm[MAIL_SLOTS], post_acc[MAIL_SLOTS];   // share of the CUs of a kind that is offered to the helpers at all, per mille, and its running remainder
+    i32 lim[POOL_KINDS];   // a request of this kind is only posted while fewer than this many wait unclaimed in the workgroup's shard (else the CU is evaluated here)
+    i32 post_pm[POOL_KINDS], post_acc[POOL_KINDS];   // share of the CUs of a kind that is offered to the helpers at all, per mille, and its running remainder
     i32 posted[3];      // the CU of depth 0 / 1 being walked has a request out
-    i32 stale[MAIL_SLOTS], gaveup;   // sequence number of a request this workgroup stopped waiting for (its mailbox is not reused before that answer has arrived); the last wait gave up
+    i32 stale[POOL_KINDS], gaveup;   // sequence number of a request this workgroup stopped waiting for (its mailbox is not reused before that answer has arrived); the last wait gave up
     i32 kept;           // CUs of this frame evaluated here because the helpers were busy (debug statistic)
     i32 aborted;        // the launch's watchdog has fired (read once per CTU and after every wait)
-    unsigned long long hb_last, hb_gap, hb_when;   // heartbeat (debug): clock of the last beat, longest gap between two beats and when it began
+#ifdef IMCVT_HB
+    unsigned long long hb_last, hb_gap, hb_when;   // heartbeat (debug, -DIMCVT_HB builds): clock of the last beat, longest gap between two beats and when it began
+#endif
     u32 waited, waited_max;   // 100 MHz ticks this frame's main workgroup spent waiting for answers, and the longest single wait (debug statistics)
     i32 pace_inc, pace_mine, pace_n, pace_base;   // pace control: 65536 / CTUs of this frame, this workgroup's share done, main workgroups of the launch, configured base priority
-    i32 seq[MAIL_SLOTS];   // requests posted (main) / served (helper) so far, per slot
+    i32 seq[POOL_KINDS];   // requests posted (main) / served (helper) so far, per slot
     i32 pipe;           // this launch's workgroups carry a pipe wave (256 threads or more)
     i32 wide;           // ... and four partner wavefronts (512 threads): the trial coders of the 8x8 CUs run split over two wavefronts each
 };
@@ -517,6 +524,13 @@ struct alignas(16) WideCtl {
     i32 b_seg, b_cons;                           // four-TU set: token segments (header + TU 0, TU 1, TU 2, TU 3) complete so far / coded so far, counted over the frame
     i32 b_hand;                                  // ... and 8x8 CUs whose last segment's range half wave 4 has handed to wave 1 (= cu8 once the current CU's is)
     i32 seg_end[4][NMODE];                       // ... and where each candidate's segment ends in its stream (a segment starts on a token-block boundary)
+    // 8x8 CUs with a partner workgroup (hevc_frame.h): main workgroup
+    i32 part_ok;                                 // this main workgroup's partner has reported in (read from its mailbox once per CTU)
+    i32 seq8, stale8;                            // 8x8 requests posted so far / sequence number of one this workgroup stopped waiting for (nothing is posted until that answer has landed)
+    i32 remote8;                                 // the 8x8 CU being walked has its 2Nx2N sets out: the PU chain shares nothing with a four-TU wave here
+    i32 ans_seq;                                 // sequence number of the answer wave 0 has staged in LDS (Ans8), or -1: it stopped waiting
+    // partner workgroup
+    i32 solo2n;                                  // this workgroup evaluates 2Nx2N sets of 8x8 CUs with no NxN chain beside them: the four-TU wave makes TU 0 itself, the one-TU set has two lenders
 };
 // A PU step of an 8x8 CU in a wide workgroup (hevc_frame.h pu_step_wide): the PU wave predicts, transforms and quantises the 35 candidates,
 // leaves levels and prediction here, makes the FIRST part of every candidate's tokens (cbf, last position, significance / greater-1 /

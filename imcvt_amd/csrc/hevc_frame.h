@@ -23,12 +23,23 @@ HD Avail child_avail(const Avail &p, int k) {       // Z-order availability of q
     return c;
 }
 #define F (SM.F)
-// debug heartbeat (thread 0): the longest interval between two beats of this workgroup and when it began
+// debug heartbeat (thread 0; -DIMCVT_HB builds — the three 64-bit words are LDS the shipped image does not have to spare): the longest interval between two
+// beats of this workgroup and when it began
+#ifdef IMCVT_HB
 HD void hb_beat() {
     const unsigned long long now = wd_now();
     if (F.hb_last && now - F.hb_last > F.hb_gap) { F.hb_gap = now - F.hb_last; F.hb_when = F.hb_last; }
     F.hb_last = now;
 }
+HD void hb_set(unsigned long long v) { F.hb_last = v; }
+#define HB_GAP F.hb_gap
+#define HB_WHEN F.hb_when
+#else
+HD void hb_beat() {}
+HD void hb_set(unsigned long long) {}
+#define HB_GAP 0ull
+#define HB_WHEN 0ull
+#endif
 #ifndef NXN_PRIO_SOLO
 #define NXN_PRIO_SOLO 1
 #endif
@@ -371,10 +382,11 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
         }
     }
     const int wide8 = F.wide && !big;                   // 8x8 CU of a wide workgroup: two partner wavefronts take passes of the one-TU set, the four-TU set is coded segment by segment by wave 5
+    const int solo = wide8 && lds_ld_i32(&WCTL.solo2n) != 0;      // ... of a PARTNER workgroup: no NxN chain beside the sets — TU 0 is made here, a second lender takes candidates 32 .. 34
     if (big) wg_sync_p(); else if (wide8 && wave == 0) { wave_sync(); LANES(l) { if (l == 0) lds_st_i32(&WCTL.a_go, lds_ld_i32(&WCTL.a_go) + 1); } } else wave_sync_lds();         // wave 2 / the lenders start from the owners' header counts
     P1Item it[2]; int nit = 1;
     if (!big) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = (wide8 && wave == 0) ? 16 : NMODE;
-                if (wide8 && wave == 0) { nit = 2; it[1].own = 0; it[1].shape = 0; it[1].lo = 32; it[1].hi = NMODE; } }      // (candidates 16..31: wave 5, lend_passes)
+                if (wide8 && wave == 0 && !solo) { nit = 2; it[1].own = 0; it[1].shape = 0; it[1].lo = 32; it[1].hi = NMODE; } }      // (candidates 16..31: wave 5, lend_passes)
     else if (F.wide) {                                  // five wavefronts: the one-TU set on waves 0 and 7, the four-TU set's mode chains on waves 1, 2 and 6
         const int a0 = N == 32 ? 18 : 20, b0 = N == 32 ? 12 : 16, b1 = N == 32 ? 24 : 32;
         const int sh = (wave == 0 || wave == WAVE_PU_PARTNER) ? 0 : 1;
@@ -392,7 +404,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
         P.own = it[ii].own; P.c_lo = it[ii].lo; P.c_hi = it[ii].hi; P.shape = shape; P.tok = wave_tok(F.sc, it[ii].own);
         const int ntu = (shape == 0) ? 1 : 4;
         int k_first = 0;
-        if (TU0_SHARE && N == 8 && shape == 1) { tu0_from_pu0(wave, P.tok); k_first = 1; if (wide8) seg_close(W, 0); }      // TU 0 = the PU wave's PU 0
+        if (TU0_SHARE && N == 8 && shape == 1 && !solo) { tu0_from_pu0(wave, P.tok); k_first = 1; if (wide8) seg_close(W, 0); }      // TU 0 = the PU wave's PU 0
         for (int k = k_first; k < ntu; k++) {
             if (shape == 0) {
                 border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
@@ -411,6 +423,7 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     }
     if (wide8 && wave == 0) {                           // the lenders' candidates are done: their tokens are in memory, counts and SSE in this wavefront's arrays
         while (lds_ld_i32(&WCTL.lend_done[0]) != lds_ld_i32(&WCTL.a_go)) pipe_pause();
+        if (solo) while (lds_ld_i32(&WCTL.lend_done[1]) != lds_ld_i32(&WCTL.a_go)) pipe_pause();
         wave_sync();
     }
     if (wide8 && wave == 1) { prof_add(PF_P1_4, pt); fourtu_last_range_half(); return; }      // (the trial coders of this set have been running on wave 5 all along: partner_fourtu)
@@ -467,6 +480,7 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
     const Tables &T = SM.T;
     PuX &U = PUX; SplitQ &q = XM(2).q;
     const u32 seq = pu_seq_of(k);
+    const int share0 = TU0_SHARE && k == 0 && lds_ld_i32(&WCTL.remote8) == 0;      // PU 0's streams are the four-TU wave's TU 0 — unless that wave runs on another compute unit
     LANES(l) { split_reset(q, l); }
     LANES(l) {
         const int c = l, live = c < NMODE;
@@ -514,7 +528,7 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         const int nb = live ? U.bcnt[c] : 0;
         prof_add(PF_T_NTOK, t4);
         if (live) { W.tokn[c] = 8 + na + nb; W.tnz[c] = (u8)(nzm != 0); }
-        if (TU0_SHARE && k == 0 && live) {              // PU 0: the four-TU wave takes TU 0 from these streams (tu0_from_pu0) — to memory, the remaining-level part behind the first, idle tokens up to the block boundary (the rows stay as they are)
+        if (share0 && live) {                           // PU 0: the four-TU wave takes TU 0 from these streams (tu0_from_pu0) — to memory, the remaining-level part behind the first, idle tokens up to the block boundary (the rows stay as they are)
             u16 *const g = P.tok + (size_t)c * TOK_CAP;
             g_st16((i16 *)(g + 7), (int)row[7]);
             row_to_stream(row + 8, g, 8, na);
@@ -524,7 +538,7 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         }
     }
     long long t5 = prof_now();
-    if (TU0_SHARE && k == 0) {
+    if (share0) {
         wave_sync();                                    // the streams are in memory
         while ((u32)lds_ld_i32((const i32 *)&U.r_seq) != seq) pipe_pause();      // ... and SSE / reconstructions in this wave's slice (long since)
         wave_sync_lds();
@@ -555,7 +569,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
     for (int k = 0; k < 4; k++) {
         const Avail ca = child_avail(av, k);
         const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
-        if (TU0_SHARE && k == 1) {                      // the four-TU wave has its copy of PU 0's pass (long ago: it takes it while this wave prices PU 0)
+        if (TU0_SHARE && k == 1 && !(F.wide && lds_ld_i32(&WCTL.remote8) != 0)) {      // the four-TU wave has its copy of PU 0's pass (long ago: it takes it while this wave prices PU 0)
             while (lds_ld_i32(&SM.pu0_taken) == 0) pipe_pause();
             wave_sync_lds();
             LANES(l) { if (l == 0) { lds_st_i32(&SM.pu0_ready, 0); lds_st_i32(&SM.pu0_taken, 0); } }
@@ -610,7 +624,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             // the block boundary after PU 2 and after PU 3
             const int at = !pipe ? k * NXN_KEEP_STRIDE : k == 3 ? 3 * NXN_KEEP_STRIDE : (k >= 1 ? W.pu_cnt[0] : 0) + (k >= 2 ? W.pu_cnt[1] : 0);
             u16 *dst = nxn + NXN_KEEP + at;
-            if (F.wide && k != 0) {                     // wide workgroup: the winner's tokens lie in its lane row (cbf_luma + first part) and in wave 7's row (remaining levels); PU 0's streams went to memory
+            if (F.wide && (k != 0 || lds_ld_i32(&WCTL.remote8) != 0)) {      // wide workgroup: the winner's tokens lie in its lane row (cbf_luma + first part) and in wave 7's row (remaining levels); PU 0's streams went to memory (unless nobody shares them)
                 const int na1 = 1 + PUX.na[bm];
                 const u16 *ra = lane_row(W, bm) + 7, *rb = PUX.brow[bm];
                 for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), (int)(i < na1 ? ra[i] : rb[i - na1]));
@@ -979,7 +993,16 @@ HDN void enter_cu(int depth_, int N_, int y0_, int x0_, int code_split_, int avm
         const int tid = w * 64 + l;
         if (tid < CTX_STRIDE) SM.entry_cx[depth][tid] = SM.cx[tid];
         if (tid == 64) SM.entry_a[depth] = SM.live;
-        if (tid == 65 && N == 8 && F.wide) WCTL.cu8++;
+        if (tid == 65 && N == 8 && F.wide) {
+            WideCtl &C = WCTL;
+            C.cu8++;
+            int r8 = 0;                                 // this CU's 2Nx2N sets go to the partner workgroup (decide_cu8_remote) — if there is one, and no answer of an abandoned request is still on its way
+            if (F.mail && C.part_ok) {
+                if (C.stale8 && (i32)m_ld32(&F.mail->s[SLOT_8].res_flag) == C.stale8) C.stale8 = 0;
+                r8 = C.stale8 == 0;
+            }
+            C.remote8 = r8;
+        }
     }
     wg_sync();
     if (F.mail && N >= 16) {     // pool: a helper starts on this CU's 70 unsplit candidates now — unless requests already wait unclaimed (every
@@ -1100,7 +1123,7 @@ HD void team_await(i32 *flag, i32 v, int slot) {
                 mail_poll_pause();
             }
             const u32 dt = (u32)(wd_now() - t0); F.waited += dt; if (dt > F.waited_max) F.waited_max = dt;
-            F.hb_last = wd_now();                   // (waiting is not a gap)
+            hb_set(wd_now());                   // (waiting is not a gap)
         }
     }
     wg_sync();
@@ -1306,6 +1329,316 @@ HDN void serve_request(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m
     team_publish(&m->res_flag, seq);
 }
 
+// =====================================================================================================================
+// 8x8 CUs with a partner workgroup (round 6; wide launches).  One frame alone is the chain of its 8x8 CUs, and an 8x8 CU of a wide workgroup is
+// work-bound on its compute unit: eight wavefronts, two per SIMD, all busy in its second half.  The CU's two 2Nx2N candidate
+// sets start from the coder state at the CU's entry and predict from samples outside it, exactly like those of a 16x16 / 32x32 CU — nothing in
+// them depends on the NxN chain that runs beside them (reference :1419-1483 against :1490-1543).  So a main workgroup that has a PARTNER workgroup
+// (kernel_main: partner i serves main workgroup i; its own mailbox slot, no queue) posts every 8x8 CU's entry state, walks the NxN chain alone —
+// four wavefronts, a SIMD each — and takes the partner's answer (the last minimum of the 70, as a helper gives it) when the chain is through:
+//     main       wave 0: request out, answer in (staged in LDS while the chain runs)      wave 2: PU chain      wave 3: pipe wave
+//                wave 4: byte half of the pipe wave's streams                           wave 5: the PU chain's partner (rows, byte half of PU 3's pricing)
+//     partner    wave 0 + wave 2 (candidates 16..31, byte half) + wave 7 (candidates 32..34): one-TU set      wave 1 + wave 3 (coders): four-TU set, TU 0 included
+// The decision is the reference's: modes 0..34 one TU, 0..34 four TUs (the partner's last minimum), then NxN, each accepted with `best >= cost` (:1439, :1475, :1545).
+// =====================================================================================================================
+HD void stage_tables(const Tables *gT);
+struct Ans8 { i32 cost, kind, mode, nbytes; FinState fin; i32 pad_; alignas(4) u8 ctx[CTX_STRIDE]; alignas(4) u8 rec[64]; alignas(4) u8 bytes[TRIAL_OUT_BYTES]; };
+#define ANS8 (*(Ans8 *)WM(0).u.raw)      // wave 0's pass buffer: idle while the CU's 2Nx2N sets are out
+static_assert(sizeof(Ans8) <= 7168, "the staged answer lives in a wave's pass buffer");
+#ifndef PART_POLL_SLEEP
+#define PART_POLL_SLEEP 4                // x 64 cycles between polls of the partner mailbox: one wavefront per compute unit polls, the answer sits on the frame's chain
+#endif
+#ifdef IMCVT_HOSTEMU
+HD void part_poll_pause() { emu_yield(); }
+static long g_remote8[3];                // (test builds: 8x8 CUs decided with the partner's answer, of those won by the partner's candidate, CUs whose answer was abandoned)
+#define R8CNT(i) (g_remote8[i]++)
+#else
+#define R8CNT(i) ((void)0)
+HD void part_poll_pause() { __builtin_amdgcn_s_sleep(PART_POLL_SLEEP); }
+#endif
+// main workgroup, wave 0 alone (the other wavefronts are walking the NxN chain): the request, then the answer into LDS
+HDN void remote8_wave0(int y0_, int x0_, int avm_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
+    MailSlot *m = &F.mail->s[SLOT_8];
+    WideCtl &C = WCTL;
+    const int uy = y0 >> 2, ux = x0 >> 2;
+    const int seq = lds_ld_i32(&C.seq8) + 1;
+    LANES(l) {
+        if (l < CTX_STRIDE / 4) m_st32(m->req.ctx + 4 * l, *(const u32a *)&SM.entry_cx[2][4 * l]);
+        if (l >= 32 && l < 32 + 5) {                      // row above: tile row y0, columns x0 .. x0 + 16 (corner first)
+            const int i = l - 32;
+            const u8 *r = &SM.rec[y0][imin(x0 + 4 * i, 64)];
+            m_st32(m->req.above + 4 * i, (u32)r[0] | (u32)r[1] << 8 | (u32)r[2] << 16 | (u32)r[3] << 24);
+        }
+        if (l >= 40 && l < 40 + 4) {                      // column to the left: tile column x0, rows y0 + 1 .. y0 + 16
+            const int i = l - 40;
+            u32 v = 0;
+            for (int k = 0; k < 4; k++) v |= (u32)SM.rec[imin(y0 + 1 + 4 * i + k, 32)][x0] << (8 * k);
+            m_st32(m->req.left + 4 * i, v);
+        }
+        if (l == 48) {
+            i32 *r = (i32 *)&m->req;
+            const Arith a = SM.entry_a[2];
+            const i32 v[20] = { OP_WORK, F.frame, F.ctu_y, F.ctu_x, 8, y0, x0, avm, nb_size(uy, ux - 1), nb_size(uy - 1, ux), nb_mode(uy, ux - 1), nb_mode(uy - 1, ux),
+                                a.range, a.low, a.nbits, a.nbytes, a.bufbyte, a.zeros, a.cnt, seq };
+            for (int i = 0; i < 20; i++) m_st32(r + i, (u32)v[i]);
+        }
+    }
+    drain_stores();
+    wave_sync();
+    LANES(l) { if (l == 0) { lds_st_i32(&C.seq8, seq); m_st32(&m->req_flag, (u32)seq); } }
+    // the answer: lane 0 polls, then the wavefront stages it
+    LANES(l) {
+        if (l == 0) {
+            const unsigned long long t0 = wd_now();
+            int got = seq;
+            for (int n = 0; (i32)m_ld32(&m->res_flag) != seq; n++) {
+                if (wd_poll(F.pq, t0, n, 3, SLOT_8, seq)) { F.aborted = 1; got = -1; break; }
+#ifdef IMCVT_HOSTEMU
+                if (n >= ABANDON_POLLS) { got = -1; break; }
+#else
+                if ((n & 15) == 15 && wd_now() - t0 > ABANDON_TICKS) { got = -1; break; }
+#endif
+                part_poll_pause();
+            }
+            lds_st_i32(&C.ans_seq, got);
+        }
+    }
+    wave_sync_lds();
+    if (lds_ld_i32(&C.ans_seq) != seq) return;
+    const HelpRes *R = &m->res;
+    Ans8 &A8 = ANS8;
+    LANES(l) {
+        if (l == 0) { A8.cost = ld_i(&R->cost); A8.kind = ld_i(&R->kind); A8.mode = ld_i(&R->mode); A8.fin.w0 = m_ld32(&R->fin.w0); A8.fin.w1 = m_ld32(&R->fin.w1); A8.fin.w2 = m_ld32(&R->fin.w2); }
+        const int nbytes = ld_i(&R->nbytes);
+        if (l == 1) A8.nbytes = nbytes;
+        if (l < CTX_STRIDE / 4) *(u32a *)&A8.ctx[4 * l] = m_ld32(R->ctx + 4 * l);
+        if (l >= 32 && l < 48) *(u32a *)&A8.rec[4 * (l - 32)] = m_ld32(R->rec + 4 * (l - 32));
+        for (int i = l; i < (nbytes + 3) / 4; i += 64) *(u32a *)&A8.bytes[4 * i] = m_ld32(R->bytes + 4 * i);
+    }
+    wave_sync_lds();
+}
+// All waves call this with identical arguments.  Returns non-zero when the partner's answer did not come in time: the caller evaluates the CU itself
+// (decide_cu: same result — the PU chain starts again from the same samples), and nothing more is posted until the late answer has landed.
+HDN int decide_cu8_remote(int y0_, int x0_, int avm_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
+    u8 *live_sink = F.job.out + F.out_pos;
+    WideCtl &C = WCTL;
+    WAVES_ALL(w) {
+        if (w == 0) remote8_wave0(y0, x0, avm);
+        else if (w == 2) eval_NxN(2, y0, x0, avm);
+        else if (w == PIPE_WAVE) { partner_pu_early(y0, x0); nxn_pipe(y0, x0); }
+        else if (w == WAVE_B_CODER) partner_pipe();            // (wave 4: a SIMD of its own here — the one-TU set's wavefront that shares it elsewhere is idle)
+        else if (w == WAVE_A_PARTNER) partner_pu(y0, x0);      // (wave 5: likewise)
+    }
+    wg_sync_p();
+    if (lds_ld_i32(&C.ans_seq) != lds_ld_i32(&C.seq8)) {       // gave up (or the watchdog fired): this mailbox is out of use until the late answer has arrived
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) { lds_st_i32(&C.stale8, lds_ld_i32(&C.seq8)); lds_st_i32(&C.remote8, 0); C.cu8++; F.kept++; R8CNT(2); } }      // (cu8: the PU steps of the second walk get sequence numbers of their own)
+        wg_sync();
+        return 1;
+    }
+    const Ans8 &A8 = ANS8;
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) {
+            int best = A8.cost, kind = A8.kind;               // (I32MAX >= cost: the last minimum of the 70 is always taken first)
+            const int mode = A8.mode;
+            if (best >= WM(2).nxn_cost) { best = WM(2).nxn_cost; kind = 3; }
+            SM.win_kind = kind; SM.win_mode = mode;
+            R8CNT(0); if (kind != 3) R8CNT(1);
+            if (F.sc.trace && F.trace_n + 16 <= F.sc.trace_cap) {
+                i32 *t = F.sc.trace + F.trace_n;
+                t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = 8; t[3] = kind; t[4] = (kind == 3) ? (WM(2).pu_mode[0] | WM(2).pu_mode[1] << 8 | WM(2).pu_mode[2] << 16 | WM(2).pu_mode[3] << 24) : mode;
+                t[5] = best; t[6] = A8.kind == 1 ? A8.cost : 0; t[7] = A8.kind == 2 ? A8.cost : 0;      // (only the better of the two sets' minima travels)
+                t += 8;
+                t[0] = F.ctu_y + y0; t[1] = F.ctu_x + x0; t[2] = 4; t[3] = 3; t[4] = WM(2).pu_mode[0] | WM(2).pu_mode[1] << 8 | WM(2).pu_mode[2] << 16 | WM(2).pu_mode[3] << 24;
+                t[5] = WM(2).nxn_cost; t[6] = WM(2).pu_sse[0] + WM(2).pu_sse[1]; t[7] = WM(2).pu_sse[2] + WM(2).pu_sse[3];
+                F.trace_n += 16;
+            }
+        }
+    }
+    wg_sync_p();
+    const int kind = SM.win_kind, mode = SM.win_mode;
+    if (kind == 3) {                                          // the NxN trial's result sits in the pipe wave's slice, lane nxn_lane (as decide_cu)
+        const int wl = SM.nxn_lane;
+        const u8 *src = lane_bytes(F.sc, PIPE_WAVE, wl);
+        const FinState fe = PM.fin[0];
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            if (tid < CTX_STRIDE) SM.cx[tid] = PM.u.p2.cx[wl][tid];
+            if (tid >= 128 && tid < 128 + 4) {
+                const int i = (tid - 128) >> 1, j = (tid - 128) & 1, uy = (y0 >> 2) + i, ux = (x0 >> 2) + j;
+                SM.mapsz[uy + 1][ux + 1] = 8; SM.mapmode[uy + 1][ux + 1] = (u8)WM(2).pu_mode[i * 2 + j];
+            }
+        }
+        wg_sync_p();
+        WAVES(w) LANES(l) {
+            if (w == 1) {
+                const Arith e = unpack_arith(fe);
+                Arith a = SM.entry_a[2];
+                a.low = e.low; a.range = e.range; a.nbits = e.nbits;
+                resolve_leads(a, src, (int)g_ld32(src + TRIAL_BYTES - 4), live_sink);
+                if (l == 0) SM.live = a;
+            }
+        }
+        wg_sync_p();
+    } else {                                                  // the partner's candidate: bytes, contexts, coder state, maps, reconstruction (:1441-1445, :1477-1481)
+        const int cnt0 = SM.entry_a[2].cnt, nbytes = A8.nbytes;
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            for (int i = tid; i < nbytes; i += WG_THREADS) g_st8(live_sink + cnt0 + i, (int)A8.bytes[i]);
+            if (tid < CTX_STRIDE / 4) *(u32a *)&SM.cx[4 * tid] = *(const u32a *)&A8.ctx[4 * tid];
+            if (tid == 64) SM.live = unpack_arith(A8.fin);
+            if (tid >= 128 && tid < 128 + 4) {
+                const int i = (tid - 128) >> 1, j = (tid - 128) & 1, uy = (y0 >> 2) + i, ux = (x0 >> 2) + j;
+                SM.mapsz[uy + 1][ux + 1] = 8; SM.mapmode[uy + 1][ux + 1] = (u8)mode;
+            }
+            if (tid >= 96 && tid < 96 + 16) {
+                const int i = tid - 96, y = i >> 1, x4 = (i & 1) * 4;
+                const u32 v = *(const u32a *)&A8.rec[y * 8 + x4];
+                u8 *d = &SM.rec[y0 + y + 1][x0 + x4 + 1];
+                d[0] = (u8)v; d[1] = (u8)(v >> 8); d[2] = (u8)(v >> 16); d[3] = (u8)(v >> 24);
+            }
+        }
+        wg_sync_p();
+    }
+    return 0;
+}
+
+// partner workgroup: one request — the two 2Nx2N sets of the 8x8 CU it describes, answered with the last minimum of the 70 (as serve_request, N = 8)
+HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *m_) {
+    const ColdTables *const gK = uni_p(gK_); const FrameJob *const jobs = uni_p(jobs_); MailSlot *const m = uni_p(m_);
+    const HelpReq *Q = &m->req;
+    const int seq = ld_i(&Q->seq);
+    HelpRes *R = &m->res;
+    const int frame = ld_i(&Q->frame), cy = ld_i(&Q->cy), cx = ld_i(&Q->cx);
+    const int y0 = ld_i(&Q->y0), x0 = ld_i(&Q->x0), avm = ld_i(&Q->avm);
+    const int depth = 2, N = 8;
+    const int newframe = frame != F.frame;                      // (the job and the per-quantiser tables change with the frame, not with the CU)
+    WAVES(w) LANES(l) {
+        if (w == 0 && l == 0) { if (newframe) F.job = jobs[frame]; F.ctu_y = cy; F.ctu_x = cx; F.out_pos = 0; F.trace_n = 0; WCTL.cu8++; }
+    }
+    wg_sync();
+    const FrameJob J = F.job;
+    WAVES(w) LANES(l) {
+        const int tid = w * 64 + l;
+        if (tid < 64) {                                         // source pixels of the CU (:1621)
+            const int y = y0 + (tid >> 3), x = x0 + (tid & 7);
+            SM.org[y][x] = g_ld8(J.img + (size_t)clip3(cy + y, 0, J.h - 1) * J.w + clip3(cx + x, 0, J.w - 1));
+        }
+        if (tid >= 64 && tid < 64 + 5) {                        // the samples it predicts from, placed where the main workgroup's tile has them
+            const int i = tid - 64;
+            const u32 v = m_ld32(Q->above + 4 * i);
+            u8 *d = &SM.rec[y0][imin(x0 + 4 * i, 64)];
+            d[0] = (u8)v; d[1] = (u8)(v >> 8); d[2] = (u8)(v >> 16); d[3] = (u8)(v >> 24);
+        }
+        if (tid >= 72 && tid < 72 + 4) {
+            const int i = tid - 72;
+            const u32 v = m_ld32(Q->left + 4 * i);
+            for (int k = 0; k < 4; k++) if (y0 + 1 + 4 * i + k <= 32) SM.rec[y0 + 1 + 4 * i + k][x0] = (u8)(v >> (8 * k));
+        }
+        if (tid >= 128 && tid < 128 + CTX_STRIDE / 4) *(u32a *)&SM.entry_cx[depth][4 * (tid - 128)] = m_ld32(Q->ctx + 4 * (tid - 128));
+        if (newframe && tid >= 152 && tid < 152 + 4 * RQ_CLASSES) (&SM.rthr[0][0])[tid - 152] = (i32)g_ld32(&gK->rthr[J.q][0][0] + (tid - 152));
+        if (tid == 32) {
+            const i32 *r = (const i32 *)&Q->a;
+            Arith a; a.range = ld_i(r); a.low = ld_i(r + 1); a.nbits = ld_i(r + 2); a.nbytes = ld_i(r + 3);
+            a.bufbyte = ld_i(r + 4); a.zeros = ld_i(r + 5); a.cnt = ld_i(r + 6);
+            SM.entry_a[depth] = a;
+            const int uy = y0 >> 2, ux = x0 >> 2;                 // the two neighbour cells the CU header reads (:957-976)
+            SM.mapsz[uy + 1][ux] = (u8)ld_i(&Q->szl); SM.mapsz[uy][ux + 1] = (u8)ld_i(&Q->sza);
+            SM.mapmode[uy + 1][ux] = (u8)ld_i(&Q->ml); SM.mapmode[uy][ux + 1] = (u8)ld_i(&Q->ma);
+            F.frame = frame;
+        }
+    }
+    wg_sync();
+    WAVES_ALL(w) {
+        if (w < 2) eval_2Nx2N(w, depth, N, y0, x0, avm);
+        else if (w == 2) { lend_passes(2, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }      // candidates 16 .. 31 of the one-TU set, then the byte half of its coders (SIMD c)
+        else if (w == PIPE_WAVE) partner_fourtu(depth);                                             // the four-TU set's coders, segment by segment behind wave 1's passes (SIMD d)
+        else if (w == WAVE_PU_PARTNER) lend_passes(w, 1, 32, NMODE, y0, x0, avm);                   // candidates 32 .. 34 (wave 7)
+    }
+    wg_sync();
+    WAVES(w) LANES(l) {
+        if (w == 0) {
+            int m1, m2;
+            const int l1 = wave_last_min(l < NMODE ? WM(0).cost[l] : 0, l < NMODE, l, &m1);
+            const int l2 = wave_last_min(l < NMODE ? WM(1).cost[l] : 0, l < NMODE, l, &m2);
+            if (l == 0) { const int four = m1 >= m2; SM.win_kind = four ? 2 : 1; SM.win_mode = four ? l2 : l1; SM.red[0] = four ? m2 : m1; }
+        }
+    }
+    wg_sync();
+    const int kind = SM.win_kind, mode = SM.win_mode;
+    {
+        const int ww = kind - 1;
+        const u8 *src = lane_bytes(F.sc, ww, mode);
+        u8 *tmp = lane_bytes(F.sc, ww ^ 1, 0);
+        const int cnt0 = SM.entry_a[depth].cnt;
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            if (tid < CTX_STRIDE / 4) m_st32(R->ctx + 4 * tid, *(const u32a *)&WM(ww).u.p2.cx[mode][4 * tid]);
+        }
+        const FinState fe = WM(ww).fin[mode];
+        wg_sync();
+        rebuild_winner(kind, mode, N, y0, x0, avm);
+        WAVES(w) LANES(l) {
+            if (w == 1) {
+                const Arith e = unpack_arith(fe);
+                Arith a = SM.entry_a[depth];
+                a.low = e.low; a.range = e.range; a.nbits = e.nbits;
+                resolve_leads(a, src, (int)g_ld32(src + TRIAL_BYTES - 4), tmp - cnt0);
+                if (l == 0) SM.live = a;
+            }
+        }
+        wg_sync();
+        const FinState fin = pack_arith(SM.live);
+        const int nbytes = SM.live.cnt - cnt0;
+        WAVES(w) LANES(l) {
+            const int tid = w * 64 + l;
+            for (int i = tid; i < (nbytes + 3) / 4; i += WG_THREADS) m_st32(R->bytes + 4 * i, g_ld32(tmp + 4 * i));
+            if (tid == 64) {
+                m_st32(&R->cost, (u32)SM.red[0]); m_st32(&R->kind, (u32)kind); m_st32(&R->mode, (u32)mode); m_st32(&R->nbytes, (u32)nbytes);
+                m_st32(&R->fin.w0, fin.w0); m_st32(&R->fin.w1, fin.w1); m_st32(&R->fin.w2, fin.w2);
+            }
+            if (tid >= 96 && tid < 96 + 16) {
+                const int i = tid - 96, y = i >> 1, x4 = (i & 1) * 4;
+                const u8 *sp = &SM.rec[y0 + y + 1][x0 + x4 + 1];
+                m_st32(R->rec + y * 8 + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
+            }
+        }
+    }
+    team_publish(&m->res_flag, seq);
+}
+// partner workgroup `pid`: serves main workgroup pid's 8x8 requests until every frame is finished
+HDN void partner8_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int pid_, int njobs_) {
+    const Tables *const gT = uni_p(gT_); const ColdTables *const gK = uni_p(gK_); const FrameJob *const jobs = uni_p(jobs_); TeamMail *const mail = uni_p(mail_); PoolQ *const pq = uni_p(pq_);
+    const int pid = uni_i(pid_); const int njobs = uni_i(njobs_);
+    MailSlot *m = &mail[pid].s[SLOT_8];
+    stage_tables(gT);
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = (TeamMail *)0; F.pq = pq; F.frame = -1; F.aborted = 0; WCTL.solo2n = 1; m_st32(&m->pad0_[8], 1u); } }      // (pad0_[8]: "the partner has reported in")
+    wg_sync();
+    int served = 0;
+    for (;;) {
+        WAVES(w) LANES(l) {
+            if (w == 0 && l == 0) {
+                int go = 0;
+                for (int n = 0; ; n++) {
+                    if ((i32)m_ld32(&m->req_flag) == served + 1) { go = 1; break; }
+                    if ((n & 63) == 63 && (m_ld32(&pq->frames_done) == (u32)njobs || m_ld32(&pq->abort) != 0u)) break;      // every frame is finished (or the launch is being abandoned)
+                    part_poll_pause();
+                }
+                SM.red[1] = go;
+            }
+        }
+        wg_sync();
+        const int go = SM.red[1];
+        wg_sync();
+        if (!go) break;
+        serve_request8(gK, jobs, m);
+        served++;
+        wg_sync();
+    }
+}
+
+
 HD void encode_ctu() {
     const FrameJob J = F.job;
     const int cy = F.ctu_y, cx = F.ctu_x;
@@ -1351,7 +1684,7 @@ HD void encode_ctu() {
             const int y8 = y16 + (i8_ >> 1) * 8, x8 = x16 + (i8_ & 1) * 8;
             const Avail a8 = child_avail(a16, i8_);
             enter_cu(2, 8, y8, x8, 0, 0);
-            decide_cu(2, 8, y8, x8, pack_avail(a8));
+            if (!(F.wide && lds_ld_i32(&WCTL.remote8) != 0 && !decide_cu8_remote(y8, x8, pack_avail(a8)))) decide_cu(2, 8, y8, x8, pack_avail(a8));
         }
         price_split(1, 16, y16, x16);
         if (!(team && F.posted[1]) || decide_remote(1, 16, y16, x16)) decide_cu(1, 16, y16, x16, pack_avail(a16));
@@ -1432,6 +1765,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
                     F.ctu_y = cy; F.ctu_x = cx;
                     if (F.mail) {
                         if (m_ld32(&F.pq->abort) != 0u) F.aborted = 1;
+                        if (F.wide) WCTL.part_ok = m_ld32(&F.mail->s[SLOT_8].pad0_[8]) != 0u;      // the partner workgroup (8x8 CUs' 2Nx2N sets) has reported in
                         // Pace control.  The launch ends with its slowest frame, and on a full device a workgroup's speed depends on
                         // the age of its waves (the older wave of a SIMD wins the issue arbitration, the guide's two-waves-per-SIMD
                         // section: workgroups dispatched later run their frames up to 1.5x slower).  So every main workgroup compares the
@@ -1496,7 +1830,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
         WAVES(w) LANES(l) {
             if (w == 0 && l == 0) {
                 int pick = -1, id = -1, round = 0, shard = home; u32 ticket = 0;
-                hb_beat(); F.hb_last = 0;                   // (idle time is not a gap)
+                hb_beat(); hb_set(0);                   // (idle time is not a gap)
                 // Home shard first, then one other shard per round.  16x16 requests go before 32x32 ones (their main workgroups need the
                 // answers sooner) three times out of four: requests arrive in that ratio (four 16x16 CUs — three quarters of them
                 // offered — per 32x32 CU), and with a strict order a busy pool never got to the 32x32 queue: main workgroups were
@@ -1543,7 +1877,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
                     if (got) id = (int)(v & 0xFFFu) - 1;
                     else if (pick >= 0) pick = -3;          // poll again
                 }
-                F.hb_last = wd_now();
+                hb_set(wd_now());
                 SM.red[1] = pick; SM.red[2] = id;
             }
         }
@@ -1573,6 +1907,7 @@ struct KArgs {
     int post16, post32;                         // per mille of the 16x16 / 32x32 CUs a main workgroup offers to the helpers
     int lim16, lim32, prio, quota;              // quota: workgroups per compute unit that start as main workgroups                     // pool tuning: unclaimed requests per shard beyond which a main workgroup keeps a CU (16x16 / 32x32); wave priority of the main workgroups
     int team_size, nteams, nhelp;               // team_size 1: every workgroup encodes whole frames alone; > 1: `nteams` main workgroups + a pool of `nhelp` helper workgroups
+    int npart;                                  // wide pool launches: partner workgroups (partner i takes the 2Nx2N sets of main workgroup i's 8x8 CUs, "8x8 CUs with a partner workgroup")
     int role;                                   // pool launches: 0 roles by placement (one launch holds main and helper workgroups); 1 / 2: this launch holds the main / the helper workgroups of a
                                                 // pool that is spread over two cooperating launches (different workgroup sizes on disjoint sets of compute units, hevc_hip.hip launch_split)
 };
@@ -1606,10 +1941,12 @@ HD void kernel_main(const KArgs &A, int block) {
         atomicMin((unsigned long long *)(A.counter + 4), now); atomicMax((unsigned long long *)(A.counter + 6), now);
     }
     struct Leave { int *c; unsigned long long *dbg; int blk; __device__ ~Leave() { if (threadIdx.x == 0) { atomicAdd(c + 2, -1);
-        if (dbg) { dbg[4 * blk] = F.hb_gap; dbg[4 * blk + 1] = F.hb_when; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
+        if (dbg) { dbg[4 * blk] = HB_GAP; dbg[4 * blk + 1] = HB_WHEN; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
+#ifdef IMCVT_HB
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; for (int i = 0; i < NLEND; i++) WCTL.lend_done[i] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
+#endif
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; for (int i = 0; i < NLEND; i++) WCTL.lend_done[i] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; WCTL.part_ok = 0; WCTL.seq8 = 0; WCTL.stale8 = 0; WCTL.remote8 = 0; WCTL.ans_seq = 0; WCTL.solo2n = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide() && PU_HINTS; SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
@@ -1635,12 +1972,17 @@ HD void kernel_main(const KArgs &A, int block) {
                 // (a launch of main workgroups only: every workgroup takes an index while they last; of helpers only: none does — an idle helper may still take one later, helper_loop)
                 const int want = A.role == 1 ? 1 : A.role == 2 ? 0 : (int)m_add32(&A.pq->cu_count[key], 1u) < A.quota;
                 if (want && m_ld32(&A.pq->mains_taken) < (u32)nm) { const u32 m = m_add32(&A.pq->mains_taken, 1u); if (m < (u32)nm) mid = (int)m; }
-                SM.red[0] = mid;
+                // wide launches with partner workgroups: the next `npart` workgroups to start serve the 8x8 CUs of main workgroups 0 .. npart - 1 (partner8_loop)
+                int pid = -1;
+                if (mid < 0 && A.npart > 0 && wg_is_wide() && m_ld32(&A.pq->parts_taken) < (u32)A.npart) { const u32 p_ = m_add32(&A.pq->parts_taken, 1u); if (p_ < (u32)A.npart) pid = (int)p_; }
+                SM.red[0] = mid; SM.red[1] = pid;
             }
         }
         wg_sync();
         team = SM.red[0];
+        const int pid = SM.red[1];
         wg_sync();
+        if (team < 0 && pid >= 0) { sc.trace = (i32 *)0; partner8_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, pid, A.njobs); return; }
         if (team < 0) {
             sc.trace = (i32 *)0;
             team = helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, block % POOL_SHARDS, 1, A.counter, A.njobs);

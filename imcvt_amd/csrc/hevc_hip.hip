@@ -27,11 +27,11 @@
 #endif
 __global__ __launch_bounds__(KERNEL_MAX_THREADS, KERNEL_MIN_WAVES) void hevc_encode_frames(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                  const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0) {
+                                                                 TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0, int npart) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
     A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.post16 = post16; A.post32 = post32; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio; A.quota = quota; A.fclk = fclk;
-    A.role = role;
+    A.role = role; A.npart = npart;
     kernel_main(A, (int)blockIdx.x + block0);
 }
 // the same kernel instantiated for wide launches (hevc_wide.hip: 256 registers per wavefront, built with loop-invariant code motion).  Weak: a library
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(KERNEL_MAX_THREADS, KERNEL_MIN_WAVES) void hevc_enc
 extern "C" __attribute__((weak)) int imcvt_wide_kernel_prepare(int *blocks_per_cu, int *scratch_bytes_per_lane);
 extern "C" __attribute__((weak)) void imcvt_wide_kernel_launch(int grid, void *stream, const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                          const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                         TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0);
+                                         TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0, int npart);
 
 // ---------------------------------------------------------------------------------------------------
 struct imcvt_hevc_ctx {
@@ -67,7 +67,8 @@ struct imcvt_hevc_ctx {
     int wide = -1, wide_wg = 0, occ_wide = 0, last_wide = 0;   // wide workgroups (512 threads: pipe wave + four partner wavefronts, one workgroup per compute unit): < 0 whenever a pipe-wave launch fits wide_wg workgroups, 0 never, 1 as -1
     int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
     int wide_kernel = 0, wide_scratch = 0;  // wide launches run hevc_encode_frames_wide (hevc_wide.hip; IMCVT_HEVC_WIDE_KERNEL=0: the common instantiation), its private segment per lane
-    int split = 0, split_hpc = 0, last_split = 0;      // a pool spread over two cooperating launches (launch_split): < 0 where planned, 0 never, 1 as < 0; helper workgroups per compute unit of the helpers' set (0: default)
+    int partners = -1, last_part = 0;       // partner workgroups (wide pools: the 2Nx2N sets of a main workgroup's 8x8 CUs on a second compute unit, hevc_frame.h): < 0 wherever they fit, 0 never, 1 as < 0
+    int split = -1, split_hpc = 0, last_split = 0;      // a pool spread over two cooperating launches (launch_split): < 0 where planned, 0 never, 1 as < 0; helper workgroups per compute unit of the helpers' set (0: default)
     hipStream_t st_split[2] = { nullptr, nullptr }; int split_cus[2] = { 0, 0 };      // streams bound to two disjoint sets of compute units, and how many each holds
     hipEvent_t ev_split[3] = { nullptr, nullptr, nullptr };
     u32 *prog = nullptr;                    // progress records of the next launches' frames, two words each (imcvt_hevc_set_progress), or null
@@ -117,18 +118,18 @@ static int pool_limit(int nmains, int nhelp, int kind) {
 // pipe 2: wide workgroups (512 threads: pipe wave + four partner wavefronts and their record queues), one per compute unit
 // role / block0: 0 / 0 for a launch that holds the whole pool; a pool spread over two launches (launch_split) passes 1 / 0 for the main workgroups' and 2 / nmains for the helpers'
 // (block0: where this launch's workgroups start in the scratch table and among the queue shards)
-static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0, int role = 0, int block0 = 0, int split16 = -1, int split32 = -1) {
+static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0, int role = 0, int block0 = 0, int split16 = -1, int split32 = -1, int npart = 0) {
     const int p16 = c->post16 >= 0 ? c->post16 : split16 >= 0 ? split16 : pool_split(nmains, nhelp, 0), p32 = c->post32 >= 0 ? c->post32 : split32 >= 0 ? split32 : pool_split(nmains, nhelp, 1);
     const int l16 = c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), l32 = c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1);
     const int prio = c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), quota = (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1);
     if (pipe >= 2 && c->wide_kernel) {
         imcvt_wide_kernel_launch(grid, (void *)stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs, (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof,
-                                 c->d_mail, c->d_pq, team_size, nmains, nhelp, p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0);
+                                 c->d_mail, c->d_pq, team_size, nmains, nhelp, p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0, npart);
         return;
     }
     hipLaunchKernelGGL(hevc_encode_frames, dim3(grid), dim3(pipe >= 2 ? WG_THREADS_WIDE : pipe ? WG_THREADS_PIPE : WG_THREADS), pipe >= 2 ? WIDE_LDS_BYTES : pipe ? PIPE_LDS_BYTES : 0, stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs,
                        (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof, c->d_mail, c->d_pq, team_size, nmains, nhelp,
-                       p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0);
+                       p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0, npart);
 }
 
 // residency census: `grid` workgroups that count themselves, wait ~1 ms and record how many had started by then (kernel_main, team_size < 0)
@@ -185,6 +186,7 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
             if (getenv("IMCVT_HEVC_VERBOSE")) fprintf(stderr, "imcvt_hevc: wide kernel: %d per compute unit, %d B/lane private segment\n", nb, sb);
         }
     }
+    if (const char *e = getenv("IMCVT_HEVC_PARTNERS")) c->partners = atoi(e);
     if (const char *e = getenv("IMCVT_HEVC_SPLIT")) c->split = atoi(e);
     if (const char *e = getenv("IMCVT_HEVC_SPLIT_HPC")) c->split_hpc = atoi(e);
     c->wide_wg = max_workgroups > 0 ? 0 : c->occ_wide * prop.multiProcessorCount;      // (a context with an explicit workgroup budget plans without them)
@@ -307,21 +309,23 @@ extern "C" int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shap
 // `cus` compute units that holds wide_wg wide and occ_wg 192-thread workgroups per compute unit; hpc: helper workgroups per compute unit (0: default)
 extern "C" int imcvt_hevc_plan_split(int mode, int nmains, int cus, int wide_wg, int occ_wg, int hpc, int *nhelp) {
     if (mode != 2 || nmains < 1 || cus < 2 || wide_wg < cus - cus / 16 || occ_wg < 1) return 0;      // (nearly every compute unit must be able to hold a wide workgroup)
-    if (imcvt_hevc_plan_wide(1, 3 * nmains, wide_wg, 0)) return 0;       // two wide helpers per main workgroup fit: one launch
-    if (2 * nmains > cus) return 0;                                       // (beyond half of the compute units the helpers' half cannot keep up: 256-thread workgroups as planned)
+    if (2 * nmains > cus) return 0;                                       // the main workgroups get one half of the compute units, the helpers the other
+    // one launch of wide workgroups gives a main workgroup (wide_wg - nmains) / nmains helpers; down to 1.4 it is as fast as the split (96 frames: 2.32 s
+    // against 2.35 s; 128 frames, one helper each: 2.76 s against 2.40 s, profiles/r06a_ab.log)
+    if (5 * (wide_wg - nmains) >= 7 * nmains) return 0;
     if (hpc < 1) hpc = 3;
     if (hpc > occ_wg) hpc = occ_wg;
-    int h = (cus - nmains) * hpc;
+    int h = (cus - cus / 2) * hpc;
     if (h > 4 * nmains) h = 4 * nmains;                                   // (a main workgroup has two requests out at most; the rest would only poll)
     if (h < nmains) return 0;
     if (nhelp) *nhelp = h;
     return 1;
 }
-// streams bound to the first `cus_a` compute units and to the rest (cached: the masks only change with the number of main workgroups)
-static int split_streams(imcvt_hevc_ctx *c, int cus_a) {
-    if (c->st_split[0] && c->split_cus[0] == cus_a) return 0;
-    for (int i = 0; i < 2; i++) if (c->st_split[i]) { (void)hipStreamSynchronize(c->st_split[i]); (void)hipStreamDestroy(c->st_split[i]); c->st_split[i] = nullptr; }
-    const int words = (c->cus + 31) / 32;
+// streams bound to the two halves of the compute units, created once per context (a stream whose mask was changed after another had been destroyed ran on the old
+// mask: 112 main workgroups on the 96 compute units of the launch before took two rounds, profiles/r06a_ab.log)
+static int split_streams(imcvt_hevc_ctx *c) {
+    if (c->st_split[0]) return 0;
+    const int words = (c->cus + 31) / 32, cus_a = c->cus / 2;
     std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
     // (the driver deals the mask's bits out over XCDs, then shader engines, then arrays: a run of consecutive bits is spread evenly over the device)
     for (int i = 0; i < c->cus; i++) (i < cus_a ? ma : mb)[(size_t)(i / 32)] |= 1u << (i % 32);
@@ -331,6 +335,18 @@ static int split_streams(imcvt_hevc_ctx *c, int cus_a) {
     c->split_cus[0] = cus_a; c->split_cus[1] = c->cus - cus_a;
     return 0;
 }
+// Partner workgroups (round 6): in a wide pool every main workgroup gets a second compute unit for the two 2Nx2N candidate sets of its 8x8 CUs (hevc_frame.h
+// "8x8 CUs with a partner workgroup") when the launch has room: one partner per main workgroup beside the planned helpers, or — a pool that just misses
+// that — with the helpers cut to what is left, never below 1.5 per main workgroup.  pure; returns the number of partner workgroups (0 or nmains).
+extern "C" int imcvt_hevc_plan_partners(int nmains, int *nhelp, int wide_wg, int forced_shape) {
+    if (nmains < 1 || !nhelp || wide_wg < 1) return 0;
+    const int cap = forced_shape ? wide_wg : wide_wg - wide_wg / 16;
+    if (2 * nmains + *nhelp <= cap) return nmains;
+    if (!forced_shape && 2 * nmains + (3 * nmains + 1) / 2 <= cap) { *nhelp = cap - 2 * nmains; return nmains; }
+    return 0;
+}
+extern "C" void imcvt_hevc_set_partners(imcvt_hevc_ctx *c, int mode) { if (c) c->partners = mode; }
+extern "C" int imcvt_hevc_last_partners(imcvt_hevc_ctx *c) { return c ? c->last_part : IMCVT_ERR_ARG; }
 extern "C" void imcvt_hevc_set_split(imcvt_hevc_ctx *c, int mode, int helpers_per_cu) { if (c) { c->split = mode; c->split_hpc = helpers_per_cu; } }
 extern "C" int imcvt_hevc_last_split(imcvt_hevc_ctx *c) { return c ? c->last_split : IMCVT_ERR_ARG; }
 extern "C" void imcvt_hevc_set_team(imcvt_hevc_ctx *c, int team_size) { if (c) c->force_team = team_size < 0 ? 0 : team_size > 3 ? 3 : team_size; }
@@ -448,8 +464,10 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         use_wide = use_split ? 1 : imcvt_hevc_plan_wide_pool(1, mode, forced, c->wide_wg, &nmains, &h2);
         if (use_wide && !use_split) { nhelp = h2; use_pipe = 1; }
     }
-    if (use_split && split_streams(c, nmains) != 0) { (void)hipGetLastError(); return IMCVT_ERR_HIP; }
-    const int grid = nmains + nhelp;
+    if (use_split && split_streams(c) != 0) { (void)hipGetLastError(); return IMCVT_ERR_HIP; }
+    int npart = 0;
+    if (use_wide && !use_split && mode == 2 && c->partners != 0) npart = imcvt_hevc_plan_partners(nmains, &nhelp, c->wide_wg, forced);
+    const int grid = nmains + nhelp + npart;
     if (mode <= 0 || grid < 1 || grid > c->max_wg || (mode > 1 && (nmains > c->mail_cap || 2 * nmains > POOL_SHARDS * POOL_QCAP))) {
         fprintf(stderr, "imcvt_hevc: launch shape %d + %d exceeds the context (%d workgroups, %d mailboxes)\n", nmains, nhelp, c->max_wg, c->mail_cap);
         return IMCVT_ERR_ARG;
@@ -487,6 +505,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
     c->last_pipe = use_pipe;
     c->last_wide = use_wide;
     c->last_split = use_split;
+    c->last_part = npart;
 
     HIPCHK(hipEventRecord(c->ev0, stream));
     if (use_split) {          // the main workgroups (wide) on their compute units, the helpers (192 threads) on the others; both end before `stream` goes on
@@ -499,7 +518,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         HIPCHK(hipEventRecord(c->ev_split[1], c->st_split[0])); HIPCHK(hipEventRecord(c->ev_split[2], c->st_split[1]));
         HIPCHK(hipStreamWaitEvent(stream, c->ev_split[1], 0)); HIPCHK(hipStreamWaitEvent(stream, c->ev_split[2], 0));
     } else {
-    launch(c, grid, stream, n, mode, nmains, nhelp, c->last_wide ? 2 : c->last_pipe);
+    launch(c, grid, stream, n, mode, nmains, nhelp, c->last_wide ? 2 : c->last_pipe, 0, 0, -1, -1, npart);
     HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev1, stream));
@@ -564,7 +583,7 @@ extern "C" int imcvt_hevc_last_status(imcvt_hevc_ctx *c) {
     HIPCHK(hipMemcpy(v, &c->d_pq->abort, sizeof v, hipMemcpyDeviceToHost));
     if (v[0] == 0) return earlier;
     fprintf(stderr, "imcvt_hevc: device watchdog: a %s gave up after %.0f s (slot/shard %u, seq/ticket %u, main workgroup %u, frame %d; launch %d + %d workgroups) — results invalid\n",
-            v[1] == 1 ? "main workgroup waiting for a helper's answer" : "helper waiting for a ticket's owner", (double)WD_TICKS / 1e8, v[2], v[3], v[4], (int)v[5], c->last_mains, c->last_help);
+            v[1] == 1 ? "main workgroup waiting for a helper's answer" : v[1] == 3 ? "main workgroup waiting for its partner's answer" : "helper waiting for a ticket's owner", (double)WD_TICKS / 1e8, v[2], v[3], v[4], (int)v[5], c->last_mains, c->last_help);
     if (v[1] == 1) fprintf(stderr, "  when it gave up: its shard's queue of that kind had head %u tail %u; request flag %#x (0x1xxxx: taken by the helper with that home shard)\n", v[6], v[7], v[8]);
     if (v[1] == 1) fprintf(stderr, "  clocks (ms before the watchdog fired): wait began %.2f, request taken %.2f, inputs staged %.2f, candidates evaluated %.2f, answer about to be published %.2f (stamps of an earlier request of this mailbox if larger than the wait)\n",
                            (double)(i32)(v[13] - v[14]) / 1e5, (double)(i32)(v[13] - v[9]) / 1e5, (double)(i32)(v[13] - v[10]) / 1e5, (double)(i32)(v[13] - v[11]) / 1e5, (double)(i32)(v[13] - v[12]) / 1e5);
@@ -573,7 +592,7 @@ extern "C" int imcvt_hevc_last_status(imcvt_hevc_ctx *c) {
         if (hipMemcpy(q, c->d_pq, sizeof(PoolQ), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "  frames_done %u alive %u mains_taken %u progress %u\n", q->frames_done, q->alive, q->mains_taken, q->progress);
             for (int i = 0; i < POOL_SHARDS; i++) fprintf(stderr, "  shard %2d: 16x16 head %u tail %u | 32x32 head %u tail %u\n", i, q->sh[i].head[0], q->sh[i].tail[0], q->sh[i].head[1], q->sh[i].tail[1]);
-            if (v[1] == 1 && (int)v[4] < c->mail_cap && v[2] < MAIL_SLOTS) {
+            if (v[1] == 1 && (int)v[4] < c->mail_cap && v[2] < POOL_KINDS) {
                 MailSlot *ms = new MailSlot();
                 if (hipMemcpy(ms, &c->d_mail[v[4]].s[v[2]], sizeof(MailSlot), hipMemcpyDeviceToHost) == hipSuccess)
                     fprintf(stderr, "  its mailbox: request seq %d (op %d frame %d cy %d cx %d N %d y0 %d x0 %d), result flag %d\n", ms->req.seq, ms->req.op, ms->req.frame, ms->req.cy, ms->req.cx, ms->req.N, ms->req.y0, ms->req.x0, ms->res_flag);
@@ -663,7 +682,7 @@ struct DevState {
     UpLane up[UP_LANES];                        // staging (created by the first batch that is large enough)
     u32 *h_prog = nullptr; int prog_cap = 0;    // pinned progress records of the running launch, two words per frame
     std::vector<u32> got_rows, got_pos;         // CTU rows / stream bytes of each frame that have reached the caller's buffers
-    int rc = 0; bool launched = false;
+    int rc = 0; bool launched = false, staged_out = false;
     double t_up = 0, t_follow = 0, t_tail = 0; size_t followed = 0, tail = 0;      // statistics of the last call (imcvt_hevc_batch_transfer_stats)
 };
 static std::mutex g_lock;
@@ -716,6 +735,7 @@ extern "C" void imcvt_hevc_shutdown(void) {
 struct BatchArgs { unsigned char *const *pbuffers; const unsigned char *const *imgs; unsigned char *const *rcons; int *ysz, *xsz; const int *qpd6; int *out_len; };
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+static int staging_ready(DevState &d);
 // inputs of one device's frames through the staging buffers: the chunks of all frames are one list, the lanes take them in turn
 static int upload_staged(DevState &d, const BatchArgs &A) {
     struct Item { const u8 *src; u8 *dst; size_t len; };
@@ -725,14 +745,7 @@ static int upload_staged(DevState &d, const BatchArgs &A) {
         const size_t n = (size_t)A.ysz[i] * A.xsz[i];
         for (size_t o = 0; o < n; o += UP_CHUNK) items.push_back({ A.imgs[i] + o, d.slab + d.off_img[j] + o, n - o < UP_CHUNK ? n - o : UP_CHUNK });
     }
-    for (int k = 0; k < UP_LANES; k++) {
-        UpLane &u = d.up[k];
-        if (!u.st) { if (k == 0) u.st = d.st_copy; else { if (hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking) != hipSuccess) return IMCVT_ERR_HIP; u.own_stream = true; } }
-        for (int b = 0; b < 2; b++) {
-            if (!u.buf[b] && hipHostMalloc((void **)&u.buf[b], UP_CHUNK, hipHostMallocDefault) != hipSuccess) return IMCVT_ERR_HIP;
-            if (!u.ev[b] && hipEventCreateWithFlags(&u.ev[b], hipEventDisableTiming) != hipSuccess) return IMCVT_ERR_HIP;
-        }
-    }
+    if (int e = staging_ready(d)) return e;
     std::atomic<size_t> next(0);
     std::atomic<int> err(0);
     auto lane = [&](int k) {
@@ -756,16 +769,17 @@ static int upload_staged(DevState &d, const BatchArgs &A) {
     return err;
 }
 
-// what the device has finished of frame j -> the caller's buffers.  fin: the launch is over (everything that is left); otherwise only what the
-// frame's progress record says is final, and only in pieces worth a copy.  Asynchronous on st_copy; *bytes counts what was queued.
-static int collect_frame(DevState &d, const BatchArgs &A, int j, bool fin, size_t *bytes) {
+// what the device has finished of frame j and the caller's buffers do not have yet, as copy items.  fin: the launch is over (everything that is left);
+// otherwise only what the frame's progress record says is final, and only in pieces worth a copy.
+struct OutItem { const u8 *src; u8 *dst; size_t len; };
+static void collect_frame(DevState &d, const BatchArgs &A, int j, bool fin, std::vector<OutItem> &items) {
     const int i = d.idx[(size_t)j], hp = imcvt_hevc_padded(A.ysz[i]), wp = imcvt_hevc_padded(A.xsz[i]);
     u32 rows, pos;
     if (fin) { rows = (u32)(hp / 32); pos = (u32)d.lens[(size_t)j]; }
     else {
         const volatile u32 *pr = d.h_prog + 2 * (size_t)j;
         const u32 r = pr[0]; pos = pr[1]; rows = r & ~PROG_DONE;
-        if (rows > (u32)(hp / 32) || pos > (u32)imcvt_hevc_stream_bound(A.ysz[i], A.xsz[i])) return 0;      // (never: a record that makes no sense is ignored, the final pass collects the frame)
+        if (rows > (u32)(hp / 32) || pos > (u32)imcvt_hevc_stream_bound(A.ysz[i], A.xsz[i])) return;      // (never: a record that makes no sense is ignored, the final pass collects the frame)
         if (!(r & PROG_DONE)) {
             if (rows < d.got_rows[(size_t)j] + FOLLOW_ROWS) rows = d.got_rows[(size_t)j];
             if (pos < d.got_pos[(size_t)j] + 65536u) pos = d.got_pos[(size_t)j];
@@ -773,15 +787,72 @@ static int collect_frame(DevState &d, const BatchArgs &A, int j, bool fin, size_
     }
     if (rows > d.got_rows[(size_t)j]) {
         const size_t o = (size_t)d.got_rows[(size_t)j] * 32 * wp, n = (size_t)(rows - d.got_rows[(size_t)j]) * 32 * wp;
-        if (hipMemcpyAsync(A.rcons[i] + o, d.fr[(size_t)j].d_rcon + o, n, hipMemcpyDeviceToHost, d.st_copy) != hipSuccess) return IMCVT_ERR_HIP;
-        d.got_rows[(size_t)j] = rows; *bytes += n;
+        items.push_back({ d.fr[(size_t)j].d_rcon + o, A.rcons[i] + o, n });
+        d.got_rows[(size_t)j] = rows;
     }
     if (pos > d.got_pos[(size_t)j]) {
         const size_t o = d.got_pos[(size_t)j], n = (size_t)pos - o;
-        if (hipMemcpyAsync(A.pbuffers[i] + o, d.fr[(size_t)j].d_out + o, n, hipMemcpyDeviceToHost, d.st_copy) != hipSuccess) return IMCVT_ERR_HIP;
-        d.got_pos[(size_t)j] = pos; *bytes += n;
+        items.push_back({ d.fr[(size_t)j].d_out + o, A.pbuffers[i] + o, n });
+        d.got_pos[(size_t)j] = pos;
+    }
+}
+static int staging_ready(DevState &d) {      // streams, pinned buffers and events of the lanes (created by the first batch that is large enough)
+    for (int k = 0; k < UP_LANES; k++) {
+        UpLane &u = d.up[k];
+        if (!u.st) { if (k == 0) u.st = d.st_copy; else { if (hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking) != hipSuccess) return IMCVT_ERR_HIP; u.own_stream = true; } }
+        for (int b = 0; b < 2; b++) {
+            if (!u.buf[b] && hipHostMalloc((void **)&u.buf[b], UP_CHUNK, hipHostMallocDefault) != hipSuccess) return IMCVT_ERR_HIP;
+            if (!u.ev[b] && hipEventCreateWithFlags(&u.ev[b], hipEventDisableTiming) != hipSuccess) return IMCVT_ERR_HIP;
+        }
     }
     return 0;
+}
+// copy items out.  how 0: straight into the caller's (pageable) memory, asynchronous on st_copy; how 1: through lane 0's pinned buffers by the calling thread
+// (device -> pinned by the copy engine, pinned -> caller by memcpy); how 2: through all lanes' buffers by worker threads (what is left when the launch has ended)
+static int copy_out(DevState &d, const std::vector<OutItem> &items, int how, size_t *bytes) {
+    size_t total = 0;
+    for (const OutItem &it : items) total += it.len;
+    *bytes += total;
+    if (items.empty()) return 0;
+    if (how == 0) {
+        for (const OutItem &it : items) if (hipMemcpyAsync(it.dst, it.src, it.len, hipMemcpyDeviceToHost, d.st_copy) != hipSuccess) return IMCVT_ERR_HIP;
+        return 0;
+    }
+    if (int e = staging_ready(d)) return e;
+    std::vector<OutItem> chunks;
+    for (const OutItem &it : items) for (size_t o = 0; o < it.len; o += UP_CHUNK) chunks.push_back({ it.src + o, it.dst + o, it.len - o < UP_CHUNK ? it.len - o : UP_CHUNK });
+    std::atomic<size_t> next(0);
+    std::atomic<int> err(0);
+    auto lane = [&](int k) {
+        UpLane &u = d.up[k];
+        if (hipSetDevice(d.dev) != hipSuccess) { err = IMCVT_ERR_HIP; return; }
+        size_t mine[2] = { 0, 0 }; bool have[2] = { false, false };
+        for (int turn = 0; err == 0; turn ^= 1) {      // the copy engine fills one buffer while this thread empties the other
+            const size_t it = next++;
+            const bool more = it < chunks.size();
+            if (more) {
+                if (hipMemcpyAsync(u.buf[turn], chunks[it].src, chunks[it].len, hipMemcpyDeviceToHost, u.st) != hipSuccess || hipEventRecord(u.ev[turn], u.st) != hipSuccess) { err = IMCVT_ERR_HIP; break; }
+                mine[turn] = it; have[turn] = true;
+            }
+            const int other = turn ^ 1;
+            if (have[other]) {
+                if (hipEventSynchronize(u.ev[other]) != hipSuccess) { err = IMCVT_ERR_HIP; break; }
+                memcpy(chunks[mine[other]].dst, u.buf[other], chunks[mine[other]].len);
+                have[other] = false;
+            }
+            if (!more) {
+                if (have[turn]) { if (hipEventSynchronize(u.ev[turn]) != hipSuccess) { err = IMCVT_ERR_HIP; break; } memcpy(chunks[mine[turn]].dst, u.buf[turn], chunks[mine[turn]].len); have[turn] = false; }
+                break;
+            }
+        }
+        if (err != 0) (void)hipStreamSynchronize(u.st);
+    };
+    if (how == 1) { lane(0); return err; }
+    std::vector<std::thread> th;
+    for (int k = 1; k < UP_LANES; k++) th.emplace_back(lane, k);
+    lane(0);
+    for (std::thread &t : th) t.join();
+    return err;
 }
 
 // one device's share of a batch, start to finish (its own thread when the batch spans several devices)
@@ -821,7 +892,12 @@ static void run_device(DevState &d, const BatchArgs &A) {
         if (hipMemcpyAsync(d.slab + d.off_img[(size_t)j], A.imgs[i], (size_t)A.ysz[i] * A.xsz[i], hipMemcpyHostToDevice, d.st) != hipSuccess) { fail(IMCVT_ERR_HIP); return; }
     }
     d.t_up = now_s() - t0;
-    const bool follow = !plain && bytes_out >= FOLLOW_MIN_BYTES;
+    // IMCVT_HEVC_FOLLOW (A/B): 0 collect after the launch; 1 follow it with copies straight into the caller's memory; 2 records on, collect after; 3 (default) follow it
+    // through the pinned staging buffers
+    int fmode = 3;
+    if (const char *e = getenv("IMCVT_HEVC_FOLLOW")) fmode = atoi(e);
+    const bool follow = !plain && fmode != 0 && bytes_out >= FOLLOW_MIN_BYTES;
+    d.staged_out = !plain && bytes_out >= FOLLOW_MIN_BYTES;
     if (follow) {
         if (m > d.prog_cap) {
             if (d.h_prog) (void)hipHostFree(d.h_prog);
@@ -840,8 +916,11 @@ static void run_device(DevState &d, const BatchArgs &A) {
             const hipError_t q = hipEventQuery(d.ctx->ev1);
             if (q != hipErrorNotReady) { if (q != hipSuccess) { (void)hipGetLastError(); fail(IMCVT_ERR_HIP); } break; }
             size_t got = 0;
-            for (int j = 0; j < m && d.rc == 0; j++) if (int e = collect_frame(d, A, j, false, &got)) fail(e);
-            if (d.rc) break;
+            if (fmode != 2) {
+                std::vector<OutItem> items;
+                for (int j = 0; j < m; j++) collect_frame(d, A, j, false, items);
+                if (int e = copy_out(d, items, fmode == 1 ? 0 : 1, &got)) { fail(e); break; }
+            }
             d.followed += got;
             if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
@@ -859,10 +938,16 @@ static void finish_device(DevState &d, const BatchArgs &A) {      // the launch 
     if (!d.launched) return;
     if (d.rc == 0) d.rc = imcvt_hevc_last_status(d.ctx);
     if (d.rc == 0 && hipMemcpy(d.lens.data(), d.slab + d.off_len, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) fail(IMCVT_ERR_HIP);
+    std::vector<OutItem> items;
     for (int j = 0; j < m && d.rc == 0; j++) {
         const int i = d.idx[(size_t)j];
         if (d.lens[(size_t)j] < 1 || (long long)d.lens[(size_t)j] > imcvt_hevc_stream_bound(A.ysz[i], A.xsz[i]) || (u32)d.lens[(size_t)j] < d.got_pos[(size_t)j]) { fail(IMCVT_ERR_HIP); break; }
-        if (int e = collect_frame(d, A, j, true, &d.tail)) fail(e);
+        collect_frame(d, A, j, true, items);
+    }
+    if (d.rc == 0) {
+        size_t left = 0;
+        for (const OutItem &it : items) left += it.len;
+        if (int e = copy_out(d, items, (d.staged_out && left >= ((size_t)4 << 20)) ? 2 : 0, &d.tail)) fail(e);
     }
     if (hipStreamSynchronize(d.st_copy) != hipSuccess) fail(IMCVT_ERR_HIP);
     d.t_tail = now_s() - t0;

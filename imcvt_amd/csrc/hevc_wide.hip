@@ -9,11 +9,11 @@
 
 __global__ __launch_bounds__(WG_THREADS_WIDE, 2) void hevc_encode_frames_wide(const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                                                               const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                                                              TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0) {
+                                                                              TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0, int npart) {
     KArgs A;
     A.gT = gT; A.gK = gK; A.jobs = jobs; A.hdrs = hdrs; A.njobs = njobs; A.scr = scr; A.counter = counter; A.trace = trace; A.trace_cap = trace_cap; A.prof = prof;
     A.mail = mail; A.pq = pq; A.team_size = team_size; A.nteams = nteams; A.nhelp = nhelp; A.post16 = post16; A.post32 = post32; A.lim16 = lim16; A.lim32 = lim32; A.prio = prio; A.quota = quota; A.fclk = fclk;
-    A.role = role;
+    A.role = role; A.npart = npart;
     kernel_main(A, (int)blockIdx.x + block0);
 }
 
@@ -30,7 +30,7 @@ extern "C" int imcvt_wide_kernel_prepare(int *blocks_per_cu, int *scratch_bytes_
 }
 extern "C" void imcvt_wide_kernel_launch(int grid, void *stream, const Tables *gT, const ColdTables *gK, const FrameJob *jobs, const u8 *hdrs, int njobs,
                                          const Scratch *scr, int *counter, i32 *trace, int trace_cap, unsigned long long *prof,
-                                         TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0) {
+                                         TeamMail *mail, PoolQ *pq, int team_size, int nteams, int nhelp, int post16, int post32, int lim16, int lim32, int prio, int quota, unsigned long long *fclk, int role, int block0, int npart) {
     hipLaunchKernelGGL(hevc_encode_frames_wide, dim3(grid), dim3(WG_THREADS_WIDE), WIDE_LDS_BYTES, (hipStream_t)stream, gT, gK, jobs, hdrs, njobs, scr, counter, trace, trace_cap, prof,
-                       mail, pq, team_size, nteams, nhelp, post16, post32, lim16, lim32, prio, quota, fclk, role, block0);
+                       mail, pq, team_size, nteams, nhelp, post16, post32, lim16, lim32, prio, quota, fclk, role, block0, npart);
 }

@@ -28,7 +28,8 @@ EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "i
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
            "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_plan_wide_pool", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
            "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats",
-           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats", "imcvt_hevc_set_split", "imcvt_hevc_last_split", "imcvt_hevc_plan_split")
+           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats", "imcvt_hevc_set_split", "imcvt_hevc_last_split", "imcvt_hevc_plan_split",
+           "imcvt_hevc_set_partners", "imcvt_hevc_last_partners", "imcvt_hevc_plan_partners")
 
 
 class imcvt_hevc_frame(C.Structure):
@@ -139,6 +140,12 @@ def load_library():
         lib.imcvt_hevc_set_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.imcvt_hevc_last_split.restype = C.c_int
         lib.imcvt_hevc_last_split.argtypes = [C.c_void_p]
+        lib.imcvt_hevc_set_partners.restype = None
+        lib.imcvt_hevc_set_partners.argtypes = [C.c_void_p, C.c_int]
+        lib.imcvt_hevc_last_partners.restype = C.c_int
+        lib.imcvt_hevc_last_partners.argtypes = [C.c_void_p]
+        lib.imcvt_hevc_plan_partners.restype = C.c_int
+        lib.imcvt_hevc_plan_partners.argtypes = [C.c_int, _ip, C.c_int, C.c_int]
         lib.imcvt_hevc_plan_split.restype = C.c_int
         lib.imcvt_hevc_plan_split.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]
     _lib = lib
@@ -253,6 +260,14 @@ class DeviceEncoder:
         """Wide workgroups (512 threads, split trial coders): -1 automatic, 0 never, 1 wherever they fit.  Results are identical."""
         if hasattr(self.lib, "imcvt_hevc_set_wide"):
             self.lib.imcvt_hevc_set_wide(self.ctx, int(mode))
+
+    def set_partners(self, mode: int):
+        """Partner workgroups (wide pools: the 2Nx2N sets of a main workgroup's 8x8 CUs on a second compute unit): -1 / 1 wherever they fit, 0 never."""
+        self.lib.imcvt_hevc_set_partners(self.ctx, int(mode))
+
+    def last_partners(self) -> int:
+        """Partner workgroups of the last launch."""
+        return int(self.lib.imcvt_hevc_last_partners(self.ctx))
 
     def set_split(self, mode: int, helpers_per_cu: int = 0):
         """A pool as two cooperating launches (wide main workgroups + 192-thread helpers on disjoint compute units): 0 never, 1 / -1 where planned."""

@@ -142,10 +142,19 @@ int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape);
  * returned): a pool that does not fit as planned still runs wide when its main workgroups take at most half of the `wide_wg`
  * workgroups — *nhelp is cut to the rest.  Returns 1 if the launch runs wide workgroups. */
 int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shape, int wide_wg, const int *nmains, int *nhelp);
+/* Partner workgroups (wide pools): every main workgroup gets a second compute unit that evaluates the two 2Nx2N candidate sets of its 8x8 CUs while it walks their
+ * NxN chains alone (four wavefronts, a SIMD each) — shorter frames wherever one frame's serial chain sets the pace.  mode < 0 (default) / 1: wherever
+ * imcvt_hevc_plan_partners finds room; 0: never.  Results are identical.  Environment at context creation: IMCVT_HEVC_PARTNERS. */
+void imcvt_hevc_set_partners(imcvt_hevc_ctx *ctx, int mode);
+/* Partner workgroups of the last launch (0 or its main workgroups). */
+int imcvt_hevc_last_partners(imcvt_hevc_ctx *ctx);
+/* Pure: partner workgroups for a wide pool of nmains main and *nhelp helper workgroups on a device that holds wide_wg wide workgroups: nmains when they fit beside the
+ * helpers (a sixteenth of the compute units stays free unless the shape is forced), or with *nhelp cut to the rest as long as 1.5 helpers per main workgroup remain; else 0. */
+int imcvt_hevc_plan_partners(int nmains, int *nhelp, int wide_wg, int forced_shape);
 /* A pool spread over two cooperating launches: wide main workgroups (512 threads, a compute unit each) on one set of compute units, 192-thread
- * helper workgroups, several per compute unit, on the others (streams with disjoint compute-unit masks) — for pools of 81 .. 128 main workgroups,
- * whose wide shape in ONE launch leaves every main workgroup fewer than two (wide) helpers.  mode 0 (default): never; < 0 / 1: wherever
- * imcvt_hevc_plan_split says; helpers_per_cu 0: default (3).  Results are identical.  Environment at context creation: IMCVT_HEVC_SPLIT, IMCVT_HEVC_SPLIT_HPC. */
+ * helper workgroups, several per compute unit, on the others (streams with disjoint compute-unit masks) — for pools of 107 .. 128 main workgroups,
+ * whose wide shape in ONE launch leaves every main workgroup fewer than 1.4 (wide) helpers.  mode < 0 (default) / 1: wherever
+ * imcvt_hevc_plan_split says; 0: never; helpers_per_cu 0: default (3).  Results are identical.  Environment at context creation: IMCVT_HEVC_SPLIT, IMCVT_HEVC_SPLIT_HPC. */
 void imcvt_hevc_set_split(imcvt_hevc_ctx *ctx, int mode, int helpers_per_cu);
 /* 1 if the last launch was such a pair of launches, else 0. */
 int imcvt_hevc_last_split(imcvt_hevc_ctx *ctx);

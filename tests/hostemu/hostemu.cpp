@@ -174,12 +174,13 @@ static void emu_entry() { KArgs a = g_args; if (g_role_split && a.nhelp > 0) a.r
 // nhelp 0: `nmains` workgroups encode the frames alone (frames pulled one after the other); > 0: they hand the 16x16 / 32x32 candidate
 // sets to a pool of `nhelp` helper workgroups (hevc_frame.h)
 static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
-                      int *ysz, int *xsz, int qpd6, int *out_len, int *trace, int trace_cap, int nmains, int nhelp) {
+                      int *ysz, int *xsz, int qpd6, int *out_len, int *trace, int trace_cap, int nmains, int nhelp, int npart = 0) {
     static Tables T; static ColdTables K; static int ready = 0;
     if (!ready) { imcvt::build_tables(T, K); ready = 1; }
     if (nmains < 1) nmains = 1;
     if (nhelp < 0) nhelp = 0;
-    const int nteams = nmains, nwg = nmains + nhelp;
+    if (npart < 0 || nhelp < 1) npart = 0;
+    const int nteams = nmains, nwg = nmains + nhelp + npart;
     if (nwg > EMU_MAX_WG) return -1;
     FrameJob *jobs = (FrameJob *)calloc(n, sizeof(FrameJob));
     u8 *hdrs = (u8 *)calloc(n, HDR_MAX);
@@ -207,7 +208,7 @@ static int emu_encode(int n, unsigned char *const *pbuffers, const unsigned char
     memset(pq, 0, sizeof(PoolQ));
     int counter[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     g_args.gT = &T; g_args.gK = &K; g_args.jobs = jobs; g_args.hdrs = hdrs; g_args.njobs = n; g_args.scr = sc; g_args.counter = counter;
-    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.post16 = 750; g_args.post32 = 1000; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0; g_args.quota = getenv("HOSTEMU_QUOTA") ? atoi(getenv("HOSTEMU_QUOTA")) : 1; g_args.fclk = nullptr; g_args.role = 0;      // (quota 0: no workgroup starts as a main one — idle helpers take the roles)
+    g_args.trace = trace; g_args.trace_cap = trace_cap; g_args.prof = nullptr; g_args.mail = mail; g_args.pq = pq; g_args.team_size = nhelp > 0 ? 2 : 1; g_args.nteams = nteams; g_args.nhelp = nhelp; g_args.post16 = 750; g_args.post32 = 1000; g_args.lim16 = 1; g_args.lim32 = 1; g_args.prio = 0; g_args.quota = getenv("HOSTEMU_QUOTA") ? atoi(getenv("HOSTEMU_QUOTA")) : 1; g_args.fclk = nullptr; g_args.role = 0; g_args.npart = npart;      // (quota 0: no workgroup starts as a main one — idle helpers take the roles)
     g_nfib = nwg * EMU_WG_THREADS; g_spins = 0;
     emu_run(emu_entry);
     for (int b = 0; b < nwg; b++) { free(pool[b]); free(g_shm_of[b]); free(g_pipe_of[b]); }
@@ -226,6 +227,12 @@ extern "C" int hostemu_HEVCImageEncoderPool(int n, unsigned char *const *pbuffer
                                             int *ysz, int *xsz, int qpd6, int *out_len, int nmains, int nhelp) {
     return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, nmains, nhelp);
 }
+// ... and `npart` partner workgroups (wide workgroups only: partner i evaluates the 2Nx2N sets of main workgroup i's 8x8 CUs)
+extern "C" int hostemu_HEVCImageEncoderPool3(int n, unsigned char *const *pbuffers, const unsigned char *const *imgs, unsigned char *const *rcons,
+                                             int *ysz, int *xsz, int qpd6, int *out_len, int nmains, int nhelp, int npart) {
+    return emu_encode(n, pbuffers, imgs, rcons, ysz, xsz, qpd6, out_len, nullptr, 0, nmains, nhelp, npart);
+}
+extern "C" void hostemu_remote8_stats(long *o, int reset) { for (int i = 0; i < 3; i++) { o[i] = g_remote8[i]; if (reset) g_remote8[i] = 0; } }
 // 1: the emulated workgroups have 256 threads, the fourth wavefront being the pipe wave (hevc_frame.h nxn_pipe); 0: 192 threads
 extern "C" void hostemu_set_pipe(int on) { g_wg_threads = on ? 256 : 192; }
 // 2: wide workgroups (512 threads: pipe wave + four partner wavefronts, the trial coders of the 8x8 CUs split over two wavefronts each)

@@ -313,11 +313,16 @@ def test_wide_workgroups_full_hd_frame_and_launches_too_large_for_them(amd):
     enc.set_wide(-1)
     b64 = enc.make_batch(imgs[:64], 0)
     enc.encode(b64); a = enc.results(b64)
-    assert enc.last_wide() and enc.last_shape() == (64, 128)
+    assert enc.last_wide() and enc.last_shape() == (64, 112) and enc.last_partners() == 64      # (round 6: a partner workgroup per main workgroup, the helpers cut to what is left of 15/16 of the compute units)
     b128 = enc.make_batch(imgs[:128], 0)
     enc.encode(b128); b = enc.results(b128)
     cus = enc.residency()["cus"]
-    assert enc.last_wide() and enc.last_shape() == (128, cus - 128)
+    assert enc.last_wide() and enc.last_split() and enc.last_shape() == (128, 3 * (cus - cus // 2))      # (round 6: two cooperating launches, wide main workgroups on one half of the compute units, 192-thread helpers on the other)
+    enc.set_split(0)
+    enc.encode(b128); b_one = enc.results(b128)
+    assert enc.last_wide() and not enc.last_split() and enc.last_shape() == (128, cus - 128)
+    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(b, b_one))
+    enc.set_split(-1)
     b200 = enc.make_batch(imgs, 0)
     enc.encode(b200); c200 = enc.results(b200)
     assert not enc.last_wide()
@@ -547,27 +552,28 @@ def test_pool_launch_beside_a_co_tenant_kernel(amd):
 
 def test_pool_as_two_launches_gives_identical_streams(amd):
     """A pool spread over TWO cooperating launches (hevc_hip.hip imcvt_hevc_plan_split: wide main workgroups on their own compute units, 192-thread
-    helper workgroups on the others, streams with disjoint compute-unit masks): 96 frames with two, three and four helpers per compute unit give what
-    one launch gives, and the CPU checker's bytes."""
+    helper workgroups on the others, streams with disjoint compute-unit masks): 120 frames with two, three and four helpers per compute unit give what
+    one launch gives, and the CPU checker's bytes.  (The halves are fixed: 120 main workgroups on 128 compute units.)"""
     import torch
     from oracle import oracle, synth
-    imgs = [synth.syn(64 + 32 * (s % 3), 64 + 32 * (s % 2), 100 + s) for s in range(96)]
+    imgs = [synth.syn(64 + 32 * (s % 3), 64 + 32 * (s % 2), 100 + s) for s in range(120)]
     enc = amd.DeviceEncoder()
     batch = enc.make_batch([torch.from_numpy(a).cuda() for a in imgs], 0)
+    enc.set_split(0)
     enc.encode(batch); ref = enc.results(batch)
     assert not enc.last_split()
-    for i in (0, 37, 95):
+    for i in (0, 37, 119):
         ws, wr, _ = oracle.cpu_encode(imgs[i], 0)
         assert ref[i][0] == ws and (ref[i][1] == wr).all(), i
     for hpc in (2, 3, 4):
         enc.set_split(1, hpc)
         enc.encode(batch); got = enc.results(batch)
-        assert enc.last_split() and enc.last_wide() and enc.last_shape() == (96, min(160 * hpc, 384)), (hpc, enc.last_shape())
+        assert enc.last_split() and enc.last_wide() and enc.last_shape() == (120, min(128 * hpc, 480)), (hpc, enc.last_shape())
         for i, ((s, r), (s2, r2)) in enumerate(zip(got, ref)):
             assert s == s2 and (r == r2).all(), (hpc, i)
-    enc.set_split(0)
+    enc.set_split(-1)
     enc.encode(batch)
-    assert not enc.last_split()
+    assert enc.last_split()                       # the default: where imcvt_hevc_plan_split says
     enc.close()
 
 
@@ -615,3 +621,45 @@ def test_host_batch_follows_the_running_launch(amd, monkeypatch):
     ws, wr, dims = oracle.cpu_encode(imgs[7], 1)
     assert a[7][0] == ws and (a[7][1] == wr).all() and a[7][2] == dims
     lib.imcvt_hevc_shutdown()
+
+
+def test_partner_workgroups_give_identical_streams(amd):
+    """Wide pools with PARTNER workgroups (hevc_frame.h "8x8 CUs with a partner workgroup": the two 2Nx2N candidate sets of every 8x8 CU on a second compute unit, the
+    main workgroup walking the NxN chain alone): the golden vectors one frame at a time (1 main + 1 partner + 2 helpers) and all in one launch, partners on
+    and off — the reference's streams and reconstructions either way."""
+    import torch
+    es = [e for e in SMALL if e["qpd6"] in (0, 4)]
+    enc = amd.DeviceEncoder()
+    for e in es[:6] + [e for e in es if e["input"].get("file") == "p5_gray.pgm"]:
+        b = enc.make_batch([torch.from_numpy(kat_input(e["input"]).copy()).cuda()], e["qpd6"])
+        enc.encode(b)
+        (s, r), = enc.results(b)
+        assert enc.last_wide() and enc.last_partners() == 1 and enc.last_shape() == (1, 2), kat_id(e)
+        assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+    for q in (0, 4):
+        qs = [e for e in es if e["qpd6"] == q]
+        batch = enc.make_batch([torch.from_numpy(kat_input(e["input"]).copy()).cuda() for e in qs], q)
+        for mode in (-1, 0):
+            enc.set_partners(mode)
+            enc.encode(batch)
+            assert enc.last_wide() and enc.last_partners() == (len(qs) if mode else 0), (q, mode, enc.last_shape())
+            for e, (s, r) in zip(qs, enc.results(batch)):
+                assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"], (kat_id(e), mode)
+    enc.set_partners(-1)
+    enc.close()
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_partner_workgroups_1080p_digest(amd, seed):
+    """One 1080p frame (BASELINE config 2's shape) with a partner workgroup — 1 main + 1 partner + 2 helper workgroups, a compute unit each — against the
+    reference's digests, stream and reconstruction."""
+    import torch
+    from oracle import synth
+    e = next(e for e in LARGE if e["input"].get("arg") == seed and e["qpd6"] == 0)
+    enc = amd.DeviceEncoder()
+    b = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, seed)).cuda()], 0)
+    enc.encode(b)
+    (s, r), = enc.results(b)
+    assert enc.last_wide() and enc.last_partners() == 1
+    assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
+    enc.close()

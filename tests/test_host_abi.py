@@ -190,14 +190,33 @@ def test_split_launch_policy(built):
         h = C.c_int(-1)
         return lib.imcvt_hevc_plan_split(mode, m, cus, wide_wg, occ, hpc, C.byref(h)), h.value
 
-    assert split(64) == (0, -1) and split(80) == (0, -1)              # 3 x 80 = 240 wide workgroups fit one launch
-    assert split(81) == (1, 324) and split(128) == (1, 384)           # (256 - m) compute units x 3 helpers, at most four per main workgroup
+    assert split(64) == (0, -1) and split(80) == (0, -1) and split(96) == (0, -1) and split(106) == (0, -1)      # one launch of wide workgroups leaves 1.4 helpers per main workgroup or more
+    assert split(107) == (1, 384) and split(112) == (1, 384) and split(128) == (1, 384)      # half of the compute units x 3 helpers, at most four per main workgroup
     assert split(128, hpc=2) == (1, 256) and split(128, hpc=4) == (1, 512) and split(128, hpc=9) == (1, 512)
     assert split(129) == (0, -1)                                       # beyond half of the compute units: as planned
-    assert split(100, mode=1) == (0, -1) and split(100, wide_wg=200) == (0, -1) and split(100, wide_wg=250)[0] == 1      # no pool / fewer wide workgroups resident than compute units
+    assert split(120, mode=1) == (0, -1) and split(120, wide_wg=200) == (0, -1) and split(120, wide_wg=250)[0] == 1      # no pool / fewer wide workgroups resident than compute units
     for m in range(1, 300):
         use, h = split(m)
-        assert use in (0, 1) and (not use or (m <= h <= 4 * m and m + (h + 2) // 3 <= 256))
+        assert use in (0, 1) and (not use or (m <= h <= 4 * m and 106 < m <= 128))
+
+
+def test_partner_workgroup_policy(built):
+    """imcvt_hevc_plan_partners is pure: a wide pool gets one partner workgroup per main workgroup (the 2Nx2N sets of its 8x8 CUs on a second compute unit) when the
+    launch has room beside the planned helpers, or with the helpers cut to what is left as long as 1.5 per main workgroup remain."""
+    import imcvt_amd
+    lib = imcvt_amd.load_library()
+
+    def part(m, h, wg=256, forced=0):
+        hh = C.c_int(h)
+        return lib.imcvt_hevc_plan_partners(m, C.byref(hh), wg, forced), hh.value
+
+    assert part(1, 2) == (1, 2) and part(48, 96) == (48, 96) and part(60, 120) == (60, 120)       # 4 x 60 = 240 = 15/16 of the compute units
+    assert part(61, 122) == (61, 118) and part(64, 128) == (64, 112) and part(68, 136) == (68, 104)   # helpers cut to the rest, 1.5 per main workgroup at least
+    assert part(69, 138) == (0, 138) and part(80, 160) == (0, 160)                                  # no room: as planned
+    assert part(64, 128, forced=1) == (64, 128) and part(65, 130, forced=1) == (0, 130)           # a forced shape may fill the last compute unit, and is never changed
+    for m in range(1, 130):
+        n, h = part(m, 2 * m)
+        assert n in (0, m) and (n == 0 or (2 * m + h <= 240 and 2 * h >= 3 * m)) and (n != 0 or h == 2 * m)
 
 
 def test_submission_queue_merges_concurrent_callers(built):

@@ -206,16 +206,16 @@ def test_rdoq_never_class_is_really_never(hostemu):
             assert all(hostemu.hostemu_rdoq_threshold(q, s, c) < 0 for c in range(10))
 
 
-def emu_encode_pool(lib, imgs, q, nmains, nhelp):
+def emu_encode_pool(lib, imgs, q, nmains, nhelp, npart=0):
     n = len(imgs)
     imgs = [np.ascontiguousarray(a) for a in imgs]
     outs = [np.zeros(2 * (a.shape[1] + 32) * (a.shape[0] + 32) + 65536, np.uint8) for a in imgs]
     rcs = [np.zeros(((a.shape[0] + 31) // 32 * 32) * ((a.shape[1] + 31) // 32 * 32), np.uint8) for a in imgs]
     P = u8p * n
     ys = (C.c_int * n)(*[a.shape[0] for a in imgs]); xs = (C.c_int * n)(*[a.shape[1] for a in imgs]); lens = (C.c_int * n)()
-    lib.hostemu_HEVCImageEncoderPool.restype = C.c_int
-    assert lib.hostemu_HEVCImageEncoderPool(n, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]),
-                                            P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, q, lens, nmains, nhelp) == 0
+    lib.hostemu_HEVCImageEncoderPool3.restype = C.c_int
+    assert lib.hostemu_HEVCImageEncoderPool3(n, P(*[o.ctypes.data_as(u8p) for o in outs]), P(*[a.ctypes.data_as(u8p) for a in imgs]),
+                                             P(*[r.ctypes.data_as(u8p) for r in rcs]), ys, xs, q, lens, nmains, nhelp, npart) == 0
     lib.hostemu_prog.restype = C.c_uint
     for i in range(n):
         assert lib.hostemu_prog(i, 0) == (ys[i] // 32 | 0x80000000) and lib.hostemu_prog(i, 1) == lens[i], i
@@ -270,6 +270,59 @@ def test_wide_workgroups_with_and_without_helpers(hostemu_wide, q, nmains, nhelp
     too) and as plain frame-per-workgroup launches pulling several frames each: the reference's bytes."""
     es = [e for e in OVF if e["qpd6"] == q]
     res = emu_encode_pool(hostemu_wide, [kat_input(e["input"]) for e in es], q, nmains, nhelp)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
+@pytest.mark.parametrize("nmains,nhelp,npart", [(1, 1, 1), (1, 2, 1), (2, 2, 2), (2, 3, 1)])
+@pytest.mark.parametrize("q", [0, 4])
+def test_wide_partner_workgroups_match_golden(hostemu_wide, q, nmains, nhelp, npart):
+    """Wide pools with PARTNER workgroups (hevc_frame.h "8x8 CUs with a partner workgroup"): main workgroup i posts the entry state of every 8x8 CU to
+    partner i, which evaluates the CU's two 2Nx2N candidate sets (TU 0 of the four-TU set made there, two lenders for the one-TU set) while the main
+    workgroup walks the NxN chain alone; the answer — the last minimum of the 70 — meets the NxN cost under the reference's order and tie rule
+    (:1439, :1475, :1545).  One partner for two main workgroups too (the second keeps its sets): the reference's bytes."""
+    es = [e for e in OVF if e["qpd6"] == q]
+    st = (C.c_long * 3)()
+    hostemu_wide.hostemu_remote8_stats(st, 1)
+    res = emu_encode_pool(hostemu_wide, [kat_input(e["input"]) for e in es], q, nmains, nhelp, npart)
+    hostemu_wide.hostemu_remote8_stats(st, 1)
+    ctus = sum(((e["input"].get("h", 32) + 31) // 32) * ((e["input"].get("w", 32) + 31) // 32) for e in es)
+    assert st[0] >= 16 * ctus * npart // (2 * nmains) and 0 < st[1] < st[0] and st[2] == 0, (list(st), ctus)      # the partners did serve, both kinds of winner occurred, nothing was abandoned
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
+def test_wide_partner_workgroups_natural_image(hostemu_wide):
+    # 10 x 9 CTUs of the reference's own sample picture at both ends of the quantiser range (every decision branch, SURVEY App. B.3)
+    for q in (0, 4):
+        e = next(e for e in kat_entries() if e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] == q)
+        (stream, rcon), = emu_encode_pool(hostemu_wide, [kat_input(e["input"])], q, 1, 1, 1)
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"] and hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], q
+
+
+def test_wide_partner_workgroups_exact_lead_paths(hostemu_wide_ovf):
+    es = [e for e in OVF if e["qpd6"] == 0]
+    res = emu_encode_pool(hostemu_wide_ovf, [kat_input(e["input"]) for e in es], 0, 1, 1, 1)
+    for e, (stream, rcon) in zip(es, res):
+        assert hashlib.sha256(stream).hexdigest() == e["sha256"] and hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
+@pytest.mark.parametrize("q", [0, 3])
+def test_abandoned_partner_answers_are_recomputed(hostemu_abn, q):
+    """... and a main workgroup that stops waiting for its partner (three polls here) walks the CU again itself — all three candidate sets, same bytes —
+    and posts nothing until the late answer has landed."""
+    es = [e for e in OVF if e["qpd6"] == q] or [e for e in OVF][:2]
+    hostemu_abn.hostemu_set_threads(512)
+    st = (C.c_long * 3)()
+    hostemu_abn.hostemu_remote8_stats(st, 1)
+    try:
+        res = emu_encode_pool(hostemu_abn, [kat_input(e["input"]) for e in es], es[0]["qpd6"], 1, 1, 1)
+    finally:
+        hostemu_abn.hostemu_set_threads(192)
+    hostemu_abn.hostemu_remote8_stats(st, 1)
+    assert st[2] > 0, list(st)              # answers were abandoned
     for e, (stream, rcon) in zip(es, res):
         assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)

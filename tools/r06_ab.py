@@ -11,7 +11,7 @@ import imcvt_amd
 from imcvt_amd import synth
 
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
-what = [a for a in sys.argv[1:] if not a.startswith("-") and not a.isdigit()] or ["wide", "split"]
+what = [a for a in sys.argv[1:] if not a.startswith("-") and not a.isdigit()] or ["wide", "split", "partners", "follow"]
 dev = torch.device("cuda", 0)
 gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bench512_kat.json")))["frames"]
 
@@ -47,9 +47,49 @@ if "wide" in what:
     for e in encs.values():
         e.close()
 
+if "partners" in what:
+    enc = imcvt_amd.DeviceEncoder()
+    for n in (1, 64):
+        imgs = frames(n)
+        b = enc.make_batch(imgs, 0)
+        res = {}
+        for r in range(reps):
+            for mode in (-1, 0):
+                enc.set_partners(mode)
+                enc.encode(b); torch.cuda.synchronize()
+                res.setdefault(mode, []).append((round(enc.last_kernel_ms(), 1), enc.last_partners(), enc.last_shape()))
+                check(b, n)
+        print(json.dumps({"probe": "partner_workgroups", "frames": n, "with_partners": {"ms": [v[0] for v in res[-1]], "partners": res[-1][0][1], "shape": list(res[-1][0][2])},
+                          "without": {"ms": [v[0] for v in res[0]], "partners": res[0][0][1], "shape": list(res[0][0][2])}}), flush=True)
+        del b, imgs
+    enc.set_partners(-1)
+    img4k = [torch.from_numpy(synth.syn(3840, 2160, 0)).to(dev)]
+    b = enc.make_batch(img4k, 0)
+    enc.encode(b); torch.cuda.synchronize()
+    print(json.dumps({"probe": "partner_workgroups", "frames": "one 4K frame", "ms": round(enc.last_kernel_ms(), 1), "partners": enc.last_partners()}), flush=True)
+    enc.close()
+
+if "follow" in what:
+    from imcvt_amd import hevc
+    n = 512
+    imgs = [synth.syn(1920, 1080, s) for s in range(n)]
+    hevc.HEVCImageEncoderBatch(imgs[:32], 0)
+    for mode in ("3", "1", "2", "0", "3"):
+        os.environ["IMCVT_HEVC_FOLLOW"] = mode
+        t0 = time.perf_counter()
+        res = hevc.HEVCImageEncoderBatch(imgs, 0, copy=False)
+        dt = time.perf_counter() - t0
+        xs = hevc.transfer_stats()
+        e = gold["511"]
+        assert len(res[511][0]) == e["bytes"] and hashlib.sha256(res[511][0]).hexdigest() == e["sha256"] and hashlib.sha256(res[511][1].tobytes()).hexdigest() == e["rcon_sha256"]
+        print(json.dumps({"probe": "host_follow", "IMCVT_HEVC_FOLLOW": mode, "wall_ms": round(dt * 1e3, 1), **{k: (round(v * 1e3, 1) if k.endswith("_s") else int(v)) for k, v in xs.items()}}), flush=True)
+        del res
+    del os.environ["IMCVT_HEVC_FOLLOW"]
+    imcvt_amd.load_library().imcvt_hevc_shutdown()
+
 if "split" in what:
     enc = imcvt_amd.DeviceEncoder()
-    for n in (128, 96, 112):
+    for n in (128, 112):
         imgs = frames(n)
         b = enc.make_batch(imgs, 0)
         res = {}
