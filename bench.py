@@ -337,16 +337,23 @@ def solo_view(enc, big, digests, qpd6, n=1000):
     b = enc.make_batch([big[i % F] for i in range(n)], qpd6)
     enc.set_team(1)
     enc.encode(b); torch.cuda.synchronize()
-    enc.encode(b); torch.cuda.synchronize()
-    ms = enc.last_kernel_ms()
-    resident, spread = enc.last_resident(), enc.last_start_spread_us()      # (a launch that fills the device to 97 % has been seen to start a workgroup seconds late)
+    # A launch that fills 97 % of the workgroup slots sporadically starts ONE workgroup seconds late (999 of 1000 resident, that frame then runs
+    # after the first workgroup has left — 14.3 s instead of 9.4 s; 3 launches of 8 on one box in round 6, profiles/r06c_ab.log).  Up to three timed launches: the
+    # line reports every one with its residency, `kernel_ms` is the best.
+    runs = []
+    for _ in range(3):
+        enc.encode(b); torch.cuda.synchronize()
+        runs.append({"kernel_ms": round(enc.last_kernel_ms(), 1), "resident_at_once": enc.last_resident(), "start_spread_us": enc.last_start_spread_us()})
+        if runs[-1]["resident_at_once"] >= n:
+            break
+    ms = min(r["kernel_ms"] for r in runs)
     enc.set_team(0)
     lens = b["lens"].cpu().tolist()
     same = all(hashlib.sha256(b["outs"][i][:lens[i]].cpu().numpy().tobytes()).hexdigest() == digests[i % F] for i in list(range(0, n, 37)) + [n - 1])
     if not same:
         raise SystemExit("solo_1000f: streams differ from the timed batch's")
     return {"frames": n, "kernel_ms": round(ms, 1), "mpx_s": round(n * W * H / ms / 1e3, 3), "shape": list(enc.last_shape()),
-            "resident_at_once": resident, "start_spread_us": spread, "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
+            "timed_launches": runs, "streams_equal_to_timed_batch": f"{len(range(0, n, 37)) + 1} sampled"}
 
 
 def share_view(enc, big, qpd6, k512):

@@ -538,6 +538,7 @@ struct alignas(16) WideCtl {
 // (pu_part_b) makes the REST (remaining levels: rows `brow` — bypass chunks only, which the byte half of the pricing takes from the rows itself);
 // another (pu_recon_k, pu_price) makes the reconstructions and SSE and runs the byte half of the pricing.  Tokens reach global memory only
 // where someone needs them there.
+#define NXN_KEEP_STRIDE 160                      // tokens reserved per kept PU winner (a PU candidate's stream is at most 1 + 34 + 72)
 #define BROW_CAP 72                              // tokens of a partner row: 16 levels x 32 bins at most + 7 pending sign bins = 519 bins <= 65 chunks
 #define BROW_STRIDE (BROW_CAP + 10)              // u16 per lane (41 dwords: odd): room for the 8 idle tokens that pad the last token block
 struct alignas(16) PuX {
@@ -546,6 +547,7 @@ struct alignas(16) PuX {
     i32 bcnt[NMODE];                             // tokens in the partner's row
     i32 na[NMODE];                               // tokens of the first part behind cbf_luma (lane row slots 8 ..)
     u32 pu_seq, b_seq, r_seq;                    // sequence number of the PU whose levels are published / whose rows are complete / whose reconstructions and SSE are in place
+    alignas(16) u16 kept[4 * NXN_KEEP_STRIDE];   // the four PU winners' tokens for the pipe wave (round 6: LDS instead of the candidate slot in memory — no store drain on the PU chain, no load latency on its tail): PUs 0 .. 2 back to back, PU 3 from 3 x NXN_KEEP_STRIDE, each run padded to a token block with idle tokens
 };
 #define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem) + sizeof(PuX))
 #define PUX (*(PuX *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem)))
@@ -2691,6 +2693,34 @@ HD void stream_seg_R(int &range, u8 *cx, SplitQ &q, int lane, int &blk, const u1
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(nv) : : "memory");
         cur.x = nv.x; cur.y = nv.y; cur.z = nv.z; cur.w = nv.w;
 #endif
+    }
+}
+// ... the same with the tokens in LDS (the kept PU winners of a wide workgroup's NxN trial, PuX::kept): no load to wait for
+HD void stream_seg_R_ldsrc(int &range, u8 *cx, SplitQ &q, int lane, int &blk, const u16 *p, int n) {
+    const int last_blk = imax((n - 1) >> 3, 0);
+    const int ql = lane < NMODE ? lane : 0;
+    u32 *const row = q.rec[ql];
+    const u32a *pw = (const u32a *)p;
+    U4 cur; cur.x = pw[0]; cur.y = pw[1]; cur.z = pw[2]; cur.w = pw[3];
+    int cons_seen = lds_ld_i32(&q.cons[ql]);
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        const u32a *pn = pw + 4 * imin((k0 >> 3) + 1, last_blk);
+        U4 nxt; nxt.x = pn[0]; nxt.y = pn[1]; nxt.z = pn[2]; nxt.w = pn[3];
+        if (k0 < n) {
+            while (WAVE_ANY(blk - cons_seen >= QDEPTH)) { if (blk - cons_seen >= QDEPTH) { pipe_pause(); cons_seen = lds_ld_i32(&q.cons[ql]); } }
+            u32 rec[8];
+            block_R8(range, cx, cur, rec);
+            u32 *d = row + (blk & (QDEPTH - 1)) * 8;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) d[j] = rec[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            blk++;
+            lds_st_i32(&q.prod[ql], blk);
+        }
+        cur = nxt;
     }
 }
 // The range half on RESOLVED tokens that lie in LDS (a lane's own row, or its row at a partner: hevc_frame.h pu_step_wide), 16-byte-block

@@ -465,7 +465,6 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
 // Token layout of a PU candidate (slot c): [7] cbf_luma, [8..] last position + group (the part PU pricing codes, :1515).
 // Slot NMODE holds the NxN stream ([0..) header, then the four winners' tokens) and, from NXN_KEEP on, the winners' copies.
 #define NXN_KEEP 1024
-#define NXN_KEEP_STRIDE 160
 // One PU step of the NxN chain in a wide workgroup, on the PU wave: pass and pricing of the 35 candidates of PU k (hevc_core.h "A PU step ...").
 //   here      prediction, DST, RDOQ -> levels published; first part of the tokens into the lane rows; range half of the pricing over them from LDS
 //             (the remaining-level rows are bypass chunks: the byte half prices them alone); PU 0 only: the complete streams to memory (the four-TU wave's TU 0)
@@ -623,20 +622,23 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
             // the pipe wave codes the winners of PUs 0..2 as ONE stream segment (kept back to back) and PU 3's as another: idle tokens up to
             // the block boundary after PU 2 and after PU 3
             const int at = !pipe ? k * NXN_KEEP_STRIDE : k == 3 ? 3 * NXN_KEEP_STRIDE : (k >= 1 ? W.pu_cnt[0] : 0) + (k >= 2 ? W.pu_cnt[1] : 0);
-            u16 *dst = nxn + NXN_KEEP + at;
-            if (F.wide && (k != 0 || lds_ld_i32(&WCTL.remote8) != 0)) {      // wide workgroup: the winner's tokens lie in its lane row (cbf_luma + first part) and in wave 7's row (remaining levels); PU 0's streams went to memory (unless nobody shares them)
+            const int end = at + cnt;
+            if (F.wide) {                               // wide workgroup: the winner's tokens lie in its lane row (cbf_luma + first part) and in wave 7's row (remaining levels) and are kept in LDS (PuX::kept): the pipe wave's coders read them there
+                u16 *dst = PUX.kept + at;
                 const int na1 = 1 + PUX.na[bm];
                 const u16 *ra = lane_row(W, bm) + 7, *rb = PUX.brow[bm];
-                for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), (int)(i < na1 ? ra[i] : rb[i - na1]));
-            } else
+                for (int i = l; i < cnt; i += 64) dst[i] = i < na1 ? ra[i] : rb[i - na1];
+                if (k >= 2 && l < 8 && ((end + l) >> 3) == (end >> 3) && (end & 7) != 0) PUX.kept[end + l] = (u16)TOK_IDLE;
+            } else {
+            u16 *dst = nxn + NXN_KEEP + at;
             for (int i = l; i < cnt; i += 64) g_st16((i16 *)(dst + i), g_ld16((const i16 *)(src + i)));
-            const int end = at + cnt;
             if (pipe && k >= 2 && l < 8 && ((end + l) >> 3) == (end >> 3) && (end & 7) != 0) g_st16((i16 *)(nxn + NXN_KEEP + end + l), (int)TOK_IDLE);
+            }
             if (l < 16) SM.rec[yk + (l >> 2) + 1][xk + (l & 3) + 1] = W.u.w2.rec4[bm][l];
         }
         wave_sync_lds();
         if (pipe && k >= 2) {                           // PUs 0..2 are enough for the pipe wave to start (it tries all 35 modes of PU 3 in the header), PU 3 lets it finish
-            wave_sync();                                // the kept tokens are in memory
+            if (!F.wide) wave_sync();                   // the kept tokens are in memory (wide workgroups keep them in LDS)
             LANES(l) { if (l == 0) lds_st_i32(k == 2 ? &SM.pipe_a : &SM.pipe_b, 1); }
         }
         if (F.wide) tl_mark(52 + k);                     // 52 .. 55: PU k decided and kept
@@ -733,12 +735,12 @@ HDN void nxn_pipe_wide() {
             if (on) ctx_copy(cx, SM.entry_cx[2]);
             stream_seg_R<false>(range, cx, q, l, blk, hdr, on ? nh : 0);
             const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
-            stream_seg_R<false>(range, cx, q, l, blk, kept, on ? n012 : 0);
+            stream_seg_R_ldsrc(range, cx, q, l, blk, PUX.kept, on ? n012 : 0);
             while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
-            wave_sync();
+            wave_sync_lds();
             if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));      // PU 3 is decided: the partner may go on too
             const int mine = on & (l == W2.pu_mode[3]);
-            stream_seg_R<false>(range, cx, q, l, blk, kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+            stream_seg_R_ldsrc(range, cx, q, l, blk, PUX.kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
             if (mine) { q.range_out[l] = range; SM.nxn_lane = l; }
             if (l == 0) { lds_st_i32(&SM.pipe_a, 0); lds_st_i32(&SM.pipe_b, 0); }
         }
@@ -1387,6 +1389,7 @@ HDN void remote8_wave0(int y0_, int x0_, int avm_) {
     drain_stores();
     wave_sync();
     LANES(l) { if (l == 0) { lds_st_i32(&C.seq8, seq); m_st32(&m->req_flag, (u32)seq); } }
+    tl_mark(11);                                               // 11: the request is out
     // the answer: lane 0 polls, then the wavefront stages it
     LANES(l) {
         if (l == 0) {
@@ -1405,6 +1408,7 @@ HDN void remote8_wave0(int y0_, int x0_, int avm_) {
         }
     }
     wave_sync_lds();
+    tl_mark(67);                                               // 67: the answer's flag seen
     if (lds_ld_i32(&C.ans_seq) != seq) return;
     const HelpRes *R = &m->res;
     Ans8 &A8 = ANS8;
@@ -1424,14 +1428,17 @@ HDN int decide_cu8_remote(int y0_, int x0_, int avm_) {
     const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
     u8 *live_sink = F.job.out + F.out_pos;
     WideCtl &C = WCTL;
+    tl_start();                                                // (-DIMCVT_PROF_TL builds: timeline of the CU, tools/prof_timeline.py)
     WAVES_ALL(w) {
         if (w == 0) remote8_wave0(y0, x0, avm);
         else if (w == 2) eval_NxN(2, y0, x0, avm);
         else if (w == PIPE_WAVE) { partner_pu_early(y0, x0); nxn_pipe(y0, x0); }
         else if (w == WAVE_B_CODER) partner_pipe();            // (wave 4: a SIMD of its own here — the one-TU set's wavefront that shares it elsewhere is idle)
         else if (w == WAVE_A_PARTNER) partner_pu(y0, x0);      // (wave 5: likewise)
+        if (w == 0 || (w >= 2 && w <= 5)) tl_mark(1 + w);      // 1: the partner's answer is staged; 3 .. 6: the NxN chain's wavefronts are through
     }
     wg_sync_p();
+    WAVES(w) { if (w == 0) tl_mark(9); }
     if (lds_ld_i32(&C.ans_seq) != lds_ld_i32(&C.seq8)) {       // gave up (or the watchdog fired): this mailbox is out of use until the late answer has arrived
         WAVES(w) LANES(l) { if (w == 0 && l == 0) { lds_st_i32(&C.stale8, lds_ld_i32(&C.seq8)); lds_st_i32(&C.remote8, 0); C.cu8++; F.kept++; R8CNT(2); } }      // (cu8: the PU steps of the second walk get sequence numbers of their own)
         wg_sync();
@@ -1501,6 +1508,7 @@ HDN int decide_cu8_remote(int y0_, int x0_, int avm_) {
         }
         wg_sync_p();
     }
+    WAVES(w) { if (w == 0) tl_mark(10); }
     return 0;
 }
 
@@ -1514,6 +1522,7 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
     const int y0 = ld_i(&Q->y0), x0 = ld_i(&Q->x0), avm = ld_i(&Q->avm);
     const int depth = 2, N = 8;
     const int newframe = frame != F.frame;                      // (the job and the per-quantiser tables change with the frame, not with the CU)
+    tl_start();                                                 // (timeline builds: the request has been seen)
     WAVES(w) LANES(l) {
         if (w == 0 && l == 0) { if (newframe) F.job = jobs[frame]; F.ctu_y = cy; F.ctu_x = cx; F.out_pos = 0; F.trace_n = 0; WCTL.cu8++; }
     }
@@ -1550,13 +1559,16 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
         }
     }
     wg_sync();
+    WAVES(w) { if (w == 0) tl_mark(11); }                       // 11: inputs staged
     WAVES_ALL(w) {
         if (w < 2) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else if (w == 2) { lend_passes(2, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }      // candidates 16 .. 31 of the one-TU set, then the byte half of its coders (SIMD c)
         else if (w == PIPE_WAVE) partner_fourtu(depth);                                             // the four-TU set's coders, segment by segment behind wave 1's passes (SIMD d)
         else if (w == WAVE_PU_PARTNER) lend_passes(w, 1, 32, NMODE, y0, x0, avm);                   // candidates 32 .. 34 (wave 7)
+        if (w <= PIPE_WAVE || w == WAVE_PU_PARTNER) tl_mark(1 + w);      // 1 .. 4, 8: the wavefronts are through the candidate sets
     }
     wg_sync();
+    WAVES(w) { if (w == 0) tl_mark(9); }
     WAVES(w) LANES(l) {
         if (w == 0) {
             int m1, m2;
@@ -1578,7 +1590,9 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
         }
         const FinState fe = WM(ww).fin[mode];
         wg_sync();
+        WAVES(w) { if (w == 0) tl_mark(12); }                   // 12: winner picked, its contexts out
         rebuild_winner(kind, mode, N, y0, x0, avm);
+        WAVES(w) { if (w == 0) tl_mark(13); }                   // 13: winner's reconstruction rebuilt
         WAVES(w) LANES(l) {
             if (w == 1) {
                 const Arith e = unpack_arith(fe);
@@ -1588,6 +1602,7 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
                 if (l == 0) SM.live = a;
             }
         }
+        WAVES(w) { if (w == 1) tl_mark(14); }                   // 14: its leads are bytes
         wg_sync();
         const FinState fin = pack_arith(SM.live);
         const int nbytes = SM.live.cnt - cnt0;
@@ -1606,6 +1621,7 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
         }
     }
     team_publish(&m->res_flag, seq);
+    WAVES(w) { if (w == 0) tl_mark(10); }                       // 10: answered
 }
 // partner workgroup `pid`: serves main workgroup pid's 8x8 requests until every frame is finished
 HDN void partner8_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int pid_, int njobs_) {
@@ -1613,6 +1629,9 @@ HDN void partner8_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob 
     const int pid = uni_i(pid_); const int njobs = uni_i(njobs_);
     MailSlot *m = &mail[pid].s[SLOT_8];
     stage_tables(gT);
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+    if (threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) SM.prof[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
+#endif
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.sc = sc; F.mail = (TeamMail *)0; F.pq = pq; F.frame = -1; F.aborted = 0; WCTL.solo2n = 1; m_st32(&m->pad0_[8], 1u); } }      // (pad0_[8]: "the partner has reported in")
     wg_sync();
     int served = 0;
@@ -1636,6 +1655,9 @@ HDN void partner8_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob 
         served++;
         wg_sync();
     }
+#if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
+    if (sc.prof && threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(2 * NWAVES + (threadIdx.x >> 6)) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);      // role 2's slice
+#endif
 }
 
 

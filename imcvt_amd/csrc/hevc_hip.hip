@@ -67,7 +67,7 @@ struct imcvt_hevc_ctx {
     int wide = -1, wide_wg = 0, occ_wide = 0, last_wide = 0;   // wide workgroups (512 threads: pipe wave + four partner wavefronts, one workgroup per compute unit): < 0 whenever a pipe-wave launch fits wide_wg workgroups, 0 never, 1 as -1
     int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
     int wide_kernel = 0, wide_scratch = 0;  // wide launches run hevc_encode_frames_wide (hevc_wide.hip; IMCVT_HEVC_WIDE_KERNEL=0: the common instantiation), its private segment per lane
-    int partners = -1, last_part = 0;       // partner workgroups (wide pools: the 2Nx2N sets of a main workgroup's 8x8 CUs on a second compute unit, hevc_frame.h): < 0 wherever they fit, 0 never, 1 as < 0
+    int partners = 0, last_part = 0;        // partner workgroups (wide pools: the 2Nx2N sets of a main workgroup's 8x8 CUs on a second compute unit, hevc_frame.h): 0 never (default: measured slower), 1 / < 0 wherever they fit
     int split = -1, split_hpc = 0, last_split = 0;      // a pool spread over two cooperating launches (launch_split): < 0 where planned, 0 never, 1 as < 0; helper workgroups per compute unit of the helpers' set (0: default)
     hipStream_t st_split[2] = { nullptr, nullptr }; int split_cus[2] = { 0, 0 };      // streams bound to two disjoint sets of compute units, and how many each holds
     hipEvent_t ev_split[3] = { nullptr, nullptr, nullptr };
@@ -228,14 +228,14 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     // every workgroup leaves at once) bring the ring to size before real work arrives.
     auto prewarm = [&]() {
         bool good = true;
+        if (c->wide_kernel && c->wide_wg > 0) {      // the wide instantiation's private segment first: the LAST launches the runtime sees before real work are full 192-thread ones
+            good = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;      // (a 256-thread census launch in that place left a later full launch with ~940 of 1000 workgroups resident, profiles/r04c_census_probe.log)
+            if (good) launch(c, c->wide_wg, 0, 0, 1, 0, 0, 2);
+            good = good && hipDeviceSynchronize() == hipSuccess;
+        }
         for (int i = 0; i < 3 && good; i++) {
             good = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;
             if (good) launch(c, c->max_wg, 0, 0, 1, 0, 0);
-            good = good && hipDeviceSynchronize() == hipSuccess;
-        }
-        if (good && c->wide_kernel && c->wide_wg > 0) {      // the wide instantiation's private segment too, before real work arrives
-            good = hipMemset(c->d_counter, 0, 8 * sizeof(int)) == hipSuccess;
-            if (good) launch(c, c->wide_wg, 0, 0, 1, 0, 0, 2);
             good = good && hipDeviceSynchronize() == hipSuccess;
         }
         return good;
@@ -688,7 +688,7 @@ struct DevState {
 static std::mutex g_lock;
 static std::vector<DevState> g_devs;
 static int g_last_devices = 0;
-static double g_xfer[5];                        // last batch: seconds uploading, following, collecting the tail; bytes copied while the launch ran / after it
+static double g_xfer[6];                        // last batch: seconds uploading, following, collecting the tail; bytes copied while the launch ran / after it
 
 static int dev_init(DevState &d) {
     if (d.ctx) return 0;
@@ -717,6 +717,7 @@ static void dev_release(DevState &d) {
 }
 
 extern "C" int imcvt_hevc_batch_devices(void) { return g_last_devices; }
+extern "C" double imcvt_hevc_batch_kernel_ms(void) { std::lock_guard<std::mutex> guard(g_lock); return g_xfer[5]; }      // the longest kernel time (HIP events) over the devices of the last host-pointer batch
 extern "C" void imcvt_hevc_batch_transfer_stats(double *upload_s, double *follow_s, double *tail_s, double *bytes_during, double *bytes_after) {
     std::lock_guard<std::mutex> guard(g_lock);
     if (upload_s) *upload_s = g_xfer[0];
@@ -987,12 +988,13 @@ static int encode_batch_on_devices(int n, unsigned char *const *pbuffers, const 
     int rc = 0;
     for (int k = 0; k < D; k++) if (rc == 0) rc = dev_of(k).rc;
     for (int k = 0; k < D; k++) { DevState &d = dev_of(k); if (rc != 0 && d.rc == 0) d.rc = rc; finish_device(d, A); if (rc == 0) rc = d.rc; }      // (after an error nothing more is copied, but every stream is drained)
-    for (int k = 0; k < 5; k++) g_xfer[k] = 0;
+    for (int k = 0; k < 6; k++) g_xfer[k] = 0;
     for (int k = 0; k < D; k++) {
         DevState &d = dev_of(k);
         if (rc == 0) for (size_t j = 0; j < d.idx.size(); j++) { const int i = d.idx[j]; out_len[i] = d.lens[j]; ysz[i] = imcvt_hevc_padded(ysz[i]); xsz[i] = imcvt_hevc_padded(xsz[i]); }
         g_xfer[0] = d.t_up > g_xfer[0] ? d.t_up : g_xfer[0]; g_xfer[1] = d.t_follow > g_xfer[1] ? d.t_follow : g_xfer[1]; g_xfer[2] += d.t_tail;
         g_xfer[3] += (double)d.followed; g_xfer[4] += (double)d.tail;
+        if (d.launched) { const double km = (double)imcvt_hevc_last_kernel_ms(d.ctx); if (km > g_xfer[5]) g_xfer[5] = km; }
         d.idx.clear();
     }
     g_last_devices = D;

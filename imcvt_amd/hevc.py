@@ -28,7 +28,7 @@ EXPORTS = ("HEVCImageEncoder", "writeHEVCImageFile", "HEVCImageEncoderBatch", "i
            "imcvt_hevc_set_trace", "imcvt_hevc_debug_prof", "imcvt_hevc_debug_occupancy", "imcvt_hevc_version",
            "imcvt_hevc_set_team", "imcvt_hevc_set_pipe", "imcvt_hevc_last_pipe", "imcvt_hevc_set_wide", "imcvt_hevc_last_wide", "imcvt_hevc_plan_wide", "imcvt_hevc_plan_wide_pool", "imcvt_hevc_last_team", "imcvt_hevc_last_shape", "imcvt_hevc_set_shape", "imcvt_hevc_set_pool_tuning", "imcvt_hevc_set_pool_split", "imcvt_hevc_batch_devices", "imcvt_hevc_shutdown", "imcvt_hevc_debug_census", "imcvt_hevc_last_resident", "imcvt_hevc_last_status", "imcvt_hevc_set_frame_clock", "imcvt_hevc_last_start_spread_us", "imcvt_hevc_plan", "imcvt_hevc_plan_pipe",
            "imcvt_hevc_residency", "imcvt_hevc_debug_filler", "imcvt_hevc_debug_set_backend", "imcvt_hevc_coalesce_stats",
-           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats", "imcvt_hevc_set_split", "imcvt_hevc_last_split", "imcvt_hevc_plan_split",
+           "imcvt_hevc_set_progress", "imcvt_hevc_batch_transfer_stats", "imcvt_hevc_batch_kernel_ms", "imcvt_hevc_set_split", "imcvt_hevc_last_split", "imcvt_hevc_plan_split",
            "imcvt_hevc_set_partners", "imcvt_hevc_last_partners", "imcvt_hevc_plan_partners")
 
 
@@ -136,6 +136,8 @@ def load_library():
         lib.imcvt_hevc_set_progress.argtypes = [C.c_void_p, C.c_void_p]
         lib.imcvt_hevc_batch_transfer_stats.restype = None
         lib.imcvt_hevc_batch_transfer_stats.argtypes = [C.POINTER(C.c_double)] * 5
+        lib.imcvt_hevc_batch_kernel_ms.restype = C.c_double
+        lib.imcvt_hevc_batch_kernel_ms.argtypes = []
         lib.imcvt_hevc_set_split.restype = None
         lib.imcvt_hevc_set_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.imcvt_hevc_last_split.restype = C.c_int
@@ -194,7 +196,7 @@ def transfer_stats():
     lib = load_library()
     v = [C.c_double(0) for _ in range(5)]
     lib.imcvt_hevc_batch_transfer_stats(*[C.byref(x) for x in v])
-    return dict(zip(("upload_s", "follow_s", "tail_s", "bytes_during", "bytes_after"), (x.value for x in v)))
+    return dict(zip(("upload_s", "follow_s", "tail_s", "bytes_during", "bytes_after"), (x.value for x in v)), kernel_ms=float(lib.imcvt_hevc_batch_kernel_ms()))
 
 
 def HEVCImageEncoderBatch(imgs, qpd6=0, copy=True):

@@ -74,6 +74,8 @@ int imcvt_hevc_batch_devices(void);
  * ended; bytes copied out while the launch ran / after it.  The reference's writeHEVCImageFile (src/imageio_hevc.c:14-52) has no counterpart:
  * its encoder works in the caller's memory. */
 void imcvt_hevc_batch_transfer_stats(double *upload_s, double *follow_s, double *tail_s, double *bytes_during, double *bytes_after);
+/* Kernel time of the last host-pointer batch in milliseconds (HIP events on the launch stream; the longest over its devices). */
+double imcvt_hevc_batch_kernel_ms(void);
 /* Releases the contexts, streams and device memory the host-pointer entry points hold (they are re-created on the next call). */
 void imcvt_hevc_shutdown(void);
 
@@ -143,8 +145,10 @@ int imcvt_hevc_plan_wide(int use_pipe, int grid, int wide_wg, int forced_shape);
  * workgroups — *nhelp is cut to the rest.  Returns 1 if the launch runs wide workgroups. */
 int imcvt_hevc_plan_wide_pool(int use_pipe, int mode, int forced_shape, int wide_wg, const int *nmains, int *nhelp);
 /* Partner workgroups (wide pools): every main workgroup gets a second compute unit that evaluates the two 2Nx2N candidate sets of its 8x8 CUs while it walks their
- * NxN chains alone (four wavefronts, a SIMD each) — shorter frames wherever one frame's serial chain sets the pace.  mode < 0 (default) / 1: wherever
- * imcvt_hevc_plan_partners finds room; 0: never.  Results are identical.  Environment at context creation: IMCVT_HEVC_PARTNERS. */
+ * NxN chains alone (four wavefronts, a SIMD each).  mode 0 (default): never — measured on MI355X the partner's answer arrives after the NxN chain has finished
+ * (its four-TU set is a chain of four 4x4 passes, 29 k cycles each), one 1080p frame 2.43 s against 2.16 s, and with an infinitely fast partner the CU would gain
+ * 6 % (profiles/r06c_timeline.log); 1 / < 0: wherever imcvt_hevc_plan_partners finds room.  Results are identical.  Environment at
+ * context creation: IMCVT_HEVC_PARTNERS. */
 void imcvt_hevc_set_partners(imcvt_hevc_ctx *ctx, int mode);
 /* Partner workgroups of the last launch (0 or its main workgroups). */
 int imcvt_hevc_last_partners(imcvt_hevc_ctx *ctx);

@@ -15,7 +15,9 @@ batch = enc.make_batch([torch.from_numpy(synth.syn(w, h, 0)).cuda()], q)
 enc.encode(batch); torch.cuda.synchronize(); enc.debug_prof(True)
 enc.encode(batch); torch.cuda.synchronize()
 ms = enc.last_kernel_ms()
-flat = [v for row in enc.debug_prof(True)[:3] for v in row]
+prof = enc.debug_prof(True)
+flat = [v for row in prof[:3] for v in row]
+part = [v for row in prof[6:9] for v in row] if len(prof) >= 9 else []      # role 2: the partner workgroup (8x8 CUs' 2Nx2N sets on a second compute unit)
 n = flat[0]
 names = {9: "all waves through the candidate sets (barrier)", 10: "winner committed"}
 for wv, what in enumerate(["wave 0 (one-TU set: passes, range half)", "wave 1 (four-TU set: passes)", "wave 2 (PU chain)", "wave 3 (pipe)", "wave 4 (four-TU set: coders)",
@@ -28,8 +30,20 @@ for k in range(4):
     names[52 + k] = f"PU {k}: decided and kept"; names[36 + k] = f"four-TU set: TU {k} passed"
 names[56] = "PU 1: step begins"; names[57] = "PU 1: borders made"; names[58] = "PU 1: pricing: guard checked"; names[59] = "PU 1: pricing: reconstructions seen"; names[60] = "PU 1: pricing: costs stored"; names[61] = "PU 1: mode picked"
 names[62] = "PU 1: predicted"; names[63] = "PU 1: transformed"; names[64] = "PU 1: quantised"
+names[11] = "request to the partner workgroup is out"; names[67] = "the partner's answer: flag seen"
 names[40] = "wave 0: first pass item done"; names[41] = "wave 0: second pass item done"; names[42] = "one-TU set: tokens complete"
 print(f"trials finished {flat[66]}, with lanes on the exact path {flat[65]}")
 print(f"1 x {w}x{h} q{q}: kernel {ms:.1f} ms, wide {enc.last_wide()}, {n} 8x8 CUs; average cycles since the CU was entered:")
 for ev, t in sorted(((ev, flat[ev] / max(n, 1)) for ev in names if flat[ev]), key=lambda x: x[1]):
     print(f"  {t:9.0f}  {names[ev]}")
+
+if part and part[0]:
+    pn = part[0]
+    pnames = {11: "inputs staged", 1: "wave 0 (one-TU set: pass 0..15, range half) done", 2: "wave 1 (four-TU set: passes, last range half) done", 3: "wave 2 (one-TU set: pass 16..31, byte half) done",
+              4: "wave 3 (four-TU set: coders) done", 8: "wave 7 (one-TU set: pass 32..34) done", 9: "all wavefronts through (barrier)", 12: "winner picked", 13: "winner rebuilt", 14: "winner's leads are bytes", 10: "answered",
+              42: "one-TU set: tokens complete", 40: "wave 0: first pass item done"}
+    for k in range(4):
+        pnames[36 + k] = f"four-TU set: TU {k} passed"
+    print(f"partner workgroup, {pn} requests; average cycles since the request was seen:")
+    for ev, t in sorted(((ev, part[ev] / pn) for ev in pnames if part[ev]), key=lambda x: x[1]):
+        print(f"  {t:9.0f}  {pnames[ev]}")
