@@ -32,6 +32,7 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
 #define WG_THREADS_WIDE ((NWAVES + 1 + XWAVES) * 64)
 #define NMODE 35
 #define I32MAX 0x7fffffff
+#define REG_N 96           // region counters of -DIMCVT_REGCNT builds (RCNT below)
 
 #ifdef IMCVT_HOSTEMU
   struct uint2 { uint32_t x, y; }; struct int4 { int32_t x, y, z, w; };
@@ -463,6 +464,9 @@ struct alignas(16) Shm {
     i32 pipe_a, pipe_b;          // PU wave -> pipe wave: the winners of PUs 0..2 / of PU 3 are in place (cleared by the pipe wave)
     i32 nxn_lane;                // pipe wave: the lane that holds the NxN trial's result (= PU 3's mode)
     i32 pu0_ready, pu0_taken;    // 8x8 CU: the PU wave's pass over PU 0 is complete / the four-TU wave has taken its copy (hevc_frame.h tu0_from_pu0)
+#ifdef IMCVT_REGCNT
+    i32 regcnt[REG_N];           // (-DIMCVT_REGCNT: executions of the marked regions by this workgroup's wavefronts)
+#endif
 #ifdef IMCVT_PROF
     unsigned long long prof[NWAVES][PF_N];
     unsigned long long tl_t0;    // (-DIMCVT_PROF_TL: when the 8x8 CU being walked was entered)
@@ -474,7 +478,7 @@ struct alignas(16) Shm {
     alignas(16) u8 wraw[NWAVES * sizeof(WaveMem)];   // wave slices (wave 2 runs full pipeline passes for the 16x16 / 32x32 CUs too)
 };
 
-#ifndef IMCVT_PROF
+#if !defined(IMCVT_PROF) && !defined(IMCVT_REGCNT)
 static_assert(sizeof(Shm) <= 40960, "four workgroups per compute unit need an LDS image of at most 160 KB / 4");
 #endif
 // The workgroup's LDS image is one file-scope object, so non-inlined callees still address it with ds_* ops.
@@ -1670,12 +1674,17 @@ HD int tokg_end(const TokOut &o, int cnt, TgB &B) {
 }
 #undef TK_EMIT
 // one group into the shared pass buffer / count only: tokens k0.. of the writer; returns the count | c1-zero flag << 16
-HD int tok_count(const Lv16 &L, u32 nzm, int cfg) {
+#if defined(IMCVT_MARK) && !defined(IMCVT_HOSTEMU)
+#define HD_RARE HDN      // (-DIMCVT_MARK compiles: the two fallbacks of an overflowing token row — 0.003 % of the groups — stay out of the regions' static counts)
+#else
+#define HD_RARE HD
+#endif
+HD_RARE int tok_count(const Lv16 &L, u32 nzm, int cfg) {
     TokOut o; o.tb = (u16 *)0; o.pos = 0; o.cap = 0; o.glob = 0; TgB B;
     const int ra = tokg_a<false, false>(o, 0, L, nzm, cfg, B);
     return tokg_end<false, false>(o, tokg_b<false, false, 15, 0>(o, ra & 0xFFFF, L, B), B) | (ra & ~0xFFFF);
 }
-HD int tok_write(u16 *p, int k0, const Lv16 &L, u32 nzm, int cfg) {      // straight into the candidate's stream in global memory
+HD_RARE int tok_write(u16 *p, int k0, const Lv16 &L, u32 nzm, int cfg) {      // straight into the candidate's stream in global memory
     TokOut o; o.tb = p; o.pos = 0; o.cap = 0; o.glob = 1; TgB B;
     const int ra = tokg_a<true, false>(o, k0, L, nzm, cfg, B);
     return tokg_end<true, false>(o, tokg_b<true, false, 15, 0>(o, ra & 0xFFFF, L, B), B) | (ra & ~0xFFFF);
@@ -1735,6 +1744,23 @@ HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag, u32 *mc) 
 #else
 #define MARK(x)
 #endif
+// Region counters (-DIMCVT_REGCNT builds, tools/valu_dyn_mix.py): how often each marked region of the pipeline, the token generators and the stream coders is
+// executed — wave executions, counted by lane 0 at the region's END marker.  With the static opcode histogram of the region (a -DIMCVT_MARK compile) this gives the
+// DYNAMIC opcode mix of the kernel.  MARKR(name, r): region r of p1_run_t<LG> (one counter per transform size s = LG - 2); MARKQ(name, id): a region with one counter.
+#if defined(IMCVT_REGCNT) && !defined(IMCVT_HOSTEMU)
+#define RCNT(id) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&SM.regcnt[id], 1); } while (0)
+#else
+#define RCNT(id) do {} while (0)
+#endif
+#if defined(IMCVT_MARK) && !defined(IMCVT_HOSTEMU)
+#define MARKB(x) asm volatile("; MARK " x " begin" ::: "memory")      // where a run of regions begins: what lies before it in the text is not theirs
+#define MARKR(x, r) asm volatile("; MARK " x " s%c0" : : "n"(s) : "memory")
+#define MARKQ(x, id) asm volatile("; MARK " x " s0" ::: "memory")
+#else
+#define MARKB(x) do {} while (0)
+#define MARKR(x, r) RCNT(8 + 4 * (r) + s)
+#define MARKQ(x, id) RCNT(id)
+#endif
 // ---- 4x4 blocks: one lane owns the whole block, so the pipeline runs entirely in registers (DST constants are
 // immediates, no LDS intermediates, no wave syncs between the stages) and the lane writes the TU's tokens itself.
 HD void p1_run_4(int wave, const P1Args &P) {
@@ -1746,12 +1772,13 @@ HD void p1_run_4(int wave, const P1Args &P) {
         const int c = l;
         if (c < ncand) {
             const int mode = (P.only_mode >= 0) ? P.only_mode : c;
+            MARKB("b4");
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4], x[4][4], t[4][4];
-            MARK("b4_setup");
+            MARKQ("b4_setup", 0);
             long long t4 = prof_now();
             pred_block4(T, br, 4, 2, mode, 0, 0, pr);
-            MARK("b4_predict");
+            MARKQ("b4_predict", 1);
             for (int yi = 0; yi < 4; yi++) {
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + yi][P.x0];
                 for (int xi = 0; xi < 4; xi++) x[yi][xi] = (int)((ow >> (8 * xi)) & 255) - pr[yi][xi];
@@ -1771,10 +1798,10 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 x[i][2] = 84 * a - 29 * b - 74 * cc_ + 55 * d + 128;
                 x[i][3] = 55 * a - 84 * b + 74 * cc_ - 29 * d + 128;
             }
-            MARK("b4_residual_dst");
+            MARKQ("b4_residual_dst", 2);
             prof_add(PF_T_HDR, t4); t4 = prof_now();        // (4x4 pipeline, IMCVT_PROF builds: t_hdr = predict + DST, passA = RDOQ, p2_8 on wave 2 = tokens, recon = inverse + SSE)
             const int any = rdoq_group<0>(x, Q);
-            MARK("b4_rdoq");
+            MARKQ("b4_rdoq", 3);
             prof_add(PF_T_GEN, t4); t4 = prof_now();
             const int st = scan_type_of(4, mode);
             if (P.tok) {                                    // the TU's tokens: cbf_luma, last position, the one group
@@ -1801,7 +1828,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 ls_end(ls, w, W, c);
                 W.tnz[c] = (u8)(nzm != 0);
             }
-            MARK("b4_tokens");
+            MARKQ("b4_tokens", 4);
             prof_add(threadIdx_wave() == 2 ? PF_P2_8 : PF_T_NTOK, t4); t4 = prof_now();
             int part = 0;
             if (any) {
@@ -1843,7 +1870,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                 }
             }
             if (P.only_mode < 0) W.sse[c] += part;         // this lane is the only writer of sse[c] in this pass
-            MARK("b4_inverse_recon_sse");
+            MARKQ("b4_inverse_recon_sse", 5);
             prof_add(threadIdx_wave() == 2 ? PF_RECON : PF_T_NDRAIN, t4);
         }
     }
@@ -2086,6 +2113,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
     NOUNROLL
     for (int c0 = P.c_lo; c0 < ncand; c0 += G) {
       {
+        MARKB("pass");
         // lane <-> coefficient group: slot sl of this pass, group of scan rank r of that candidate's TU
         const int sl = l / lpc, r = l % lpc, c = c0 + sl, live = c < ncand;
         const int mode = (P.only_mode >= 0) ? P.only_mode : (live ? c : 0);
@@ -2095,7 +2123,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
         i16 *const rt = W.u.p1.res + sl * TR; i32 *const tt = W.u.p1.tmp + sl * TT; i16 *const it = (i16 *)W.u.p1.tmp + sl * TI;
         const int tokn0 = (P.tok && live) ? WO.tokn[c] : 0;
         u32 predw[4] = { 0, 0, 0, 0 };                  // this lane's 4x4 block of the prediction, a packed row per dword (kept in registers until step 5)
-        MARK("pass_setup");
+        MARKR("pass_setup", 0);
         u32 pq[4] = { 0, 0, 0, 0 };                     // matrix-core passes: this lane's strips of the prediction (a sample per byte)
         if constexpr (MX) {
             // ---- steps 1-3a on the matrix cores: prediction in the operand layout, tmp^T = res^T C^T, coef^T = C tmp^T (limbs)
@@ -2111,7 +2139,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 }
                 pn[d] = pq[d] ^ 0x7F7F7F7Fu;
             }
-            MARK("mx_predict");
+            MARKR("mx_predict", 1);
             int acc[16];
             const int i1 = ra + (0x8080 << a1) + (mi == 0 ? 64 * N : 0);
             for (int r4 = 0; r4 < 16; r4++) acc[r4] = i1;
@@ -2132,7 +2160,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 if (LG == 5) *(int4 *)(ct + mi * CST + 8 * d + 4 * mh) = o;
                 else if (d < nlive) *(int4 *)(ct + d * CTILE + mi * CST + 4 * mh) = o;
             }
-            MARK("mx_forward");
+            MARKR("mx_forward", 2);
         } else {
         // ---- step 1: prediction and residual
         if (live) {
@@ -2140,7 +2168,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
             int pr[4][4];
             pred_block4(T, br, N, LG, mode, by * 4, bx * 4, pr);
-            MARK("predict");
+            MARKR("predict", 3);
             for (int yi = 0; yi < 4; yi++) {
                 const int y = by * 4 + yi;
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
@@ -2152,7 +2180,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
-        MARK("residual");
+        MARKR("residual", 4);
         // ---- step 2: tmp = (C * res + ra) >> a                                              (:514 forward)
         if (live) {
             int acc[4][4];
@@ -2166,7 +2194,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
         }
         }
         wave_sync_lds();
-        MARK("fwd_stage1");
+        MARKR("fwd_stage1", 5);
         // ---- step 3: coef = (tmp * C^T + rb) >> b ; RDOQ ; tokens ; dequantise                 (:515, :540-614, :1172-1268)
         {
             int acc[4][4];
@@ -2179,9 +2207,9 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 for (int r4 = 0; r4 < 4; r4++) for (int cc = 0; cc < 4; cc++) acc[r4][cc] = rb;
                 mac_YM32<N>(acc, tt, C, by * 4, bx * 4, sw);
                 }
-                MARK("fwd_stage2");
+                MARKR("fwd_stage2", 6);
                 any = rdoq_group<s>(acc, Q);
-                MARK("rdoq");
+                MARKR("rdoq", 7);
             }
             Lv16 L; u32 nzm = 0, mcode = 0;
             if (P.tok) { if (live && any) nzm = scan_levels(L, acc, st, N >= 16, &mcode); else for (int n = 0; n < 16; n++) L.v[n] = 0; }
@@ -2206,7 +2234,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 }
                 u16 *base = P.tok + (size_t)c * TOK_CAP + tokn0;
                 const int cbf_ctx = CX_CBF_LUMA + (P.shape == 0 ? 1 : 0);
-                MARK("scan_dequant_cfg");
+                MARKR("scan_dequant_cfg", 8);
                 const long long ptk0 = prof_now();
                 // greater-1 context set carry (:1218-1221): needs only the levels, not the tokens
                 const int big = (talk && nzm != 0) ? group_big(mcode) : 0;
@@ -2227,7 +2255,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                     if (seg == 0) { to_put(o, 0, TK(cbf_ctx, 0)); cg = 1; }
                     else { TgB B; const int ra = tokg_a_fast<s>(row, 0, L, nzm, mcode, cfg, B); cg = tokg_end<true, true>(o, tokg_b<true, true, 15, 0>(o, ra & 0xFFFF, L, B), B); }
                 }
-                MARK("group_tokens");
+                MARKR("group_tokens", 9);
                 prof_add(PF_T_SETUP, ptk0);
                 const long long ptk1 = prof_now();
                 const int fits = wave_ballot(cg > ROWCAP) == 0;
@@ -2261,7 +2289,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
                         WO.tokn[c] = tokn0 + total; WO.tnz[c] = (u8)(seg != 0);
                     }
                 }
-                MARK("tokens_to_stream");
+                MARKR("tokens_to_stream", 10);
                 prof_add(PF_T_HDR, ptk2);
                 wave_sync_lds();                                            // rows are done with before res is written again
             }
@@ -2278,7 +2306,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
-        MARK("dequant_store");
+        MARKR("dequant_store", 11);
         if constexpr (MX) {
             // ---- steps 4-5 on the matrix cores: itmp = clip16((deq^T C + 64) >> 7) as [y][v], rec = clip16((itmp C + 2048) >> 12) as [y][x = i]
             const int nlive = imin(G, ncand - c0);
@@ -2299,7 +2327,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             mx_mm<LG>(acc, ih, ccol, nlive);
             for (int r4 = 0; r4 < 16; r4++) acc[r4] = (int)(((u32)acc[r4] << 8) + (u32)(2048 + cs128));
             mx_mm<LG>(acc, il, ccol, nlive);
-            MARK("mx_inverse");
+            MARKR("mx_inverse", 12);
             int part = 0;
             for (int d = 0; d < 4; d++) {
                 const int sc_ = (LG == 5) ? 0 : d, cm = c0 + sc_;
@@ -2336,7 +2364,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             }
         }
         wave_sync_lds();
-        MARK("inv_stage1");
+        MARKR("inv_stage1", 13);
         // ---- step 5: rec = clip8(clip16((itmp * C + 2048) >> 12) + pred) ; SSE                (:515 inverse, :146,:165)
         if (live) {
             int acc[4][4];
@@ -2362,7 +2390,7 @@ HD void p1_run_t(int wave, const P1Args &P) {
             if (P.only_mode < 0) lds_add(&WO.sse[c], part);
         }
         }
-        MARK("inv_stage2_recon_sse");
+        MARKR("inv_stage2_recon_sse", 14);
         wave_sync_lds();
       }
     }
@@ -2490,6 +2518,7 @@ HD void stream_seg_t(Arith &a, u8 *cx, LeadSink &sink, int &qn, const u16 *p, in
     prof_add(PF_X2, tx2);
     NOUNROLL
     for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {           // wave-uniform: one 16-byte block of tokens per lane per round
+        MARKB("p2");
         const u16 *pn = p + 8 * imin((k0 >> 3) + 1, last_blk);
 #ifdef IMCVT_HOSTEMU
         const U4 nxt = g_ld128(pn);
@@ -2501,7 +2530,7 @@ HD void stream_seg_t(Arith &a, u8 *cx, LeadSink &sink, int &qn, const u16 *p, in
         if (k0 < n) {                                       // lanes without a stream (or past its end) sit out: their cx / ring rows belong to lane 0
             const long long tp0 = prof_now();
             lsink_sync(sink, qn);                           // full 16-byte runs of leads leave the ring
-            MARK("p2_ring_sync");
+            MARKQ("p2_ring_sync", 72);
             prof_add(PF_T_NDRAIN, tp0);
             const long long tp1 = prof_now();
             if constexpr (RES) {
@@ -2515,7 +2544,7 @@ HD void stream_seg_t(Arith &a, u8 *cx, LeadSink &sink, int &qn, const u16 *p, in
             for (int j = 0; j < 8; j++)                     // no VMEM instruction in here; the stream's last block is padded with idle tokens
                 code_token_q(a, cx, sink.ring, qn, tok_of(cur, j));
             }
-            MARK("p2_eight_tokens");
+            MARKQ("p2_eight_tokens", 73);
             prof_add(PF_T_NTOK, tp1); prof_cnt(PF_BORDER, 1);
         }
 #ifdef IMCVT_HOSTEMU

@@ -486,11 +486,12 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         int x[4][4];
         int any = 0;
         long long t4 = prof_now();
+        MARKB("a4");
         if (live) any = pu_stage1(W, P, c, x);
         wave_sync_lds();
         if (l == 0) { lds_st_i32((i32 *)&U.pu_seq, (i32)seq); lds_st_i32(&q.go, lds_ld_i32(&q.go) + 1); }      // levels published (waves 7 and 6 start), queue counters zeroed
         tl_mark(16 + k);                                 // 16 .. 19: PU k's levels published
-        MARK("a4_stage1");
+        MARKQ("a4_stage1", 74);
         prof_add(PF_T_HDR, t4); t4 = prof_now();        // (IMCVT_PROF builds: t_hdr = predict + DST + RDOQ, passA = first part of the tokens, passB = range half over it, passC = waiting for the remaining-level rows, n_cg = range half over them)
         const int st = scan_type_of(4, live ? c : 0);
         Lv16 L; u32 nzm = 0, mcode = 0;
@@ -513,7 +514,7 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
         wave_sync_lds();
         if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));                     // the counts are in place: the byte half may start
         tl_mark(24 + k);                                 // 24 .. 27: first part of PU k's tokens made
-        MARK("a4_partA");
+        MARKQ("a4_partA", 75);
         prof_add(PF_T_GEN, t4); t4 = prof_now();
         int range = 510, blk = 0;
         stream_seg_R_lds(range, q, l, blk, row + 8, na);
@@ -1962,6 +1963,11 @@ HD void kernel_main(const KArgs &A, int block) {
         const unsigned long long now = wall_clock64();                  // 100 MHz: when the first and the last workgroup of the launch started
         atomicMin((unsigned long long *)(A.counter + 4), now); atomicMax((unsigned long long *)(A.counter + 6), now);
     }
+#ifdef IMCVT_REGCNT
+    if (threadIdx.x < REG_N) SM.regcnt[threadIdx.x] = 0;
+    __syncthreads();
+    struct LeaveR { unsigned long long *prof; __device__ ~LeaveR() { __syncthreads(); if (prof && threadIdx.x < REG_N) atomicAdd(prof + 3 * NWAVES * PF_N + threadIdx.x, (unsigned long long)SM.regcnt[threadIdx.x]); } } leave_r_{ A.prof };
+#endif
     struct Leave { int *c; unsigned long long *dbg; int blk; __device__ ~Leave() { if (threadIdx.x == 0) { atomicAdd(c + 2, -1);
         if (dbg) { dbg[4 * blk] = HB_GAP; dbg[4 * blk + 1] = HB_WHEN; dbg[4 * blk + 2] = (unsigned long long)hw_cu_key() | (unsigned long long)(F.mail ? 1 : 0) << 32; dbg[4 * blk + 3] = wall_clock64(); } } } } leave_{ A.counter, A.fclk ? A.fclk + 4 * A.njobs : nullptr, block };
 #ifdef IMCVT_HB

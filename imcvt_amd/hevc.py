@@ -355,10 +355,16 @@ class DeviceEncoder:
     def debug_prof(self, reset=True):
         """Per-wave cycle totals by phase (only non-zero for -DIMCVT_PROF builds): rows = 3 waves of the main role (or of
         frame-per-workgroup launches), then 3 waves of each helper role."""
-        buf = (C.c_ulonglong * 256)()
-        n = _check(self.lib.imcvt_hevc_debug_prof(self.ctx, buf, 256, int(reset)), "imcvt_hevc_debug_prof")
+        buf = (C.c_ulonglong * 512)()
+        n = _check(self.lib.imcvt_hevc_debug_prof(self.ctx, buf, 512, int(reset)), "imcvt_hevc_debug_prof")
         k = len(self.PROF_CATS)
-        return [[int(buf[w * k + i]) for i in range(k)] for w in range(n // k)]
+        self._regions = [int(buf[9 * k + i]) for i in range(max(0, min(n, 512) - 9 * k))]      # (-DIMCVT_REGCNT builds: executions of the marked regions, tools/valu_dyn_mix.py)
+        return [[int(buf[w * k + i]) for i in range(k)] for w in range(min(n // k, 9))]
+
+    def debug_regions(self, reset=True):
+        """Region execution counters of a -DIMCVT_REGCNT build (hevc_core.h RCNT), summed over the launches since the last reset."""
+        self.debug_prof(reset)
+        return self._regions
 
     def last_kernel_ms(self) -> float:
         ms = float(self.lib.imcvt_hevc_last_kernel_ms(self.ctx))
