@@ -179,12 +179,14 @@ def main():
 
     gathered = None
     kernel_ms = []
+    launch_diag = []                                   # (workgroups resident at once, microseconds between the first and the last workgroup's start) per timed launch
 
     def step(timed):
         nonlocal gathered
         enc.encode(batch)
         if timed:
             kernel_ms.append(enc.last_kernel_ms())      # HIP events on the launch stream (synchronises it)
+            launch_diag.append((enc.last_resident(), enc.last_start_spread_us()))
         if use_dist:                                    # the exchange step: encoded streams to rank 0 over RCCL
             lens = batch["lens"].cpu().tolist()
             gathered = shard.gather_streams(shard.pack_streams(batch["outs"], lens), lens, dev)
@@ -284,7 +286,8 @@ def main():
                        "step_to_step": "all frames digest-equal between the last warm-up step and the last timed step" if first is not None else "not checked (no warm-up)",
                        "encoder": imcvt_amd.load_library().imcvt_hevc_version().decode()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 8),
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "hevc_encode_frames", "kernel_ms": round(k_avg * 1e3, 2), "algorithmic_bytes": algo_bytes},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "hevc_encode_frames", "kernel_ms": round(k_avg * 1e3, 2), "algorithmic_bytes": algo_bytes,
+                         "kernel_ms_per_step": [round(v, 1) for v in kernel_ms], "resident_and_start_spread_us_per_step": launch_diag},
             "compute_view": {"transform_GMAC_per_launch": round(macs / 1e9, 1), "achieved_TMAC_s": round(macs / k_avg / 1e12, 4),
                              "note": "path is integer-ALU / serial-CABAC bound, not HBM bound (SURVEY F6, DESIGN.md §5)"},
         }
@@ -297,8 +300,16 @@ def main():
             # that makes up >= 0.4 % of the kernel's VALU instructions; adds / logic / right shifts 2.26 cycles, selects / compares / left shifts / bit-field /
             # 3-operand / multiplies 4.1 - 4.4): the peak the issue fraction is taken against
             mp = os.path.join(ROOT, "profiles", "valu_mix.json")
+            dp = os.path.join(ROOT, "profiles", "valu_dyn_mix.json")          # round 6: the DYNAMIC opcode mix (tools/valu_dyn_mix.py: region execution counters x static histograms)
             peak, peak_src = nominal, "nominal 2 cycles per wave64 VALU instruction (no measured mix in profiles/valu_mix.json)"
-            if os.path.exists(mp):
+            if os.path.exists(dp) and os.path.exists(mp):
+                dv = json.load(open(dp))
+                peak = 256 * 4 * dv["clock_ghz"] * 1e9 / dv["mix_weighted_cycles_simd"]
+                peak_src = (f"dynamic: {dv['mix_weighted_cycles_simd']} cycles per wave64 VALU instruction on the kernel's DYNAMIC opcode mix — static opcode histograms of the marked regions x their "
+                            f"executions per CTU from a region-counter build at this launch shape ({round(100 * dv['share_in_marked_regions'], 1)} % of the measured VALU instructions lie in marked regions, "
+                            f"{round(100 * dv['share_covered_by_opcode_table'], 1)} % of the dynamic instructions are opcodes with a measured cost), profiles/valu_dyn_mix.json (tools/valu_dyn_mix.py); "
+                            f"per-opcode costs from profiles/valu_mix.json (four wavefronts per SIMD on all 256 compute units); the static mix of round 5 gave {dv['static_mix_weighted_cycles_simd']}")
+            elif os.path.exists(mp):
                 mv = json.load(open(mp))
                 peak = 256 * 4 * mv["clock_ghz"] * 1e9 / mv["mix_weighted_cycles_simd"]
                 peak_src = (f"measured: {mv['mix_weighted_cycles_simd']} cycles per wave64 VALU instruction on the kernel's static opcode mix ({round(100 * mv['share_covered'], 1)} % of its VALU "

@@ -489,6 +489,20 @@ static Shm *g_shm_host;
 __shared__ Shm g_shm;
 #define SM g_shm
 #endif
+// some lane of the wave (in host emulation: this lane) needs the rare path
+#ifdef IMCVT_HOSTEMU
+#define WAVE_ANY(c) (c)
+#else
+#define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#endif
+// region counters of -DIMCVT_REGCNT builds (the marked regions: MARKR / MARKQ below)
+#if defined(IMCVT_REGCNT) && !defined(IMCVT_HOSTEMU)
+#define RCNT(id) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&SM.regcnt[id], 1); } while (0)
+#define RCNT_ANY(id) do { const int me_ = (int)(threadIdx.x & 63u); if (__builtin_amdgcn_readfirstlane(me_) == me_) atomicAdd(&SM.regcnt[id], 1); } while (0)      // inside lane-divergent code: one count per wave execution
+#else
+#define RCNT(id) do {} while (0)
+#define RCNT_ANY(id) do {} while (0)
+#endif
 #define WM(w) (*(WaveMem *)wave_mem_ptr(w))
 // The pipe wave's slice (a WaveMem cut off after the trial coders' extent) is dynamic LDS: only 256-thread launches pay for it.
 #define PIPE_UNION_BYTES 5120
@@ -705,8 +719,27 @@ HD void lsink_flush8(LeadSink &s, int valid) {           // the ring is only 4-b
     const u32a *r = (const u32a *)(s.ring + (s.fl & (LRING - 1)));
     U4 b; b.x = r[0]; b.y = r[1]; b.z = r[2]; b.w = r[3];
     g_st128(s.gbuf + 2 * s.fl, b); s.fl += 8;
+    RCNT_ANY(76);                                         // (region-counter builds: wave executions of a flush)
     // the eight low bytes as two dwords, the eight carry bits as two more; then one 8-bit mask per predicate (bit j: lead j)
-    const u32 L0 = lperm(b.y, b.x, 0x06040200u), L1 = lperm(b.w, b.z, 0x06040200u), H0 = lperm(b.y, b.x, 0x07050301u), H1 = lperm(b.w, b.z, 0x07050301u);
+    const u32 L0 = lperm(b.y, b.x, 0x06040200u), L1 = lperm(b.w, b.z, 0x06040200u);
+#ifndef LSINK_NO_QUIET
+    // Round 6: the quiet flush.  The pattern below needs a lead that may come out ZERO — low byte 0x00 (as LEAD_O_MASK sees it), or 0xFF with a carry into it —
+    // among these eight, the two before them, or a zero byte already emitted (D).  Without any of those Z is empty, nothing hits, and what the next flush
+    // inherits is the carry bits of leads 6 and 7 alone.  A lead's low byte is 0x00 or 0xFF with probability 1 / 128: 94 % of the flushes are quiet, and a
+    // flush is a wave execution for the one or two lanes whose ring has filled — ~120 vector instructions became ~35 (the guard was a sixth of the
+    // kernel's vector instructions at the bench shape, profiles/r06e_valu_dyn_mix.log: p2_ring_sync).
+    {
+        const u32 nz = bytes_nz(L0 & LEAD_O_MASK) & bytes_nz(L1 & LEAD_O_MASK) & bytes_nz(~L0) & bytes_nz(~L1);
+        const int loud = !(valid >= 8 && nz == 0x01010101u && (s.hist & 0xCFu) == 0u);
+        if (!WAVE_ANY(loud)) {                            // every lane of this wave execution is quiet (a loud one takes the quiet ones along: same result)
+            RCNT_ANY(77);                                 // (region-counter builds: ... of which quiet)
+            DBGCNT(0, 8);
+            s.hist = ((b.w >> 8 & 1u) | (b.w >> 23 & 2u)) << 4;
+            return;
+        }
+    }
+#endif
+    const u32 H0 = lperm(b.y, b.x, 0x07050301u), H1 = lperm(b.w, b.z, 0x07050301u);
     const int top = (valid >= 8 ? 8 : valid) + 1;         // bit of the last real lead once the two leads before the eight sit in bits 1, 0
     const u32 keep = (2u << top) - 1u, live8 = keep >> 2;
     const u32 O8 = ~bytes_mask8(bytes_nz(L0 & LEAD_O_MASK), bytes_nz(L1 & LEAD_O_MASK)) & live8, F8 = ~bytes_mask8(bytes_nz(~L0), bytes_nz(~L1)) & live8;
@@ -1451,12 +1484,6 @@ HDN EscRet tok_escape(TokOut o, int k0, int wr, int v, int k, u32 acc, int nb) {
     EscRet e; e.ntok = w.n - k0; e.acc = acc; e.nb = nb;
     return e;
 }
-// some lane of the wave (in host emulation: this lane) needs the rare path
-#ifdef IMCVT_HOSTEMU
-#define WAVE_ANY(c) (c)
-#else
-#define WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
-#endif
 struct TgB { int esc, base2, rice, j; BitRun run; };       // state handed from part A to part B
 #define TK_EMIT(pred, tok) do { const int p_ = (pred); if (WR) { if (PRIV) to_put(o, cnt, (tok)); else to_put_if(o, cnt, (tok), p_); } cnt += p_; } while (0)
 // returns the token count so far | (this group ends with c1 == 0) << 16
@@ -1747,11 +1774,6 @@ HD u32 scan_levels(Lv16 &L, const int x[4][4], int st, int fixed_diag, u32 *mc) 
 // Region counters (-DIMCVT_REGCNT builds, tools/valu_dyn_mix.py): how often each marked region of the pipeline, the token generators and the stream coders is
 // executed — wave executions, counted by lane 0 at the region's END marker.  With the static opcode histogram of the region (a -DIMCVT_MARK compile) this gives the
 // DYNAMIC opcode mix of the kernel.  MARKR(name, r): region r of p1_run_t<LG> (one counter per transform size s = LG - 2); MARKQ(name, id): a region with one counter.
-#if defined(IMCVT_REGCNT) && !defined(IMCVT_HOSTEMU)
-#define RCNT(id) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&SM.regcnt[id], 1); } while (0)
-#else
-#define RCNT(id) do {} while (0)
-#endif
 #if defined(IMCVT_MARK) && !defined(IMCVT_HOSTEMU)
 #define MARKB(x) asm volatile("; MARK " x " begin" ::: "memory")      // where a run of regions begins: what lies before it in the text is not theirs
 #define MARKR(x, r) asm volatile("; MARK " x " s%c0" : : "n"(s) : "memory")

@@ -71,7 +71,6 @@ struct imcvt_hevc_ctx {
     int split = -1, split_hpc = 0, last_split = 0;      // a pool spread over two cooperating launches (launch_split): < 0 where planned, 0 never, 1 as < 0; helper workgroups per compute unit of the helpers' set (0: default)
     hipStream_t st_split[2] = { nullptr, nullptr }; int split_cus[2] = { 0, 0 };      // streams bound to two disjoint sets of compute units, and how many each holds
     hipEvent_t ev_split[3] = { nullptr, nullptr, nullptr };
-    hipStream_t warmed[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; int nwarmed = 0;      // streams (other than the null stream) whose queue has seen this kernel's full grids (encode_device)
     u32 *prog = nullptr;                    // progress records of the next launches' frames, two words each (imcvt_hevc_set_progress), or null
 };
 
@@ -334,14 +333,6 @@ static int split_streams(imcvt_hevc_ctx *c) {
     HIPCHK(hipExtStreamCreateWithCUMask(&c->st_split[1], (uint32_t)words, mb.data()));
     for (int i = 0; i < 3; i++) if (!c->ev_split[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_split[i], hipEventDisableTiming));
     c->split_cus[0] = cus_a; c->split_cus[1] = c->cus - cus_a;
-    if (!getenv("IMCVT_HEVC_NO_PREWARM")) {       // the two queues see the grids they will run before real work arrives (the private-segment ring belongs to the queue)
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), c->st_split[0])); launch(c, cus_a, c->st_split[0], 0, 1, 0, 0, 2);
-            HIPCHK(hipStreamSynchronize(c->st_split[0]));
-            HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), c->st_split[1])); launch(c, (c->cus - cus_a) * c->occ_wg, c->st_split[1], 0, 1, 0, 0);
-            HIPCHK(hipStreamSynchronize(c->st_split[1]));
-        }
-    }
     return 0;
 }
 // Partner workgroups (round 6): in a wide pool every main workgroup gets a second compute unit for the two 2Nx2N candidate sets of its 8x8 CUs (hevc_frame.h
@@ -458,19 +449,6 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
                 c->pending_err = IMCVT_ERR_WATCHDOG;
                 fprintf(stderr, "imcvt_hevc: the previous launch of this context (%d + %d workgroups) was abandoned by the device watchdog - its results are invalid\n", c->last_mains, c->last_help);
             }
-        }
-    }
-    // The private-segment ring belongs to the QUEUE a dispatch goes through, and the pre-warm launches of imcvt_hevc_create went through the null stream's: a
-    // stream of the caller's own met its first full grids cold — the host-pointer path's launches (their own stream) ran 5.03 s where the same batch on the null
-    // stream ran 4.85 s, whatever the memory layout (profiles/r06c_ab.log, r06d_ab.log).  The first launch on a stream is preceded by the same empty full grids.
-    if (stream != nullptr && !getenv("IMCVT_HEVC_NO_PREWARM")) {
-        bool seen = false;
-        for (int i = 0; i < c->nwarmed; i++) seen = seen || c->warmed[i] == stream;
-        if (!seen) {
-            if (c->wide_kernel && c->wide_wg > 0) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->wide_wg, stream, 0, 1, 0, 0, 2); }
-            for (int i = 0; i < 3; i++) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->max_wg, stream, 0, 1, 0, 0); }
-            HIPCHK(hipStreamSynchronize(stream));
-            c->warmed[c->nwarmed % 8] = stream; if (c->nwarmed < 8) c->nwarmed++;
         }
     }
     int nmains = 0, nhelp = 0, forced = 0;

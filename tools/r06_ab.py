@@ -95,6 +95,25 @@ if "follow" in what:
     print(json.dumps({"probe": "host_follow", "resident_kernel_ms_same_process": ks}), flush=True)
     enc.close(); del b
 
+if "streams" in what:
+    # the same 512 frames: resident on the null stream, resident on a stream of the caller's, and through the host-pointer path (its own stream), interleaved
+    from imcvt_amd import hevc
+    n = 512
+    host_imgs = [synth.syn(1920, 1080, s) for s in range(n)]
+    hevc.HEVCImageEncoderBatch(host_imgs[:32], 0)
+    enc = imcvt_amd.DeviceEncoder()
+    b = enc.make_batch([torch.from_numpy(a).to(dev) for a in host_imgs], 0)
+    st = torch.cuda.Stream()
+    res = {"resident_null_stream": [], "resident_user_stream": [], "host_path_kernel": [], "host_path_wall": []}
+    for r in range(reps):
+        enc.encode(b); torch.cuda.synchronize(); res["resident_null_stream"].append(round(enc.last_kernel_ms(), 1))
+        enc.encode(b, stream=st); torch.cuda.synchronize(); res["resident_user_stream"].append(round(enc.last_kernel_ms(), 1))
+        t0 = time.perf_counter(); out = hevc.HEVCImageEncoderBatch(host_imgs, 0, copy=False); dt = time.perf_counter() - t0
+        res["host_path_kernel"].append(round(hevc.transfer_stats()["kernel_ms"], 1)); res["host_path_wall"].append(round(dt * 1e3, 1))
+        del out
+    print(json.dumps({"probe": "streams", "frames": n, **res}), flush=True)
+    enc.close(); imcvt_amd.load_library().imcvt_hevc_shutdown(); del b, host_imgs
+
 if "layout" in what:
     # does the device-side layout of a batch matter?  the same 512 frames resident as (a) separate torch tensors (what bench.py times), (b) ONE slab, frame by frame
     # [img | out | rcon] (what the host-pointer path builds), (c) one slab, grouped [all imgs | all outs | all rcons]; interleaved launches

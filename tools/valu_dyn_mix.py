@@ -131,5 +131,7 @@ out = {"what": "dynamic VALU opcode mix of hevc_encode_frames at the bench's lau
        "regions": rows}
 json.dump(out, open(a.out, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("regions", "top_opcodes")}, indent=1))
+if len(cnt) > 76 and cnt[76]:
+    print(f"lead-sink flushes (wave executions of lsink_flush8): {cnt[76] / ctus:.1f} per CTU against {cnt[72] / ctus:.1f} token blocks of the stream coders")
 for r in sorted(rows, key=lambda r: -r["valu_per_ctu"])[:40]:
     print("%-22s s%d  copies %d  static %7.1f  x %9.2f per CTU = %9d" % (r["region"], r["s"], r["copies"], r["static_valu"], r["executions_per_ctu"], r["valu_per_ctu"]))
