@@ -43,6 +43,12 @@ HD void hb_set(unsigned long long) {}
 #ifndef NXN_PRIO_SOLO
 #define NXN_PRIO_SOLO 1
 #endif
+#ifndef ROLE8_PERM
+// nibble w_: the role physical wavefront w_ runs in the 8x8 CUs of a wide workgroup (decide_cu).  Roles 5 (a pass + byte half of the one-TU set) and 6 (byte half of the
+// pipe wave's streams) swapped against round 5: the PU chain's SIMD-mate is the one-TU set's light partner, the four-TU passes share theirs with the wavefront that idles
+// until PU 2 is decided — 64 frames 2.30 -> 2.27 s, one frame unchanged; the other placements tried were 2 - 5 % slower (profiles/r06i_role_perm_ab.log)
+#define ROLE8_PERM 0x75643210u
+#endif
 #define HDR_MAX 96       // bytes reserved per frame for the stream headers the host prepares (:664-690)
 
 HD u16 *wave_tok(const Scratch &sc, int wave) { return sc.tok + (size_t)wave * TOK_SLOTS * TOK_CAP; }
@@ -898,7 +904,10 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
     u8 *live_sink = F.job.out + F.out_pos;
     const int tl = N == 8 && F.wide;                     // (-DIMCVT_PROF_TL builds: timeline of a wide workgroup's 8x8 CUs)
     if (tl) tl_start();
-    WAVES_ALL(w) {
+    WAVES_ALL(w_) {
+        // 8x8 CU of a wide workgroup: physical wavefront w_ runs ROLE w (roles are named by the wavefront that runs them under the identity: memory, flags and queues go
+        // by role).  Which two roles share a SIMD — wavefronts w and w + 4 do — is the placement; ROLE8_PERM permutes it (A/B builds, profiles/r06i_role_perm_ab.log).
+        const int w = (F.wide && N < 16) ? (int)(((u32)ROLE8_PERM >> (4 * w_)) & 7u) : w_;
         if (w >= NWAVES && N < 16) {
             if (w == PIPE_WAVE) { if (F.wide) partner_pu_early(y0, x0); nxn_pipe(y0, x0); }      // (wide workgroups: until PU 2 is decided the pipe wave has nothing of its own to do — reconstructions and byte half of the pricing of PUs 0..2, on a SIMD the PU wave does not run on)
             else if (!F.wide) { }
@@ -909,7 +918,7 @@ HDN void decide_cu(int depth_, int N_, int y0_, int x0_, int avm_) {
         }
         else if (w != 2 || N >= 16) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else eval_NxN(2, y0, x0, avm);
-        if (tl) tl_mark(1 + w);                          // 1 .. 8: wave w is through with its part of the candidate sets
+        if (tl) tl_mark(1 + w_);                         // 1 .. 8: wave w_ is through with its part of the candidate sets
     }
     wg_sync_p();
     if (tl) WAVES(w) { if (w == 0) tl_mark(9); }         // 9: every wave is
