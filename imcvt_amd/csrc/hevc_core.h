@@ -581,6 +581,8 @@ struct alignas(16) PuX {
 // (tools/valu_rate_probe.hip) — so the two halves of a chain sit on different SIMDs, and the PU chain's SIMD-mates are the wavefronts with the least to do:
 //     SIMD a: wave 0 (one-TU set)   + wave 4 (coders of the four-TU set)            SIMD c: wave 2 (PU chain)  + wave 6 (byte half of the pipe wave: idle until PU 2 is decided)
 //     SIMD b: wave 1 (four-TU set)  + wave 5 (a pass + byte half of the one-TU set) SIMD d: wave 3 (pipe wave; before PU 2 is decided: reconstructions + byte half of the PU pricing) + wave 7 (remaining-level tokens of the PU chain)
+// (The names are ROLES.  Round 6: in the 8x8 CUs roles 5 and 6 run on each other's wavefront — hevc_frame.h ROLE8_PERM — so that the PU chain's SIMD-mate is the one-TU set's
+// light partner and the four-TU passes share theirs with the role that idles until PU 2 is decided: 64 frames 2.30 -> 2.27 s, profiles/r06i_role_perm_ab.log.)
 #define WAVE_B_CODER (PIPE_WAVE + 1)
 #define WAVE_A_PARTNER (PIPE_WAVE + 2)
 #define WAVE_PIPE_PARTNER (PIPE_WAVE + 3)
