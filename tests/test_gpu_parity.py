@@ -669,3 +669,24 @@ def test_partner_workgroups_1080p_digest(amd, seed):
     assert enc.last_wide() and enc.last_partners() == 1
     assert len(s) == e["bytes"] and hashlib.sha256(s).hexdigest() == e["sha256"] and hashlib.sha256(r.tobytes()).hexdigest() == e["rcon_sha256"]
     enc.close()
+
+
+@pytest.mark.slow
+def test_two_launch_pool_full_size_against_reference_digests(amd):
+    """BASELINE configs[3]'s share of one GPU at N = 4 — the first 128 bench frames at full size — as the library runs it by default: two cooperating launches, 128 wide main
+    workgroups on one half of the compute units, 192-thread helpers on the other.  Streams and reconstructions against the digests the REAL reference produced
+    (tests/golden/bench512_kat.json)."""
+    import json
+    import torch
+    from conftest import ROOT
+    from oracle import synth
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "bench512_kat.json")))["frames"]
+    enc = amd.DeviceEncoder()
+    batch = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, s)).cuda() for s in range(128)], 0)
+    enc.encode(batch)
+    assert enc.last_split() and enc.last_wide() and enc.last_shape()[0] == 128
+    for s, (stream, rcon) in enumerate(enc.results(batch)):
+        e = kat[str(s)]
+        assert len(stream) == e["bytes"] and hashlib.sha256(stream).hexdigest() == e["sha256"], s
+        assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], s
+    enc.close()
