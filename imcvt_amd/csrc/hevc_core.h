@@ -548,6 +548,7 @@ struct alignas(16) WideCtl {
     i32 remote8;                                 // the 8x8 CU being walked has its 2Nx2N sets out: the PU chain shares nothing with a four-TU wave here
     i32 ans_seq;                                 // sequence number of the answer wave 0 has staged in LDS (Ans8), or -1: it stopped waiting
     // partner workgroup
+    i32 lv_seq, lv_taken;                        // four-TU set: TUs whose levels wave 1 has published (PuX::lev) / the token wavefront has taken, counted over the workgroup's requests
     i32 solo2n;                                  // this workgroup evaluates 2Nx2N sets of 8x8 CUs with no NxN chain beside them: the four-TU wave makes TU 0 itself, the one-TU set has two lenders
 };
 // A PU step of an 8x8 CU in a wide workgroup (hevc_frame.h pu_step_wide): the PU wave predicts, transforms and quantises the 35 candidates,
@@ -567,7 +568,18 @@ struct alignas(16) PuX {
     u32 pu_seq, b_seq, r_seq;                    // sequence number of the PU whose levels are published / whose rows are complete / whose reconstructions and SSE are in place
     alignas(16) u16 kept[4 * NXN_KEEP_STRIDE];   // the four PU winners' tokens for the pipe wave (round 6: LDS instead of the candidate slot in memory — no store drain on the PU chain, no load latency on its tail): PUs 0 .. 2 back to back, PU 3 from 3 x NXN_KEEP_STRIDE, each run padded to a token block with idle tokens
 };
-#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem) + sizeof(PuX))
+// Third stage of a split trial coder (round 6; the pipe wave's streams of a main workgroup whose 2Nx2N sets are with its partner workgroup — four of its wavefronts are idle):
+// the CONTEXT side of the range half on a wavefront of its own.  The context recurrence (state, bin -> next state, :913-920) involves neither the range nor low, so a
+// wavefront can run ahead with it and leave, per token, the four LPS ranges of the state the bin met and the token itself with an LPS / MPS bit (two dwords); the range
+// wavefront then does the range arithmetic alone (stream_seg_Rq) and the byte wavefront what it always did.  Rings of QDEPTH token blocks per lane, like SplitQ.
+#define CQSTRIDE (QDEPTH * 16 + 4)               // dwords per lane row
+struct alignas(16) CtxQ {
+    u32 rec[NMODE][CQSTRIDE];
+    i32 prod[NMODE], cons[NMODE];
+    i32 go, done;                                // generation started by the range wavefront / finished by the context wavefront
+};
+#define WIDE_LDS_BYTES (PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem) + sizeof(PuX) + sizeof(CtxQ))
+#define CTXQ (*(CtxQ *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem) + sizeof(PuX)))
 #define PUX (*(PuX *)(DYN_LDS + PIPE_LDS_BYTES + XWAVES * sizeof(PartnerMem) + sizeof(WideCtl) + NLEND * sizeof(WaveMem)))
 #ifdef IMCVT_HOSTEMU
 #define DYN_LDS g_pipe_host
@@ -1142,6 +1154,7 @@ struct P1Args {
     int own;             // wave whose candidate set this is (its tokn / tnz / sse arrays and token streams); the executing wave lends lanes and its pass buffer
     int c_lo, c_hi;      // candidates (modes) handled by this call
     int hint;            // 4x4 PU candidates (shape 3): the tokens carry state hints (tokg_a_fast<0, true>) — they are priced by code_token_r
+    u8 *rec8;            // partner workgroups (8x8 CUs, hevc_frame.h): every candidate keeps its reconstruction here, 64 bytes per candidate in raster order (LDS), so that the winner's need not be rebuilt; else null
 };
 
 // sign-extended byte kk of a packed word / i16 halves of a packed word
@@ -1885,6 +1898,7 @@ HD void p1_run_4(int wave, const P1Args &P) {
                     const int d = (int)((ow >> (8 * xi)) & 255) - rc;
                     part += d * d;
                     rw4 |= (u32)rc << (8 * xi);
+                    if (xi == 3 && P.rec8) *(u32a *)(P.rec8 + c * 64 + ((P.k >> 1) * 4 + yi) * 8 + (P.k & 1) * 4) = rw4;
                     if (P.out_kind == OUT_REC4) { if (xi == 3) *(u32a *)&W.u.w2.rec4[c][yi * 4] = rw4; }
                     else if (P.out_kind == OUT_TILE) SM.rec[P.y0 + yi + 1][P.x0 + xi + 1] = (u8)rc;
                     else if (P.out_kind == OUT_T3SIDE) {
@@ -1922,7 +1936,7 @@ HD TgB tokg_b_state(const Lv16 &L, u32 nzm, u32 P) {
     return B;
 }
 // PU wave, first half of the pass: prediction, residual, DST, RDOQ of candidate `c` (= mode); levels (raster) in x, prediction published with them
-HD int pu_stage1(const WaveMem &W, const P1Args &P, int c, int x[4][4]) {
+HD int pu_stage1(const WaveMem &W, const P1Args &P, int c, int x[4][4], int (*pr_out)[4] = nullptr) {
     const Tables &T = SM.T;
     const QConst Q = qconst<0>(P.q);
     BorderRef br; fill_border_ref(br, W, P.per_mode_border, c);
@@ -1961,6 +1975,7 @@ HD int pu_stage1(const WaveMem &W, const P1Args &P, int c, int x[4][4]) {
         pv[2 * r + 1] = any ? ((u32)(x[r][2] & 0xFFFF) | (u32)x[r][3] << 16) : 0u;
         pv[8 + r] = (u32)pr[r][0] | (u32)pr[r][1] << 8 | (u32)pr[r][2] << 16 | (u32)pr[r][3] << 24;
     }
+    if (pr_out) for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) pr_out[r][cc] = pr[r][cc];
     return any;
 }
 HD void pu_levels(int c, int x[4][4], int pr[4][4]) {           // a partner reads what pu_stage1 published
@@ -2399,17 +2414,20 @@ HD void p1_run_t(int wave, const P1Args &P) {
                 const int y = by * 4 + r4;
                 const u32 pw = predw[r4];
                 const u32 ow = *(const u32a *)&SM.org[P.y0 + y][P.x0 + bx * 4];
+                u32 rw4 = 0;
                 for (int cc = 0; cc < 4; cc++) {
                     const int x = bx * 4 + cc;
                     const int rc = clip3(clip16(acc[r4][cc] >> 12) + (int)((pw >> (8 * cc)) & 255), 0, 255);
                     const int d = (int)((ow >> (8 * cc)) & 255) - rc;
                     part += d * d;
+                    rw4 |= (u32)rc << (8 * cc);
                     if (P.out_kind == OUT_TILE) SM.rec[P.y0 + y + 1][P.x0 + x + 1] = (u8)rc;
                     else if (P.out_kind == OUT_T3SIDE) {
                         if (P.k < 3 && y == N - 1) SM.X.t3row[c][P.k][x] = (u8)rc;
                         if (P.k < 3 && x == N - 1) SM.X.t3col[c][P.k][y] = (u8)rc;
                     }
                 }
+                if (N == 8 && P.rec8) *(u32a *)(P.rec8 + c * 64 + y * 8 + bx * 4) = rw4;
             }
             if (P.only_mode < 0) lds_add(&WO.sse[c], part);
         }
@@ -2430,7 +2448,7 @@ HD void p1_run(int wave, const P1Args &P) {
 HDN void p1_run_cold(int wave_, const P1Args P_) {
     P1Args P;
     P.N = uni_i(P_.N); P.y0 = uni_i(P_.y0); P.x0 = uni_i(P_.x0); P.k = uni_i(P_.k); P.per_mode_border = uni_i(P_.per_mode_border); P.out_kind = uni_i(P_.out_kind);
-    P.only_mode = uni_i(P_.only_mode); P.shape = uni_i(P_.shape); P.tok = uni_p(P_.tok); P.q = uni_i(P_.q); P.own = uni_i(P_.own); P.c_lo = uni_i(P_.c_lo); P.c_hi = uni_i(P_.c_hi); P.hint = 0;
+    P.only_mode = uni_i(P_.only_mode); P.shape = uni_i(P_.shape); P.tok = uni_p(P_.tok); P.q = uni_i(P_.q); P.own = uni_i(P_.own); P.c_lo = uni_i(P_.c_lo); P.c_hi = uni_i(P_.c_hi); P.hint = 0; P.rec8 = nullptr;
     p1_run(uni_i(wave_), P);
 }     // the winner's reconstruction: once per CU, kept out of line
 
@@ -2774,6 +2792,106 @@ HD void stream_seg_R_ldsrc(int &range, u8 *cx, SplitQ &q, int lane, int &blk, co
             lds_st_i32(&q.prod[ql], blk);
         }
         cur = nxt;
+    }
+}
+// ---- the range half cut once more: context stage (stream_seg_C) and range stage (stream_seg_Rq), see CtxQ ----
+// context side of a token block, one token ahead like block_R8: out[2 j] = the LPS ranges of the state token j's bin meets, out[2 j + 1] = token | (LPS path) << 16
+HD void block_C8(u8 *cx, const U4 &cur, u32 out[16]) {
+    u32 tok = tok_of(cur, 0);
+    u32 cim = tok >> 8;
+    int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
+    int pz = cx[ci];
+    uint2 e = SM.T.pst[pz];
+    UNROLL_FULL
+    for (int j = 0; j < 8; j++) {
+        const int is_lps = (int)(tok ^ (u32)pz) & 1;
+        const int nx = (int)((is_lps ? e.y : e.y >> 8) & 255u);
+        u32 tokn = 0; int cin = 0, pzn = 0; uint2 en, ef; en.x = en.y = ef.x = ef.y = 0;
+        if (j < 7) {
+            tokn = tok_of(cur, j + 1);
+            const u32 cimn = tokn >> 8;
+            cin = (int)(cimn < (u32)CX_PAD ? cimn : (u32)CX_PAD);
+            pzn = cx[cin];
+            ef = SM.T.pst[nx];
+            en = SM.T.pst[pzn];
+        }
+        cx[ci] = (u8)nx;
+        out[2 * j] = e.x; out[2 * j + 1] = tok | (u32)is_lps << 16;
+        if (j < 7) {
+            const int same = cin == ci;
+            pz = same ? nx : pzn;
+            e.x = same ? ef.x : en.x; e.y = same ? ef.y : en.y;
+            tok = tokn; ci = cin;
+        }
+    }
+}
+// tokens p[0..n) (LDS when lds_src, else global memory) through the context stage; `cblk` counts this lane's blocks of the run
+template <bool LDS_SRC>
+HD void stream_seg_C(u8 *cx, CtxQ &cq, int lane, int &cblk, const u16 *p, int n) {
+    const int last_blk = imax((n - 1) >> 3, 0);
+    const int ql = lane < NMODE ? lane : 0;
+    u32 *const row = cq.rec[ql];
+    U4 cur;
+    if constexpr (LDS_SRC) { const u32a *pw = (const u32a *)p; cur.x = pw[0]; cur.y = pw[1]; cur.z = pw[2]; cur.w = pw[3]; } else cur = g_ld128(p);
+    int cons_seen = lds_ld_i32(&cq.cons[ql]);
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        const u16 *pn = p + 8 * imin((k0 >> 3) + 1, last_blk);
+        U4 nxt;
+        if constexpr (LDS_SRC) { const u32a *pw = (const u32a *)pn; nxt.x = pw[0]; nxt.y = pw[1]; nxt.z = pw[2]; nxt.w = pw[3]; } else nxt = g_ld128(pn);
+        if (k0 < n) {
+            while (WAVE_ANY(cblk - cons_seen >= QDEPTH)) { if (cblk - cons_seen >= QDEPTH) { pipe_pause(); cons_seen = lds_ld_i32(&cq.cons[ql]); } }
+            u32 out[16];
+            block_C8(cx, cur, out);
+            u32 *d = row + (cblk & (QDEPTH - 1)) * 16;
+            UNROLL_FULL
+            for (int j = 0; j < 16; j++) d[j] = out[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            cblk++;
+            lds_st_i32(&cq.prod[ql], cblk);
+        }
+        cur = nxt;
+    }
+}
+// ... and the range stage over its records: the range arithmetic of block_R8 alone; leaves the byte half's records in q as stream_seg_R does
+HD void stream_seg_Rq(int &range, CtxQ &cq, SplitQ &q, int lane, int &cblk, int &blk, int n) {
+    const int ql = lane < NMODE ? lane : 0;
+    const u32 *const crow = cq.rec[ql];
+    u32 *const row = q.rec[ql];
+    int prod_seen = lds_ld_i32(&cq.prod[ql]), cons_seen = lds_ld_i32(&q.cons[ql]);
+    NOUNROLL
+    for (int k0 = 0; WAVE_ANY(k0 < n); k0 += 8) {
+        if (k0 < n) {
+            while (WAVE_ANY(prod_seen <= cblk)) { if (prod_seen <= cblk) { pipe_pause(); prod_seen = lds_ld_i32(&cq.prod[ql]); } }
+            while (WAVE_ANY(blk - cons_seen >= QDEPTH)) { if (blk - cons_seen >= QDEPTH) { pipe_pause(); cons_seen = lds_ld_i32(&q.cons[ql]); } }
+            const u32 *in = crow + (cblk & (QDEPTH - 1)) * 16;
+            u32 rec[8];
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) {
+                const u32 ex = in[2 * j], meta = in[2 * j + 1];
+                const u32 tok = meta & 0xFFFFu;
+                const int is_lps = (int)(meta >> 16) & 1, byp = tok >= 0x8000u;
+                const int lps = (int)((ex >> ((range >> 3) & 24)) & 0xFF);
+                const int rm = range - lps;
+                const int r2 = is_lps ? lps : rm;
+                const int sh = clz_nz((u32)r2) - 23;
+                const int nb_ = byp ? (int)((tok >> 8) & 15u) : sh;
+                const int add = (is_lps & !byp) ? rm : 0;
+                rec[j] = (u32)add | (u32)range << 9 | (u32)nb_ << 18 | (byp ? (tok & 255u) << 22 : 0u);
+                range = byp ? range : (r2 << sh);
+            }
+            u32 *d = row + (blk & (QDEPTH - 1)) * 8;
+            UNROLL_FULL
+            for (int j = 0; j < 8; j++) d[j] = rec[j];
+#ifndef IMCVT_HOSTEMU
+            asm volatile("" ::: "memory");
+#endif
+            blk++; cblk++;
+            lds_st_i32(&q.prod[ql], blk);
+            lds_st_i32(&cq.cons[ql], cblk);
+        }
     }
 }
 // The range half on RESOLVED tokens that lie in LDS (a lane's own row, or its row at a partner: hevc_frame.h pu_step_wide), 16-byte-block

@@ -160,7 +160,7 @@ HD u32 pu_seq_of(int k) { return 4u * (u32)(lds_ld_i32(&WCTL.cu8) - 1) + (u32)k 
 HD void pu_recon_k(int y0, int x0, int k) {
     P1Args P;
     P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = (u16 *)0; P.N = 4; P.y0 = y0 + (k >> 1) * 4; P.x0 = x0 + (k & 1) * 4; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
-    P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
+    P.own = 2; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1; P.rec8 = nullptr;
     const long long tq = prof_now();                    // (IMCVT_PROF builds: the partners' times go to columns wave 2's row leaves empty — p2_32 reconstructions, p2_16 waiting for the first counts, p2_8 byte half over the first part, p2_nxn waiting for rows and final range, p1_16 byte half over the rows, x3 costs; idle: the remaining-level rows)
     pu_recon(2, P, pu_seq_of(k));
     prof_add_row(2, PF_P2_32, tq);
@@ -248,6 +248,131 @@ HDN void coder_range_half(int wave_, int depth_) {
     }
     split_flag(&q.rdone, q);
 }
+HD void seg_close(WaveMem &W, int k);
+// ---- partner workgroups (8x8 CUs' 2Nx2N sets on a second compute unit, see "8x8 CUs with a partner workgroup" below) ---------------------------------------
+// every candidate keeps its reconstruction (64 bytes, raster order): the winner's is answered without running its shape once more.  The store lies in the LDS slice of a
+// lender wavefront the partner workgroup does not use (wave 5's: 2 x 35 x 64 bytes of 8960).
+HD u8 *rec8_of(int shape) { return wave_mem_ptr(WAVE_A_PARTNER) + shape * (NMODE * 64); }
+static_assert(2 * NMODE * 64 <= (int)sizeof(WaveMem), "the candidates' reconstructions fit a lender's slice");
+// The four-TU set of a partner workgroup is its longest chain: four 4x4 passes in a row (TU k + 1 of a mode predicts from TU k's reconstruction of that mode, :1459, :1466),
+// 29 k cycles each with their tokens — which are 55 % of a pass and which nothing on the chain waits for.  So wave 1 runs predict / DST / RDOQ, publishes the levels (PuX::lev,
+// the PU steps' hand-over: a partner workgroup walks no PUs), goes on with the inverse, the reconstruction and the edges the next TU predicts from — and a second wavefront
+// (fourtu_tokens_solo) makes the TU's tokens from the levels, appends them to the candidates' streams and closes the segment for the coder wavefront (partner_fourtu).
+// Same levels, same tokens in the same order, same reconstruction as p1_run_4.
+HDN_EVAL void fourtu_passes_solo(int y0_, int x0_, int avm_) {
+    const int y0 = uni_i(y0_); const int x0 = uni_i(x0_); const int avm = uni_i(avm_);
+    const Avail av = unpack_avail(avm);
+    WaveMem &W = WM(1);
+    WideCtl &C = WCTL;
+    P1Args P;
+    P.q = F.job.q; P.only_mode = -1; P.hint = 0; P.own = 1; P.c_lo = 0; P.c_hi = NMODE; P.shape = 1; P.tok = wave_tok(F.sc, 1); P.rec8 = rec8_of(1);
+    const QConst Q = qconst<0>(P.q);
+    for (int k = 0; k < 4; k++) {
+        const Avail ca = child_avail(av, k);
+        const int yk = y0 + (k >> 1) * 4, xk = x0 + (k & 1) * 4;
+        if (k == 0) border_from_tile(1, 4, yk, xk, ca.l, ca.bl, ca.a, ca.ar);
+        else border_tu_split(8, y0, x0, k, av.l, av.bl, av.a, av.ar, 0, NMODE);
+        P.N = 4; P.y0 = yk; P.x0 = xk; P.k = k; P.per_mode_border = (k != 0); P.out_kind = OUT_T3SIDE;
+        while (lds_ld_i32(&C.lv_taken) != lds_ld_i32(&C.lv_seq)) pipe_pause();      // the token wavefront has taken the TU before
+        if (k == 0) wave_sync(); else wave_sync_lds();                              // (TU 0: the candidates' headers are in memory before anybody is told to go on from them)
+        LANES(l) {
+            const int c = l, live = c < NMODE;
+            int x[4][4], pr[4][4], t[4][4];
+            int any = 0;
+            if (live) any = pu_stage1(W, P, c, x, pr);
+            wave_sync_lds();
+            if (l == 0) lds_st_i32(&C.lv_seq, lds_ld_i32(&C.lv_seq) + 1);          // levels published
+            if (live) {
+                int part = 0;
+                if (any) {
+                    for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) x[r][cc] = clip16(x[r][cc] * (1 << Q.dqs));
+                    for (int j = 0; j < 4; j++) {
+                        const int a = x[0][j], b = x[1][j], cc_ = x[2][j], d = x[3][j];
+                        t[0][j] = clip16((29 * a + 74 * b + 84 * cc_ + 55 * d + 64) >> 7);
+                        t[1][j] = clip16((55 * a + 74 * b - 29 * cc_ - 84 * d + 64) >> 7);
+                        t[2][j] = clip16((74 * (a - cc_ + d) + 64) >> 7);
+                        t[3][j] = clip16((84 * a - 74 * b + 55 * cc_ - 29 * d + 64) >> 7);
+                    }
+                    for (int i = 0; i < 4; i++) {
+                        const int a = t[i][0], b = t[i][1], cc_ = t[i][2], d = t[i][3];
+                        x[i][0] = clip16((29 * a + 74 * b + 84 * cc_ + 55 * d + 2048) >> 12);
+                        x[i][1] = clip16((55 * a + 74 * b - 29 * cc_ - 84 * d + 2048) >> 12);
+                        x[i][2] = clip16((74 * (a - cc_ + d) + 2048) >> 12);
+                        x[i][3] = clip16((84 * a - 74 * b + 55 * cc_ - 29 * d + 2048) >> 12);
+                    }
+                } else {
+                    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) x[i][j] = 0;
+                }
+                u32 oww[4];
+                for (int yi = 0; yi < 4; yi++) oww[yi] = *(const u32a *)&SM.org[yk + yi][xk];
+                for (int yi = 0; yi < 4; yi++) {
+                    const u32 ow = oww[yi];
+                    u32 rw4 = 0;
+                    for (int xi = 0; xi < 4; xi++) {
+                        const int rc = clip3(x[yi][xi] + pr[yi][xi], 0, 255);
+                        const int d = (int)((ow >> (8 * xi)) & 255) - rc;
+                        part += d * d;
+                        rw4 |= (u32)rc << (8 * xi);
+                        if (k < 3 && yi == 3) SM.X.t3row[c][k][xi] = (u8)rc;
+                        if (k < 3 && xi == 3) SM.X.t3col[c][k][yi] = (u8)rc;
+                    }
+                    *(u32a *)(P.rec8 + c * 64 + ((k >> 1) * 4 + yi) * 8 + (k & 1) * 4) = rw4;
+                }
+                W.sse[c] += part;
+            }
+        }
+        wave_sync_lds();
+        tl_mark(36 + k);                                 // 36 .. 39: the four-TU set's TU k passed (without its tokens)
+    }
+}
+// ... and the wavefront that makes those tokens (wave 6 of a partner workgroup): TU by TU behind wave 1, into the candidates' streams (wave 1's rows, counts and streams:
+// wave 1 does not touch them after the headers), a segment closed per TU.  The token part of p1_run_4 for shape 1, no hints.
+HDN void fourtu_tokens_solo() {
+    WaveMem &W = WM(1);
+    WideCtl &C = WCTL;
+    const Tables &T = SM.T;
+    u16 *const tok = wave_tok(F.sc, 1);
+    for (int k = 0; k < 4; k++) {
+        while (lds_ld_i32(&C.lv_seq) == lds_ld_i32(&C.lv_taken)) pipe_pause();      // the next TU's levels are published
+        wave_sync_lds();
+        LANES(l) {
+            const int c = l, live = c < NMODE;
+            int x[4][4], pr[4][4];
+            if (live) pu_levels(c, x, pr);
+            wave_sync_lds();
+            if (l == 0) lds_st_i32(&C.lv_taken, lds_ld_i32(&C.lv_taken) + 1);      // taken: wave 1 may publish the TU after
+            if (live) {
+                int any = 0;
+                for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) any |= x[r][cc];
+                const int st = scan_type_of(4, c);
+                Lv16 L; u32 nzm = 0, mcode = 0;
+                if (any) nzm = scan_levels(L, x, st, 0, &mcode);
+                LaneStream ls;
+                TokW w = ls_begin(ls, W, c, lane_row(W, l), tok + (size_t)c * TOK_CAP);
+                tk_bin(w, CX_CBF_LUMA, nzm != 0);
+                if (nzm != 0) {
+                    const int in = T.incg[st][hibit(nzm)];
+                    const LastPos lp = last_pos_prep(0, st, in >> 2, in & 3);
+                    w.n = last_pos_emit<0, true>(w.o, w.n, lp);
+                    TgB B;
+                    const int cfg4 = TG_DC | TG_LAST | st << TG_ST;
+                    w.n = tokg_a_fast<0>(w.o.tb, w.n, L, nzm, mcode, cfg4, B) & 0xFFFF;
+                    if (B.esc) {
+                        ls_flush(ls, w);
+                        w.n = tokg_b<true, true, 15, 8>(w.o, w.n, L, B);
+                        if (w.n > 14) ls_flush(ls, w);
+                        w.n = tokg_b<true, true, 7, 0>(w.o, w.n, L, B);
+                    }
+                    w.n = tokg_end<true, true>(w.o, w.n, B);
+                }
+                ls_end(ls, w, W, c);
+                W.tnz[c] = (u8)(nzm != 0);
+            }
+        }
+        wave_sync_lds();
+        seg_close(W, k);
+    }
+}
 // A lender wavefront (wide workgroups): candidates lo .. hi-1 of the one-TU set of the 8x8 CU at (y0, x0), exactly as wave 0 runs its own
 // (eval_2Nx2N: same border, same pass, tokens / counts / SSE into wave 0's arrays and streams) on this wavefront's own slice.
 HDN void lend_passes(int wave_, int li_, int lo_, int hi_, int y0_, int x0_, int avm_) {
@@ -260,6 +385,7 @@ HDN void lend_passes(int wave_, int li_, int lo_, int hi_, int y0_, int x0_, int
     P1Args P;
     P.q = F.job.q; P.only_mode = -1; P.hint = 0; P.own = 0; P.c_lo = lo; P.c_hi = hi; P.shape = 0; P.tok = wave_tok(F.sc, 0);
     P.N = 8; P.y0 = y0; P.x0 = x0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_NONE;
+    P.rec8 = lds_ld_i32(&C.solo2n) != 0 ? rec8_of(0) : nullptr;      // (partner workgroup: every candidate keeps its reconstruction)
     p1_run_t<3>(wave, P);
     wave_sync();                                        // the tokens are in memory
     LANES(l) { if (l == 0) lds_st_i32(&C.lend_done[li], lds_ld_i32(&C.a_go)); }
@@ -336,6 +462,7 @@ HDN void fourtu_last_range_half() {
     WideCtl &C = WCTL;
     const u16 *tok = wave_tok(F.sc, 1);
     while (lds_ld_i32(&C.b_hand) != lds_ld_i32(&C.cu8)) pipe_pause();
+    while (lds_ld_i32(&C.b_seg) - lds_ld_i32(&C.b_cons) < 4) pipe_pause();      // (partner workgroups: the last segment is closed by the token wavefront, fourtu_tokens_solo)
     wave_sync();
     split_start(q);
     LANES(l) {
@@ -403,11 +530,13 @@ HDN_EVAL void eval_2Nx2N(int wave_, int depth_, int N_, int y0_, int x0_, int av
     else if (wave < 2) { it[0].own = wave; it[0].shape = wave; it[0].lo = 0; it[0].hi = split_mode(N, wave); }
     else { nit = 2; for (int i = 0; i < 2; i++) { it[i].own = i; it[i].shape = i; it[i].lo = split_mode(N, i); it[i].hi = NMODE; } }
     P1Args P;
-    P.q = q; P.only_mode = -1; P.hint = 0;
+    P.q = q; P.only_mode = -1; P.hint = 0; P.rec8 = nullptr;
     long long pt = prof_now();
     for (int ii = 0; ii < nit; ii++) {
         const int shape = it[ii].shape;
         P.own = it[ii].own; P.c_lo = it[ii].lo; P.c_hi = it[ii].hi; P.shape = shape; P.tok = wave_tok(F.sc, it[ii].own);
+        P.rec8 = solo ? rec8_of(shape) : nullptr;
+        if (solo && shape == 1) { fourtu_passes_solo(y0, x0, avm); continue; }      // partner workgroup: the four TU passes without their tokens (a second wavefront makes them: fourtu_tokens_solo)
         const int ntu = (shape == 0) ? 1 : 4;
         int k_first = 0;
         if (TU0_SHARE && N == 8 && shape == 1 && !solo) { tu0_from_pu0(wave, P.tok); k_first = 1; if (wide8) seg_close(W, 0); }      // TU 0 = the PU wave's PU 0
@@ -480,7 +609,7 @@ HDN_EVAL void pu_step_wide(int wave_, int yk_, int xk_, int k_) {      // (out o
     const int wave = uni_i(wave_); const int k = uni_i(k_);
     P1Args P;
     P.q = F.job.q; P.only_mode = -1; P.shape = 3; P.tok = wave_tok(F.sc, wave); P.N = 4; P.y0 = uni_i(yk_); P.x0 = uni_i(xk_); P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
-    P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1;
+    P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = 1; P.rec8 = nullptr;
     WaveMem &W = WM(wave);
     const Tables &T = SM.T;
     PuX &U = PUX; SplitQ &q = XM(2).q;
@@ -589,7 +718,7 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
         prof_add(PF_P1_32, pt); pt = prof_now();            // (NxN chain, IMCVT_PROF builds: p1_32 = borders, p1_16 = store drain before pricing, p1_8 = pick + keep,
         P1Args P;                                           //  p2_32 = NxN header + stream assembly, p2_16 = the NxN trial itself)
         P.q = q; P.only_mode = -1; P.shape = 3; P.tok = tok; P.N = 4; P.y0 = yk; P.x0 = xk; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_REC4;
-        P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = hint;
+        P.own = wave; P.c_lo = 0; P.c_hi = NMODE; P.hint = hint; P.rec8 = nullptr;
         if (F.wide) {                                   // wide workgroup: pass and pricing shared with waves 7 and 6
             pu_step_wide(wave, yk, xk, k);
             prof_add(PF_P1_4, pt); pt = prof_now();
@@ -726,28 +855,63 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 
 #define PIPE_HDR_OFF 2048     // the 35 header streams: token PIPE_HDR_OFF.. of the PU wave's candidate slots (a PU candidate uses < 200)
 // the pipe wave's coders in a wide workgroup: range half of the 35 speculative NxN streams (header, winners of PUs 0..2, PU 3's winner on the lane that guessed its mode)
+// the context stage of the pipe wave's streams (a main workgroup whose 2Nx2N sets are with its partner: wave 1 has nothing else to do) — hevc_core.h CtxQ
+HDN void pipe_ctx_stage() {
+    WaveMem &W = PM;
+    const WaveMem &W2 = WM(2);
+    const u16 *tok2 = wave_tok(F.sc, 2);
+    CtxQ &cq = CTXQ;
+    while (lds_ld_i32(&cq.go) == lds_ld_i32(&cq.done)) pipe_pause();      // the headers are made (and in memory), the rings' counters zeroed
+    wave_sync();
+    LANES(l) {
+        const int on = l < NMODE, ll = on ? l : 0;
+        const int nh = W.tokn[ll];
+        u8 *cx = W.u.p2.cx[ll];
+        const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
+        int cblk = 0;
+        if (on) ctx_copy(cx, SM.entry_cx[2]);
+        stream_seg_C<false>(cx, cq, l, cblk, hdr, on ? nh : 0);
+        const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
+        stream_seg_C<true>(cx, cq, l, cblk, PUX.kept, on ? n012 : 0);
+        split_await(&XM(PIPE_WAVE).q.mid, XM(PIPE_WAVE).q);      // PU 3 is decided (the range wavefront passes flag B on as this generation's `mid`, as to the byte half)
+        const int mine = on & (l == W2.pu_mode[3]);
+        stream_seg_C<true>(cx, cq, l, cblk, PUX.kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+    }
+    wave_sync_lds();
+    LANES(l) { if (l == 0) lds_st_i32(&cq.done, lds_ld_i32(&cq.go)); }
+}
 HDN void nxn_pipe_wide() {
     WaveMem &W = PM;
     const WaveMem &W2 = WM(2);
     u16 *tok2 = wave_tok(F.sc, 2);
-    const u16 *kept = tok2 + (size_t)NMODE * TOK_CAP + NXN_KEEP;
         SplitQ &q = XM(PIPE_WAVE).q;
+        const int three = lds_ld_i32(&WCTL.remote8) != 0;      // the 2Nx2N sets are with the partner workgroup: a third wavefront runs the context side of these coders (pipe_ctx_stage)
         split_start(q);
+        if (three) {
+            CtxQ &cq = CTXQ;
+            LANES(l) { if (l < NMODE) { cq.prod[l] = 0; cq.cons[l] = 0; } }
+            wave_sync_lds();
+            LANES(l) { if (l == 0) lds_st_i32(&cq.go, lds_ld_i32(&cq.go) + 1); }
+        }
         LANES(l) {
             const int on = l < NMODE, ll = on ? l : 0;
             const int nh = W.tokn[ll];
             u8 *cx = W.u.p2.cx[ll];
             const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
-            int range = SM.entry_a[2].range, blk = 0;
-            if (on) ctx_copy(cx, SM.entry_cx[2]);
-            stream_seg_R<false>(range, cx, q, l, blk, hdr, on ? nh : 0);
+            int range = SM.entry_a[2].range, blk = 0, cblk = 0;
             const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
-            stream_seg_R_ldsrc(range, cx, q, l, blk, PUX.kept, on ? n012 : 0);
+            if (three) stream_seg_Rq(range, CTXQ, q, l, cblk, blk, on ? nh : 0);
+            else { if (on) ctx_copy(cx, SM.entry_cx[2]); stream_seg_R<false>(range, cx, q, l, blk, hdr, on ? nh : 0); }
+            if (three) tl_mark(37);                             // 37: range half through the headers
+            if (three) stream_seg_Rq(range, CTXQ, q, l, cblk, blk, on ? n012 : 0);
+            else stream_seg_R_ldsrc(range, cx, q, l, blk, PUX.kept, on ? n012 : 0);
+            if (three) tl_mark(38);                             // 38: ... through the winners of PUs 0 .. 2
             while (lds_ld_i32(&SM.pipe_b) == 0) pipe_pause();
             wave_sync_lds();
             if (l == 0) lds_st_i32(&q.mid, lds_ld_i32(&q.go));      // PU 3 is decided: the partner may go on too
             const int mine = on & (l == W2.pu_mode[3]);
-            stream_seg_R_ldsrc(range, cx, q, l, blk, PUX.kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+            if (three) stream_seg_Rq(range, CTXQ, q, l, cblk, blk, mine ? W2.pu_cnt[3] : 0);
+            else stream_seg_R_ldsrc(range, cx, q, l, blk, PUX.kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
             if (mine) { q.range_out[l] = range; SM.nxn_lane = l; }
             if (l == 0) { lds_st_i32(&SM.pipe_a, 0); lds_st_i32(&SM.pipe_b, 0); }
         }
@@ -797,6 +961,7 @@ HDN_EVAL void nxn_pipe(int y0_, int x0_) {
         }
     }
     wave_sync();                                        // the headers are in memory; the token rows make room for the coders' contexts
+    if (F.wide && lds_ld_i32(&WCTL.remote8) != 0) tl_mark(36);      // (timeline builds, CUs whose 2Nx2N sets are out: 36 the pipe wave's 35 headers made)
     if (F.wide) { nxn_pipe_wide(); return; }           // wide workgroup: the range half of the 35 streams here, the byte half on the partner wavefront (partner_pipe)
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
@@ -853,11 +1018,14 @@ HDN void partner_pipe() {
         LeadSink sink; lsink_begin(sink, a0, X.lm[ll].ring, gbuf);
         int blk = 0, qn = 0;
         stream_seg_L(a, sink, qn, q, l, blk, on ? nh : 0);
+        if (lds_ld_i32(&WCTL.remote8) != 0) tl_mark(40);      // 40: byte half through the headers
         const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
         stream_seg_L(a, sink, qn, q, l, blk, on ? n012 : 0);
+        if (lds_ld_i32(&WCTL.remote8) != 0) tl_mark(41);      // 41: ... through the winners of PUs 0 .. 2
         split_await(&q.mid, q);                         // PU 3 is decided (its winner's tokens are in memory)
         const int mine = on & (l == W2.pu_mode[3]);
         stream_seg_L(a, sink, qn, q, l, blk, mine ? W2.pu_cnt[3] : 0);
+        if (lds_ld_i32(&WCTL.remote8) != 0) tl_mark(42);      // 42: ... through PU 3's winner
         trial_finish(a, a0, sink, qn, mine);
         split_await(&q.rdone, q);
         if (mine) {
@@ -879,7 +1047,7 @@ HDN void rebuild_winner(int kind_, int mode_, int N_, int y0_, int x0_, int avm_
             const int wave = 0;
             P1Args P;
             P.q = F.job.q; P.only_mode = mode; P.shape = 0; P.k = 0; P.per_mode_border = 0; P.out_kind = OUT_TILE; P.tok = (u16 *)0;
-            P.own = 0; P.c_lo = 0; P.c_hi = 1;
+            P.own = 0; P.c_lo = 0; P.c_hi = 1; P.rec8 = nullptr;
             if (kind == 1) {
                 border_from_tile(wave, N, y0, x0, av.l, av.bl, av.a, av.ar);
                 P.N = N; P.y0 = y0; P.x0 = x0;
@@ -1445,7 +1613,8 @@ HDN int decide_cu8_remote(int y0_, int x0_, int avm_) {
         else if (w == PIPE_WAVE) { partner_pu_early(y0, x0); nxn_pipe(y0, x0); }
         else if (w == WAVE_B_CODER) partner_pipe();            // (wave 4: a SIMD of its own here — the one-TU set's wavefront that shares it elsewhere is idle)
         else if (w == WAVE_A_PARTNER) partner_pu(y0, x0);      // (wave 5: likewise)
-        if (w == 0 || (w >= 2 && w <= 5)) tl_mark(1 + w);      // 1: the partner's answer is staged; 3 .. 6: the NxN chain's wavefronts are through
+        else if (w == 1) pipe_ctx_stage();                     // (wave 1: the context stage of the pipe wave's streams)
+        if (w <= 5) tl_mark(1 + w);      // 1: the partner's answer is staged; 3 .. 6: the NxN chain's wavefronts are through
     }
     wg_sync_p();
     WAVES(w) { if (w == 0) tl_mark(9); }
@@ -1573,7 +1742,8 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
     WAVES_ALL(w) {
         if (w < 2) eval_2Nx2N(w, depth, N, y0, x0, avm);
         else if (w == 2) { lend_passes(2, 0, 16, 32, y0, x0, avm); partner_trial(0, depth); }      // candidates 16 .. 31 of the one-TU set, then the byte half of its coders (SIMD c)
-        else if (w == PIPE_WAVE) partner_fourtu(depth);                                             // the four-TU set's coders, segment by segment behind wave 1's passes (SIMD d)
+        else if (w == PIPE_WAVE) partner_fourtu(depth);                                             // the four-TU set's coders, segment by segment behind its tokens (SIMD d)
+        else if (w == WAVE_PIPE_PARTNER) fourtu_tokens_solo();                                      // the four-TU set's tokens, TU by TU behind wave 1's passes (wave 6)
         else if (w == WAVE_PU_PARTNER) lend_passes(w, 1, 32, NMODE, y0, x0, avm);                   // candidates 32 .. 34 (wave 7)
         if (w <= PIPE_WAVE || w == WAVE_PU_PARTNER) tl_mark(1 + w);      // 1 .. 4, 8: the wavefronts are through the candidate sets
     }
@@ -1600,9 +1770,7 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
         }
         const FinState fe = WM(ww).fin[mode];
         wg_sync();
-        WAVES(w) { if (w == 0) tl_mark(12); }                   // 12: winner picked, its contexts out
-        rebuild_winner(kind, mode, N, y0, x0, avm);
-        WAVES(w) { if (w == 0) tl_mark(13); }                   // 13: winner's reconstruction rebuilt
+        WAVES(w) { if (w == 0) tl_mark(12); }                   // 12: winner picked, its contexts out (its reconstruction was kept by its pass: rec8_of)
         WAVES(w) LANES(l) {
             if (w == 1) {
                 const Arith e = unpack_arith(fe);
@@ -1623,11 +1791,7 @@ HDN void serve_request8(const ColdTables *gK_, const FrameJob *jobs_, MailSlot *
                 m_st32(&R->cost, (u32)SM.red[0]); m_st32(&R->kind, (u32)kind); m_st32(&R->mode, (u32)mode); m_st32(&R->nbytes, (u32)nbytes);
                 m_st32(&R->fin.w0, fin.w0); m_st32(&R->fin.w1, fin.w1); m_st32(&R->fin.w2, fin.w2);
             }
-            if (tid >= 96 && tid < 96 + 16) {
-                const int i = tid - 96, y = i >> 1, x4 = (i & 1) * 4;
-                const u8 *sp = &SM.rec[y0 + y + 1][x0 + x4 + 1];
-                m_st32(R->rec + y * 8 + x4, (u32)sp[0] | (u32)sp[1] << 8 | (u32)sp[2] << 16 | (u32)sp[3] << 24);
-            }
+            if (tid >= 96 && tid < 96 + 16) m_st32(R->rec + 4 * (tid - 96), *(const u32a *)(rec8_of(ww) + mode * 64 + 4 * (tid - 96)));      // the winner's reconstruction as its pass left it
         }
     }
     team_publish(&m->res_flag, seq);
@@ -1983,7 +2147,7 @@ HD void kernel_main(const KArgs &A, int block) {
     if (threadIdx.x == 0) { F.hb_last = 0; F.hb_gap = 0; F.hb_when = 0; }
 #endif
 #endif
-    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; for (int i = 0; i < NLEND; i++) WCTL.lend_done[i] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; WCTL.part_ok = 0; WCTL.seq8 = 0; WCTL.stale8 = 0; WCTL.remote8 = 0; WCTL.ans_seq = 0; WCTL.solo2n = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
+    WAVES(w) LANES(l) { if (w == 0 && l == 0 && wg_is_wide()) { for (int i = 0; i < XWAVES; i++) { SplitQ &q = XM(i).q; q.go = 0; q.mid = 0; q.rdone = 0; q.done = 0; } WCTL.a_go = 0; for (int i = 0; i < NLEND; i++) WCTL.lend_done[i] = 0; WCTL.b_seg = 0; WCTL.b_cons = 0; WCTL.b_hand = 0; WCTL.cu8 = 0; WCTL.part_ok = 0; WCTL.seq8 = 0; WCTL.stale8 = 0; WCTL.remote8 = 0; WCTL.ans_seq = 0; WCTL.solo2n = 0; WCTL.lv_seq = 0; WCTL.lv_taken = 0; CTXQ.go = 0; CTXQ.done = 0; PUX.pu_seq = 0; PUX.b_seq = 0; PUX.r_seq = 0; } }
     WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.pipe = wg_has_pipe_wave(); F.wide = wg_is_wide() && PU_HINTS; SM.pipe_a = 0; SM.pipe_b = 0; SM.nxn_lane = 0; SM.pu0_ready = 0; SM.pu0_taken = 0; } }      // (read after the barriers below)
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;

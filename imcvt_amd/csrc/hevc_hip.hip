@@ -67,7 +67,7 @@ struct imcvt_hevc_ctx {
     int wide = -1, wide_wg = 0, occ_wide = 0, last_wide = 0;   // wide workgroups (512 threads: pipe wave + four partner wavefronts, one workgroup per compute unit): < 0 whenever a pipe-wave launch fits wide_wg workgroups, 0 never, 1 as -1
     int pending_err = 0;                    // an earlier launch that nobody asked about ended badly (watchdog): reported by the next imcvt_hevc_last_status
     int wide_kernel = 0, wide_scratch = 0;  // wide launches run hevc_encode_frames_wide (hevc_wide.hip; IMCVT_HEVC_WIDE_KERNEL=0: the common instantiation), its private segment per lane
-    int partners = 0, last_part = 0;        // partner workgroups (wide pools: the 2Nx2N sets of a main workgroup's 8x8 CUs on a second compute unit, hevc_frame.h): 0 never (default: measured slower), 1 / < 0 wherever they fit
+    int partners = -1, last_part = 0;       // partner workgroups (wide pools: the 2Nx2N sets of a main workgroup's 8x8 CUs on a second compute unit, hevc_frame.h): < 0 (default) / 1 wherever they fit, 0 never
     int split = -1, split_hpc = 0, last_split = 0;      // a pool spread over two cooperating launches (launch_split): < 0 where planned, 0 never, 1 as < 0; helper workgroups per compute unit of the helpers' set (0: default)
     hipStream_t st_split[2] = { nullptr, nullptr }; int split_cus[2] = { 0, 0 };      // streams bound to two disjoint sets of compute units, and how many each holds
     hipEvent_t ev_split[3] = { nullptr, nullptr, nullptr };

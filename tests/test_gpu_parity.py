@@ -313,12 +313,12 @@ def test_wide_workgroups_full_hd_frame_and_launches_too_large_for_them(amd):
     enc.set_wide(-1)
     b64 = enc.make_batch(imgs[:64], 0)
     enc.encode(b64); a = enc.results(b64)
-    assert enc.last_wide() and enc.last_shape() == (64, 128) and enc.last_partners() == 0
-    enc.set_partners(1)
-    enc.encode(b64); a_p = enc.results(b64)
-    assert enc.last_wide() and enc.last_shape() == (64, 112) and enc.last_partners() == 64      # (round 6, optional: a partner workgroup per main workgroup, the helpers cut to what is left of 15/16 of the compute units)
-    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, a_p))
+    assert enc.last_wide() and enc.last_shape() == (64, 112) and enc.last_partners() == 64      # (round 6: a partner workgroup per main workgroup, the helpers cut to what is left of 15/16 of the compute units)
     enc.set_partners(0)
+    enc.encode(b64); a_p = enc.results(b64)
+    assert enc.last_wide() and enc.last_shape() == (64, 128) and enc.last_partners() == 0
+    assert all(x[0] == y[0] and (x[1] == y[1]).all() for x, y in zip(a, a_p))
+    enc.set_partners(-1)
     b128 = enc.make_batch(imgs[:128], 0)
     enc.encode(b128); b = enc.results(b128)
     cus = enc.residency()["cus"]
@@ -635,7 +635,6 @@ def test_partner_workgroups_give_identical_streams(amd):
     import torch
     es = [e for e in SMALL if e["qpd6"] in (0, 4)]
     enc = amd.DeviceEncoder()
-    enc.set_partners(1)                              # (off by default: correct, but slower than the main workgroup alone — DESIGN.md section 1)
     for e in es[:6] + [e for e in es if e["input"].get("file") == "p5_gray.pgm"]:
         b = enc.make_batch([torch.from_numpy(kat_input(e["input"]).copy()).cuda()], e["qpd6"])
         enc.encode(b)
@@ -662,7 +661,6 @@ def test_partner_workgroups_1080p_digest(amd, seed):
     from oracle import synth
     e = next(e for e in LARGE if e["input"].get("arg") == seed and e["qpd6"] == 0)
     enc = amd.DeviceEncoder()
-    enc.set_partners(1)
     b = enc.make_batch([torch.from_numpy(synth.syn(1920, 1080, seed)).cuda()], 0)
     enc.encode(b)
     (s, r), = enc.results(b)

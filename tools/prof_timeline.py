@@ -32,6 +32,11 @@ names[56] = "PU 1: step begins"; names[57] = "PU 1: borders made"; names[58] = "
 names[62] = "PU 1: predicted"; names[63] = "PU 1: transformed"; names[64] = "PU 1: quantised"
 names[11] = "request to the partner workgroup is out"; names[67] = "the partner's answer: flag seen"
 names[40] = "wave 0: first pass item done"; names[41] = "wave 0: second pass item done"; names[42] = "one-TU set: tokens complete"
+if flat[11]:          # (CUs whose 2Nx2N sets went to a partner workgroup: slots 36 .. 42 time the pipe wave and its byte half there)
+    for ev in (36, 37, 38, 39, 40, 41, 42):
+        names.pop(ev, None)
+    names[36] = "pipe wave: 35 headers made"; names[37] = "pipe wave: range half through the headers"; names[38] = "pipe wave: range half through the winners of PUs 0..2"
+    names[40] = "pipe byte half: through the headers"; names[41] = "pipe byte half: through the winners of PUs 0..2"; names[42] = "pipe byte half: through PU 3's winner"
 print(f"trials finished {flat[66]}, with lanes on the exact path {flat[65]}")
 print(f"1 x {w}x{h} q{q}: kernel {ms:.1f} ms, wide {enc.last_wide()}, {n} 8x8 CUs; average cycles since the CU was entered:")
 for ev, t in sorted(((ev, flat[ev] / max(n, 1)) for ev in names if flat[ev]), key=lambda x: x[1]):
