@@ -228,7 +228,7 @@ struct Tables {
     u8  cgrank_hv[2][16];  // inverse, indexed gy*8+gx (only 0,1,8,9 used)
     u8  incg[3][16];       // [type][n] -> (yi<<2)|xi inside a 4x4 group
     u8  incg_rank[3][16];  // inverse: [type][yi*4+xi] -> n
-    uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8        (:700-712)
+    uint2 pst[128];        // per packed state p: .x = the 4 LPS ranges, .y = nextLPS | nextMPS<<8 | p<<16        (:700-712)
     u32 posadd[4][3];      // sig_coeff ctx increment per in-group scan position, 2 bits each [pattern][type]  (:1115-1120)
     u64 c4tab[3];          // 4x4-TU sig_coeff ctx per scan position, 4 bits each [type]                  (:1092)
     u32 c4prev[3][4];      // [type]: per scan position n of a 4x4 TU (a byte each) the scan positions above n that share its sig_coeff context: nearest | next << 4 (0: none)
@@ -2825,9 +2825,38 @@ HD void block_C8(u8 *cx, const U4 &cur, u32 out[16]) {
         }
     }
 }
+// The same on a context copy that holds TABLE ENTRIES (8 bytes per context: pst[state], whose bits 16..22 of .y are the state) instead of state bytes: a token's
+// entry is ONE LDS read at an address the token alone gives — issued a token ahead, nothing on the chain waits for a second, dependent read (state -> entry);
+// the entry of the state the token leaves behind is read off the chain and stored back (and handed on when the next token meets the same context).
+HD void block_C8e(uint2 *cx8, const U4 &cur, u32 out[16]) {
+    u32 tok = tok_of(cur, 0);
+    u32 cim = tok >> 8;
+    int ci = (int)(cim < (u32)CX_PAD ? cim : (u32)CX_PAD);
+    uint2 e = cx8[ci];
+    UNROLL_FULL
+    for (int j = 0; j < 8; j++) {
+        const int is_lps = (int)(tok ^ (e.y >> 16)) & 1;
+        const int nx = (int)((is_lps ? e.y : e.y >> 8) & 255u);
+        const uint2 ef = SM.T.pst[nx];
+        u32 tokn = 0; int cin = 0; uint2 en; en.x = en.y = 0;
+        if (j < 7) {
+            tokn = tok_of(cur, j + 1);
+            const u32 cimn = tokn >> 8;
+            cin = (int)(cimn < (u32)CX_PAD ? cimn : (u32)CX_PAD);
+            en = cx8[cin];                                                 // (read before the store below: stale when cin == ci — then ef is handed on instead)
+        }
+        cx8[ci] = ef;
+        out[2 * j] = e.x; out[2 * j + 1] = tok | (u32)is_lps << 16;
+        if (j < 7) {
+            const int same = cin == ci;
+            e.x = same ? ef.x : en.x; e.y = same ? ef.y : en.y;
+            tok = tokn; ci = cin;
+        }
+    }
+}
 // tokens p[0..n) (LDS when lds_src, else global memory) through the context stage; `cblk` counts this lane's blocks of the run
-template <bool LDS_SRC>
-HD void stream_seg_C(u8 *cx, CtxQ &cq, int lane, int &cblk, const u16 *p, int n) {
+template <bool LDS_SRC, bool E8 = false>
+HD void stream_seg_C(u8 *cx, CtxQ &cq, int lane, int &cblk, const u16 *p, int n) {      // E8: cx is a copy of table entries (uint2 per context, block_C8e)
     const int last_blk = imax((n - 1) >> 3, 0);
     const int ql = lane < NMODE ? lane : 0;
     u32 *const row = cq.rec[ql];
@@ -2842,7 +2871,7 @@ HD void stream_seg_C(u8 *cx, CtxQ &cq, int lane, int &cblk, const u16 *p, int n)
         if (k0 < n) {
             while (WAVE_ANY(cblk - cons_seen >= QDEPTH)) { if (cblk - cons_seen >= QDEPTH) { pipe_pause(); cons_seen = lds_ld_i32(&cq.cons[ql]); } }
             u32 out[16];
-            block_C8(cx, cur, out);
+            if constexpr (E8) block_C8e((uint2 *)cx, cur, out); else block_C8(cx, cur, out);
             u32 *d = row + (cblk & (QDEPTH - 1)) * 16;
             UNROLL_FULL
             for (int j = 0; j < 16; j++) d[j] = out[j];

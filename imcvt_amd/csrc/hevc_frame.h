@@ -856,26 +856,42 @@ HDN_EVAL void eval_NxN(int wave_, int y0_, int x0_, int avm_) {
 #define PIPE_HDR_OFF 2048     // the 35 header streams: token PIPE_HDR_OFF.. of the PU wave's candidate slots (a PU candidate uses < 200)
 // the pipe wave's coders in a wide workgroup: range half of the 35 speculative NxN streams (header, winners of PUs 0..2, PU 3's winner on the lane that guessed its mode)
 // the context stage of the pipe wave's streams (a main workgroup whose 2Nx2N sets are with its partner: wave 1 has nothing else to do) — hevc_core.h CtxQ
+#define CX8_STRIDE (CTX_STRIDE + 1)        // entries per lane (odd: the lanes' copies start in different banks)
+HD uint2 *cx8_of(int lane) { return (uint2 *)wave_mem_ptr(WAVE_A_PARTNER) + lane * CX8_STRIDE; }      // the lenders' three slices are idle while a CU's 2Nx2N sets are with the partner
+static_assert((size_t)NMODE * CX8_STRIDE * 8 <= NLEND * sizeof(WaveMem), "the context copies of table entries fit the lenders' slices");
 HDN void pipe_ctx_stage() {
     WaveMem &W = PM;
     const WaveMem &W2 = WM(2);
     const u16 *tok2 = wave_tok(F.sc, 2);
     CtxQ &cq = CTXQ;
+    // the copies first — a table ENTRY per context (block_C8e) from the CU's entry states, long before anybody needs them (this wavefront has nothing else to do until PU 2 is decided)
+    LANES(l) {
+        if (l < NMODE) {
+            uint2 *c8 = cx8_of(l);
+            for (int i = 0; i < CTX_STRIDE; i++) c8[i] = SM.T.pst[SM.entry_cx[2][i] & 127];
+        }
+    }
+    wave_sync_lds();
     while (lds_ld_i32(&cq.go) == lds_ld_i32(&cq.done)) pipe_pause();      // the headers are made (and in memory), the rings' counters zeroed
     wave_sync();
     LANES(l) {
         const int on = l < NMODE, ll = on ? l : 0;
         const int nh = W.tokn[ll];
-        u8 *cx = W.u.p2.cx[ll];
+        u8 *cx = (u8 *)cx8_of(ll);
         const u16 *hdr = tok2 + (size_t)ll * TOK_CAP + PIPE_HDR_OFF;
         int cblk = 0;
-        if (on) ctx_copy(cx, SM.entry_cx[2]);
-        stream_seg_C<false>(cx, cq, l, cblk, hdr, on ? nh : 0);
+        stream_seg_C<false, true>(cx, cq, l, cblk, hdr, on ? nh : 0);
         const int n012 = W2.pu_cnt[0] + W2.pu_cnt[1] + W2.pu_cnt[2];
-        stream_seg_C<true>(cx, cq, l, cblk, PUX.kept, on ? n012 : 0);
+        stream_seg_C<true, true>(cx, cq, l, cblk, PUX.kept, on ? n012 : 0);
         split_await(&XM(PIPE_WAVE).q.mid, XM(PIPE_WAVE).q);      // PU 3 is decided (the range wavefront passes flag B on as this generation's `mid`, as to the byte half)
         const int mine = on & (l == W2.pu_mode[3]);
-        stream_seg_C<true>(cx, cq, l, cblk, PUX.kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+        stream_seg_C<true, true>(cx, cq, l, cblk, PUX.kept + 3 * NXN_KEEP_STRIDE, mine ? W2.pu_cnt[3] : 0);
+    }
+    wave_sync_lds();
+    LANES(l) {                                              // the states of the lane that guessed PU 3's mode, where the decision looks for the NxN trial's contexts
+        const uint2 *c8 = cx8_of(W2.pu_mode[3]);
+        u8 *dst = W.u.p2.cx[W2.pu_mode[3]];
+        for (int i = l; i < CTX_STRIDE; i += 64) dst[i] = (u8)((c8[i].y >> 16) & 127u);
     }
     wave_sync_lds();
     LANES(l) { if (l == 0) lds_st_i32(&cq.done, lds_ld_i32(&cq.go)); }

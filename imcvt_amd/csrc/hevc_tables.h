@@ -105,7 +105,7 @@ inline void build_tables(Tables &T, ColdTables &K) {
         const int st = p >> 1, mps = p & 1;
         const u32 next_lps = (st == 0) ? (u32)(1 - mps) : (u32)((kTransLps[st] << 1) | mps);
         T.pst[p].x = (u32)kRangeLps[st * 4] | (u32)kRangeLps[st * 4 + 1] << 8 | (u32)kRangeLps[st * 4 + 2] << 16 | (u32)kRangeLps[st * 4 + 3] << 24;
-        T.pst[p].y = next_lps | (u32)((p < 124) ? p + 2 : p) << 8;
+        T.pst[p].y = next_lps | (u32)((p < 124) ? p + 2 : p) << 8 | (u32)p << 16;      // (bits 16..22: the packed state itself — a context copy that holds table ENTRIES, hevc_core.h block_C8e, reads its MPS there; every other user takes bytes 0 / 1)
     }
     // sig_coeff_flag context increments per in-group scan position (reference :1115-1120)
     for (int pat = 0; pat < 4; pat++) for (int t = 0; t < 3; t++) {
