@@ -65,7 +65,7 @@ typedef u32 __attribute__((may_alias)) u32a;      // a dword view of data that i
   HD i32 lds_ld_i32(const i32 *p) { return *(const volatile i32 *)p; }
   HD void lds_st_i32(i32 *p, i32 v) { *(volatile i32 *)p = v; }
   HD void pipe_pause() { emu_yield(); }
-  static int emu_pipe_on(); static int emu_wide_on();
+  static int emu_pipe_on(); static int emu_wide_on(); static int emu_late_main();
   HD int wg_has_pipe_wave() { return emu_pipe_on(); }
   HD int wg_is_wide() { return emu_wide_on(); }
   HD unsigned long long wd_now() { return 0; }      // (the emulation has its own deadlock detector)
@@ -414,6 +414,19 @@ struct alignas(256) PoolQ {
     PoolShard sh[POOL_SHARDS];
     u32 cu_count[POOL_CU_KEYS];                  // workgroups of this launch that have started on each compute unit (role choice, hevc_frame.h kernel_main)
 };
+// A pool launch is old enough that every workgroup which is going to start with the others has started (they arrive within ~40 us; `start_lo`: low word of the launch's earliest
+// start, 100 MHz): a main-workgroup index that is still free by then belongs to a workgroup the dispatcher is holding back — seen seconds late on launches that fill every slot —
+// and a running helper takes it (hevc_frame.h helper_loop).
+#ifndef LATE_MAIN_TICKS
+#define LATE_MAIN_TICKS 200000u        // 2 ms
+#endif
+#ifdef IMCVT_HOSTEMU
+HD int pool_cu_key(int home) { return home; }            // (the emulated workgroups have no compute units: a queue shard stands in — two helpers of one shard do not both take the path)
+HD int late_main_due(const int *, int home) { return emu_late_main() && (home & 1); }      // (tests: HOSTEMU_LATE_MAIN=1 — the helpers of odd shards take the new path, the others the idle one)
+#else
+HD int pool_cu_key(int) { return hw_cu_key() % POOL_CU_KEYS; }
+HD int late_main_due(const int *counter, int) { const u32 t0 = m_ld32(counter + 4); return t0 != 0xFFFFFFFFu && (u32)((u32)wd_now() - t0) > LATE_MAIN_TICKS; }
+#endif
 struct FrameCtx {
     FrameJob job;
     Scratch sc;

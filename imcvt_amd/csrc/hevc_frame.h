@@ -38,7 +38,7 @@ HD void hb_set(unsigned long long v) { F.hb_last = v; }
 HD void hb_beat() {}
 HD void hb_set(unsigned long long) {}
 #define HB_GAP 0ull
-#define HB_WHEN 0ull
+#define HB_WHEN (dbg[4 * blk + 1])      // (left as it is: the wavefronts' SIMDs, kernel_main)
 #endif
 #ifndef NXN_PRIO_SOLO
 #define NXN_PRIO_SOLO 1
@@ -2048,6 +2048,21 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
                 // offered — per 32x32 CU), and with a strict order a busy pool never got to the 32x32 queue: main workgroups were
                 // seen waiting seconds for an answer that takes a millisecond (profiles/r03l_wd_probe.log).
                 const int first = (served & 3) == 3 ? SLOT_32 : SLOT_16;
+                // A main-workgroup index that is still free although the launch is milliseconds old: its workgroup is being held back by the dispatcher (launches that fill every
+                // workgroup slot: one or two of a thousand workgroups start only when another has left — seconds late, and a frame with it).  A running helper takes the index at
+                // once, busy or not (the idle take-over below waits for the pool to drain); the late workgroup finds every index taken and becomes a helper.
+                // One helper per compute unit at most (bits 16.. of the unit's arrival counter; a workgroup that arrives there later sees a count beyond every quota and becomes
+                // a helper): a compute unit with a third main workgroup stretches three frames by a fifth (profiles/r06t_full_pool_verbose.log), one with a fourth doubles them.
+                if (late_main_due(counter, home) && (i32)m_ld32(counter) < njobs && m_ld32(&pq->mains_taken) < (u32)nmains
+                    && (m_add32(&pq->cu_count[pool_cu_key(home)], 0x10000u) >> 16) == 0u) {
+                    if (m_add32(&pq->alive, (u32)-1) <= 1u) m_add32(&pq->alive, 1u);
+                    else {
+                        const u32 m = m_add32(&pq->mains_taken, 1u);
+                        if (m < (u32)nmains) { id = (int)m; pick = -2; }
+                        else m_add32(&pq->alive, 1u);
+                    }
+                }
+                if (pick != -2)
                 for (;;) {
                     for (int pass = 0; pass < 2 && pick < 0; pass++) {
                         shard = pass == 0 ? home : (home + 1 + round % (POOL_SHARDS - 1)) % POOL_SHARDS;
@@ -2147,6 +2162,8 @@ HD void kernel_main(const KArgs &A, int block) {
 #endif
 #ifndef IMCVT_HOSTEMU
     // residency diagnostic: counter[2] = workgroups of this launch running now, counter[3] = the most there ever were (imcvt_hevc_last_resident)
+    // (debug buffer: which SIMD each wavefront of this workgroup runs on — a byte each, 0x80 | HW_ID.simd_id — in word 1 of the workgroup's record; tools/pool_probe.py PP_OUTLIER)
+    if (A.fclk && (threadIdx.x & 63u) == 0u && (threadIdx.x >> 6) < 8u) ((volatile u8 *)(A.fclk + 4 * A.njobs + 4 * block + 1))[threadIdx.x >> 6] = (u8)(0x80u | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u));
     if (threadIdx.x == 0) {
         atomicMax(A.counter + 3, atomicAdd(A.counter + 2, 1) + 1);
         const unsigned long long now = wall_clock64();                  // 100 MHz: when the first and the last workgroup of the launch started

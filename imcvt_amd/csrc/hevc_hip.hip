@@ -390,8 +390,10 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         if ((long long)n * 8 > (long long)max_wg * 5) return 1;
         m = n < max_wg / 2 ? n : max_wg / 2;
         if (m < 1) return 1;
-        // (a sixteenth of the workgroup slots stays free: a device filled to the last slot by workgroups that wait for each other
-        // reacts badly to anything that takes a slot away for a moment — profiles/r03q_hb_probe.log — and starts slower)
+        // (a sixteenth of the workgroup slots stays free.  Fuller pools are faster when they go well — 512 + 512 workgroups 4.60 s against 4.83 s for 512 + 448 — but one launch
+        // in ten of 976 .. 1024 workgroups leaves a few compute units with a single workgroup for milliseconds: a main index stays free, and the workgroup that finally takes it —
+        // the late one after seconds in rounds 3 - 5, a running helper after 2 ms since round 6 (hevc_frame.h helper_loop, late_main_due) — is one the dispatcher placed last on
+        // its compute unit and runs its frame 1.1 - 1.9 x slower than the others: 5.2 - 8.9 s, profiles/r06u_pool_fill.log, r06x_outliers.log.  At 15/16 no launch of the round did that.)
         const int room = max_wg - max_wg / 16 - m;
         h = 2 * m < room ? 2 * m : room;
         if (h < 1) return 1;

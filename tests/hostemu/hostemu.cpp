@@ -120,6 +120,7 @@ static Shm *g_shm_of[EMU_MAX_WG];                          // each emulated work
 static unsigned char *g_pipe_of[EMU_MAX_WG];               // ... and its dynamic part (the pipe wave's slice)
 static int emu_pipe_on() { return g_wg_threads > 192; }
 static int emu_wide_on() { return g_wg_threads >= 512; }
+static int emu_late_main() { return getenv("HOSTEMU_LATE_MAIN") != nullptr; }      // (hevc_core.h late_main_due)
 static long g_spins;
 static void emu_set_shm(int wg);                            // (defined below, next to the device source's LDS pointer)
 static void emu_trampoline() {

@@ -133,13 +133,15 @@ def test_device_resident_batch_matches_host_abi(amd):
     enc.close()
 
 
-@pytest.mark.parametrize("flag", ["-DIMCVT_FORCE_OVF", "-DROWCAP=6", "-DP1_MFMA=0"], ids=["lead-sink-exact-paths", "token-row-overflow-path", "vector-transforms"])
+@pytest.mark.parametrize("flag", ["-DIMCVT_FORCE_OVF", "-DROWCAP=6", "-DP1_MFMA=0", "-DLATE_MAIN_TICKS=0"], ids=["lead-sink-exact-paths", "token-row-overflow-path", "vector-transforms", "late-main-take-over"])
 def test_rare_paths_on_the_device(amd, flag, tmp_path):
     """The paths that practically never run — a trial whose leads show the emulation-prevention pattern gets its byte count from the real
     logic over its list, a winner whose bytes would need emulation prevention is turned into bytes by lane 0's walk; a pass
     whose group tokens do not fit the lanes' LDS rows counts and writes them the plain way — forced by a build flag, on the
     real hardware (the host emulation checks their logic; lock-step execution is what only the GPU has).  Third variant: the
-    N = 16 / 32 transforms as vector code instead of matrix instructions (the A/B build of hevc_core.h p1_run_t) — same bytes."""
+    N = 16 / 32 transforms as vector code instead of matrix instructions (the A/B build of hevc_core.h p1_run_t) — same bytes.  Fourth: helpers take
+    free main-workgroup indices as soon as they see one (hevc_core.h late_main_due with no age limit: the take-over that otherwise waits until a launch is 2 ms old races the
+    main workgroups' own start here) — roles move between workgroups, bytes do not."""
     import subprocess, sys
     from conftest import ROOT
     so = str(tmp_path / "libimcvt_hevc_variant.so")

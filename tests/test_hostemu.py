@@ -352,6 +352,19 @@ def test_idle_helpers_take_over_as_main_workgroups(hostemu, monkeypatch):
         assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
 
 
+def test_busy_helpers_take_over_late_main_indices(hostemu, monkeypatch):
+    """... and a main index that is still free when the launch is milliseconds old (its workgroup is held back by the dispatcher: launches that fill every slot)
+    is taken by a running helper at once, busy or idle (hevc_core.h late_main_due; here: the helpers of odd queue shards take that path, the others the idle one)."""
+    monkeypatch.setenv("HOSTEMU_QUOTA", "0")
+    monkeypatch.setenv("HOSTEMU_LATE_MAIN", "1")
+    es = [e for e in OVF if e["qpd6"] == 0]
+    for nmains, nhelp in ((2, 3), (1, 3)):
+        res = emu_encode_pool(hostemu, [kat_input(e["input"]) for e in es], 0, nmains, nhelp)
+        for e, (stream, rcon) in zip(es, res):
+            assert hashlib.sha256(stream).hexdigest() == e["sha256"], kat_id(e)
+            assert hashlib.sha256(rcon.tobytes()).hexdigest() == e["rcon_sha256"], kat_id(e)
+
+
 def test_pool_mode_natural_image(hostemu):
     # 10 x 9 CTUs of the reference's own sample picture: helpers read their borders from the reconstruction plane across CTU rows
     e = next(e for e in kat_entries() if e["input"].get("file") == "p5_gray.pgm" and e["qpd6"] == 4)

@@ -37,6 +37,24 @@ for sh in sys.argv[5:]:
             import collections
             keys = collections.Counter((fc[:, 2] >> 32).tolist())
             print(f"      main workgroups ran on {len(keys)} compute units; frames per compute unit: {sorted(collections.Counter(keys.values()).items())}", flush=True)
+            cuk = (fc[:, 2] >> 32)
+            if os.environ.get("PP_OUTLIER") and ms[-1] > 1.12 * min(ms + [float(os.environ.get("PP_BASE_MS", "1e9"))]):
+                odd = [k for k, v in keys.items() if v != 2]
+                print("      OUTLIER: compute units whose number of frames is not 2: " + "; ".join(f"cu {k:#x}: " + ", ".join(f"f{i} blk {int(fc[i, 2] & 0xFFFFFFFF)} start {(fc[i, 0] - t0) / 1e5:.1f} end {(fc[i, 1] - t0) / 1e5:.0f} kept {int(fc[i, 3] & 0xFFFF)}" for i in range(n) if cuk[i] == k) for k in odd))
+                med = float(sorted(end)[n // 2])
+                slow = [i for i in range(n) if end[i] > 1.1 * med]
+                print(f"      OUTLIER: {len(slow)} frames end later than 1.1 x median: " + "; ".join(f"f{i} cu {int(cuk[i]):#x} blk {int(fc[i, 2] & 0xFFFFFFFF)} start {start[i]:.1f} end {end[i]:.0f} kept {int(fc[i, 3] & 0xFFFF)}" for i in slow[:24]))
+                simd = lambda b: "".join(str((int(wg[b, 1]) >> (8 * k)) & 3) for k in range(3) if (int(wg[b, 1]) >> (8 * k)) & 0x80)
+                print("      OUTLIER: SIMDs of the wavefronts of the slow frames' workgroups: " + "; ".join(f"f{i} blk {int(fc[i, 2] & 0xFFFFFFFF)} end {end[i]:.0f}: {simd(int(fc[i, 2] & 0xFFFFFFFF))}" for i in sorted(slow, key=lambda i: -end[i])[:16]))
+                import collections as _c2
+                allm = _c2.Counter("".join(sorted(simd(int(fc[i, 2] & 0xFFFFFFFF)))) for i in range(n))
+                print("      OUTLIER: SIMD patterns (sorted) of all main workgroups: " + str(sorted(allm.items(), key=lambda kv: -kv[1])[:12]))
+                slowp = _c2.Counter("".join(sorted(simd(int(fc[i, 2] & 0xFFFFFFFF)))) for i in slow)
+                print("      OUTLIER: ... of the slow ones: " + str(sorted(slowp.items(), key=lambda kv: -kv[1])[:12]))
+                wgs = [(int(wg[b, 2]) & 0xFFFF, int(wg[b, 2]) >> 32, b, (int(wg[b, 3]) - int(t0)) / 1e5) for b in range(1024) if wg[b, 3] != 0]
+                import collections as _c
+                per = _c.Counter(k for k, _, _, _ in wgs)
+                print("      OUTLIER: workgroups per compute unit (count: units) " + str(sorted(_c.Counter(per.values()).items())) + "; units with < 3: " + "; ".join(f"cu {k:#x}: " + ", ".join(f"blk {b} main {m} left {e:.0f}" for kk, m, b, e in wgs if kk == k) for k, v in per.items() if v < 3), flush=True)
             fc[:, 2] &= 0xFFFFFFFF
             waited = ((fc[:, 3] >> 16) & 0xFFFFFF) / 100.0; wmax = (fc[:, 3] >> 40) / 100.0; fc[:, 3] &= 0xFFFF
             top = sorted(range(n), key=lambda i: -((fc[i, 1] - t0)))[:4]
