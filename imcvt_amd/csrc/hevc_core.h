@@ -448,6 +448,7 @@ struct FrameCtx {
     unsigned long long hb_last, hb_gap, hb_when;   // heartbeat (debug, -DIMCVT_HB builds): clock of the last beat, longest gap between two beats and when it began
 #endif
     u32 waited, waited_max;   // 100 MHz ticks this frame's main workgroup spent waiting for answers, and the longest single wait (debug statistics)
+    i32 raised;         // CTUs of this frame that ran at raised wave priority (pace control; debug statistic)
     i32 pace_inc, pace_mine, pace_n, pace_base;   // pace control: 65536 / CTUs of this frame, this workgroup's share done, main workgroups of the launch, configured base priority
     i32 seq[POOL_KINDS];   // requests posted (main) / served (helper) so far, per slot
     i32 pipe;           // this launch's workgroups carry a pipe wave (256 threads or more)

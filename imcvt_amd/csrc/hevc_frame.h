@@ -37,7 +37,7 @@ HD void hb_set(unsigned long long v) { F.hb_last = v; }
 #else
 HD void hb_beat() {}
 HD void hb_set(unsigned long long) {}
-#define HB_GAP 0ull
+#define HB_GAP ((unsigned long long)(u32)F.kept)      // (debug buffer: a helper's requests served — helper_loop leaves the count there — or what the main workgroup's last frame kept)
 #define HB_WHEN (dbg[4 * blk + 1])      // (left as it is: the wavefronts' SIMDs, kernel_main)
 #endif
 #ifndef NXN_PRIO_SOLO
@@ -1987,6 +1987,7 @@ HDN void encode_frame(const Tables *gT, const ColdTables *gK, const FrameJob job
                         const u32 taken_ = m_ld32(&F.pq->mains_taken), running = taken_ < (u32)F.pace_n ? taken_ : (u32)F.pace_n;      // main workgroups that have actually started (the counter is bumped past the planned number by late claimers)
                         const int avg = (int)(m_ld32(&F.pq->progress) / (running ? running : 1u)), lag = avg - F.pace_mine;
                         if (lag * 2 > 3 * F.pace_inc) F.prio_base = 2; else if (lag * 2 < F.pace_inc) F.prio_base = F.pace_base;
+                        F.raised += F.prio_base != F.pace_base;
                     }
                 }
             }
@@ -2026,9 +2027,10 @@ HD void stage_tables(const Tables *gT) {
 // Returns -1 when every frame is finished, or the main-workgroup index this workgroup took over: an idle helper becomes a main
 // workgroup when frames wait in the queue and indices are left (fewer workgroups started as mains than there are frames to
 // encode at once — e.g. compute units that hold fewer workgroups of this launch than expected).
-HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int nmains_, int home_, int role_, int *counter_, int njobs_) {
+HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jobs_, const Scratch sc, TeamMail *mail_, PoolQ *pq_, int nmains_, int home_, int role_, int *counter_, int njobs_, int early_) {
     const Tables *const gT = uni_p(gT_); const ColdTables *const gK = uni_p(gK_); const FrameJob *const jobs = uni_p(jobs_); TeamMail *const mail = uni_p(mail_); PoolQ *const pq = uni_p(pq_); const int nmains = uni_i(nmains_); const int home = uni_i(home_); const int role = uni_i(role_);
     int *const counter = uni_p(counter_); const int njobs = uni_i(njobs_);
+    const int early = uni_i(early_);                     // this workgroup was the first of its compute unit that did not become a main workgroup: the one whose wavefronts are oldest
     int taken = -1, served = 0;
     const int home_blk = home;
     stage_tables(gT);
@@ -2053,7 +2055,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
                 // once, busy or not (the idle take-over below waits for the pool to drain); the late workgroup finds every index taken and becomes a helper.
                 // One helper per compute unit at most (bits 16.. of the unit's arrival counter; a workgroup that arrives there later sees a count beyond every quota and becomes
                 // a helper): a compute unit with a third main workgroup stretches three frames by a fifth (profiles/r06t_full_pool_verbose.log), one with a fourth doubles them.
-                if (late_main_due(counter, home) && (i32)m_ld32(counter) < njobs && m_ld32(&pq->mains_taken) < (u32)nmains
+                if (early && late_main_due(counter, home) && (i32)m_ld32(counter) < njobs && m_ld32(&pq->mains_taken) < (u32)nmains
                     && (m_add32(&pq->cu_count[pool_cu_key(home)], 0x10000u) >> 16) == 0u) {
                     if (m_add32(&pq->alive, (u32)-1) <= 1u) m_add32(&pq->alive, 1u);
                     else {
@@ -2121,6 +2123,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
 #if defined(IMCVT_PROF) && !defined(IMCVT_HOSTEMU)
     if (sc.prof && threadIdx.x < WG_THREADS && (threadIdx.x & 63u) < PF_N) atomicAdd(&sc.prof[(role * NWAVES + (threadIdx.x >> 6)) * PF_N + (threadIdx.x & 63u)], SM.prof[threadIdx.x >> 6][threadIdx.x & 63u]);
 #endif
+    WAVES(w) LANES(l) { if (w == 0 && l == 0) F.kept = served; }      // (debug buffer, HB_GAP)
     (void)role;
     return taken;
 }
@@ -2204,7 +2207,12 @@ HD void kernel_main(const KArgs &A, int block) {
 #endif
                 int mid = -1;
                 // (a launch of main workgroups only: every workgroup takes an index while they last; of helpers only: none does — an idle helper may still take one later, helper_loop)
-                const int want = A.role == 1 ? 1 : A.role == 2 ? 0 : (int)m_add32(&A.pq->cu_count[key], 1u) < A.quota;
+                const int arrival = (A.role == 1 || A.role == 2) ? 0 : (int)(m_add32(&A.pq->cu_count[key], 1u) & 0xFFFFu);      // which workgroup of this launch on its compute unit: 0, 1, ...
+                const int want = A.role == 1 ? 1 : A.role == 2 ? 0 : arrival < A.quota;
+                SM.next_frame = arrival;                 // (a free word until the frame loop)
+#ifndef IMCVT_HOSTEMU
+                if (A.fclk) ((volatile u8 *)(A.fclk + 4 * A.njobs + 4 * block + 1))[7] = (u8)(0x80u | (u32)arrival);      // (debug buffer, beside the wavefronts' SIMDs)
+#endif
                 if (want && m_ld32(&A.pq->mains_taken) < (u32)nm) { const u32 m = m_add32(&A.pq->mains_taken, 1u); if (m < (u32)nm) mid = (int)m; }
                 // wide launches with partner workgroups: the next `npart` workgroups to start serve the 8x8 CUs of main workgroups 0 .. npart - 1 (partner8_loop)
                 int pid = -1;
@@ -2215,11 +2223,12 @@ HD void kernel_main(const KArgs &A, int block) {
         wg_sync();
         team = SM.red[0];
         const int pid = SM.red[1];
+        const int arrival = SM.next_frame;
         wg_sync();
         if (team < 0 && pid >= 0) { sc.trace = (i32 *)0; partner8_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, pid, A.njobs); return; }
         if (team < 0) {
             sc.trace = (i32 *)0;
-            team = helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, block % POOL_SHARDS, 1, A.counter, A.njobs);
+            team = helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, block % POOL_SHARDS, 1, A.counter, A.njobs, arrival <= A.quota);
             if (team < 0) return;
         }
     }
@@ -2240,7 +2249,7 @@ HD void kernel_main(const KArgs &A, int block) {
         wg_sync();
         if (f >= A.njobs) break;
         sc.trace = (f == 0) ? A.trace : (i32 *)0;
-        WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.frame = f; F.kept = 0; F.waited = 0; F.waited_max = 0; } }
+        WAVES(w) LANES(l) { if (w == 0 && l == 0) { F.frame = f; F.kept = 0; F.raised = 0; F.waited = 0; F.waited_max = 0; } }
         if (F.aborted) break;
 #ifndef IMCVT_HOSTEMU
         if (A.fclk && threadIdx.x == 0) A.fclk[4 * f] = wall_clock64();
@@ -2248,7 +2257,7 @@ HD void kernel_main(const KArgs &A, int block) {
         encode_frame(A.gT, A.gK, A.jobs[f], sc, A.hdrs + (size_t)HDR_MAX * f);
         if (pool) { WAVES(w) LANES(l) { if (w == 0 && l == 0) m_add32(&A.pq->frames_done, 1u); } }      // (every request of the frame has been answered)
 #ifndef IMCVT_HOSTEMU
-        if (A.fclk && threadIdx.x == 0) { A.fclk[4 * f + 1] = wall_clock64(); A.fclk[4 * f + 2] = (unsigned long long)block | (unsigned long long)hw_cu_key() << 32; A.fclk[4 * f + 3] = (unsigned long long)F.kept | (unsigned long long)(F.waited / 1000u) << 16 | (unsigned long long)(F.waited_max / 1000u) << 40; }
+        if (A.fclk && threadIdx.x == 0) { A.fclk[4 * f + 1] = wall_clock64(); A.fclk[4 * f + 2] = (unsigned long long)block | (unsigned long long)hw_cu_key() << 32 | (unsigned long long)(F.raised & 0xFFFF) << 48; A.fclk[4 * f + 3] = (unsigned long long)F.kept | (unsigned long long)(F.waited / 1000u) << 16 | (unsigned long long)(F.waited_max / 1000u) << 40; }
 #endif
     }
 }

@@ -219,7 +219,8 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
     delete T; delete K;
     if (ok) {
         std::vector<Scratch> hs(c->max_wg);
-        for (int i = 0; i < c->max_wg; i++) scratch_carve(hs[i], (u8 *)c->d_pool + per_wg * i);
+        const bool rev = getenv("IMCVT_SCRATCH_REV") != nullptr;      // (probe: does a workgroup's speed follow its scratch slot or its place in the dispatch order?  profiles/r06za_scratch_rev.log)
+        for (int i = 0; i < c->max_wg; i++) scratch_carve(hs[i], (u8 *)c->d_pool + per_wg * (rev ? c->max_wg - 1 - i : i));
         ok = hipMemcpy(c->d_scratch, hs.data(), sizeof(Scratch) * c->max_wg, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { fprintf(stderr, "imcvt_hevc: context allocation failed\n"); imcvt_hevc_destroy(c); return nullptr; }

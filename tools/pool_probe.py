@@ -35,21 +35,34 @@ for sh in sys.argv[5:]:
             if gaps: print('      workgroups with a heartbeat gap > 20 ms (gap ms, began at ms, cu key, main?, block): ' + ' '.join(f'({g[0]:.0f},{g[1]:.0f},{g[2]:#x},{g[3]},{g[4]})' for g in sorted(gaps, reverse=True)[:24]), flush=True)
             end = (fc[:, 1] - t0) / 1e5; start = (fc[:, 0] - t0) / 1e5; late = int(end.argmax())
             import collections
-            keys = collections.Counter((fc[:, 2] >> 32).tolist())
+            keys = collections.Counter(((fc[:, 2] >> 32) & 0xFFFF).tolist())
             print(f"      main workgroups ran on {len(keys)} compute units; frames per compute unit: {sorted(collections.Counter(keys.values()).items())}", flush=True)
-            cuk = (fc[:, 2] >> 32)
+            cuk = (fc[:, 2] >> 32) & 0xFFFF
+            raised = (fc[:, 2] >> 48) & 0xFFFF
+            if os.environ.get("PP_OUTLIER"):
+                import collections as _c3
+                hs = [(int(wg[b, 0]) & 0xFFFFFFFF, (int(wg[b, 1]) >> 56) & 0x7F, b) for b in range(1024) if wg[b, 3] != 0 and not (int(wg[b, 2]) >> 32) & 1 and (int(wg[b, 1]) >> 56) & 0x80]
+                by = _c3.defaultdict(list)
+                for sv, arr, b in hs: by[arr].append(sv)
+                print("      helpers: requests served by arrival index on the compute unit: " + "; ".join(f"arrival {a}: {len(v)} helpers, mean {sum(v) / len(v):.0f} min {min(v)} max {max(v)}" for a, v in sorted(by.items())), flush=True)
+                by2 = _c3.defaultdict(list)
+                for sv, arr, b in hs: by2[b // 64].append(sv)
+                print("      helpers: mean requests served by block / 64: " + " ".join(f"{k}:{sum(v) / len(v):.0f}" for k, v in sorted(by2.items())), flush=True)
+                mr = _c3.defaultdict(list)
+                for i in range(n): mr[int(fc[i, 2] & 0xFFFFFFFF) // 64].append((float(end[i]) if False else 0, int(raised[i])))
+                print("      mains: CTUs at raised priority, mean by block / 64: " + " ".join(f"{k}:{sum(r for _, r in v) / len(v):.0f}" for k, v in sorted(mr.items())), flush=True)
             if os.environ.get("PP_OUTLIER") and ms[-1] > 1.12 * min(ms + [float(os.environ.get("PP_BASE_MS", "1e9"))]):
                 odd = [k for k, v in keys.items() if v != 2]
                 print("      OUTLIER: compute units whose number of frames is not 2: " + "; ".join(f"cu {k:#x}: " + ", ".join(f"f{i} blk {int(fc[i, 2] & 0xFFFFFFFF)} start {(fc[i, 0] - t0) / 1e5:.1f} end {(fc[i, 1] - t0) / 1e5:.0f} kept {int(fc[i, 3] & 0xFFFF)}" for i in range(n) if cuk[i] == k) for k in odd))
                 med = float(sorted(end)[n // 2])
                 slow = [i for i in range(n) if end[i] > 1.1 * med]
                 print(f"      OUTLIER: {len(slow)} frames end later than 1.1 x median: " + "; ".join(f"f{i} cu {int(cuk[i]):#x} blk {int(fc[i, 2] & 0xFFFFFFFF)} start {start[i]:.1f} end {end[i]:.0f} kept {int(fc[i, 3] & 0xFFFF)}" for i in slow[:24]))
-                simd = lambda b: "".join(str((int(wg[b, 1]) >> (8 * k)) & 3) for k in range(3) if (int(wg[b, 1]) >> (8 * k)) & 0x80)
-                print("      OUTLIER: SIMDs of the wavefronts of the slow frames' workgroups: " + "; ".join(f"f{i} blk {int(fc[i, 2] & 0xFFFFFFFF)} end {end[i]:.0f}: {simd(int(fc[i, 2] & 0xFFFFFFFF))}" for i in sorted(slow, key=lambda i: -end[i])[:16]))
+                simd = lambda b: "".join(str((int(wg[b, 1]) >> (8 * k)) & 3) for k in range(3) if (int(wg[b, 1]) >> (8 * k)) & 0x80) + (f" arrival {(int(wg[b, 1]) >> 56) & 0x7F}" if (int(wg[b, 1]) >> 56) & 0x80 else "")
+                print("      OUTLIER: SIMDs of the wavefronts of the slow frames' workgroups: " + "; ".join(f"f{i} blk {int(fc[i, 2] & 0xFFFFFFFF)} end {end[i]:.0f} raised {int(raised[i])}: {simd(int(fc[i, 2] & 0xFFFFFFFF))}" for i in sorted(slow, key=lambda i: -end[i])[:16]))
                 import collections as _c2
-                allm = _c2.Counter("".join(sorted(simd(int(fc[i, 2] & 0xFFFFFFFF)))) for i in range(n))
-                print("      OUTLIER: SIMD patterns (sorted) of all main workgroups: " + str(sorted(allm.items(), key=lambda kv: -kv[1])[:12]))
-                slowp = _c2.Counter("".join(sorted(simd(int(fc[i, 2] & 0xFFFFFFFF)))) for i in slow)
+                allm = _c2.Counter(simd(int(fc[i, 2] & 0xFFFFFFFF))[3:] for i in range(n))
+                print("      OUTLIER: arrival index on the compute unit, all main workgroups: " + str(sorted(allm.items(), key=lambda kv: -kv[1])[:12]))
+                slowp = _c2.Counter(simd(int(fc[i, 2] & 0xFFFFFFFF))[3:] for i in slow)
                 print("      OUTLIER: ... of the slow ones: " + str(sorted(slowp.items(), key=lambda kv: -kv[1])[:12]))
                 wgs = [(int(wg[b, 2]) & 0xFFFF, int(wg[b, 2]) >> 32, b, (int(wg[b, 3]) - int(t0)) / 1e5) for b in range(1024) if wg[b, 3] != 0]
                 import collections as _c
