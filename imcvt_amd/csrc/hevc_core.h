@@ -414,11 +414,13 @@ struct alignas(256) PoolQ {
     PoolShard sh[POOL_SHARDS];
     u32 cu_count[POOL_CU_KEYS];                  // workgroups of this launch that have started on each compute unit (role choice, hevc_frame.h kernel_main)
 };
-// A pool launch is old enough that every workgroup which is going to start with the others has started (they arrive within ~40 us; `start_lo`: low word of the launch's earliest
-// start, 100 MHz): a main-workgroup index that is still free by then belongs to a workgroup the dispatcher is holding back — seen seconds late on launches that fill every slot —
-// and a running helper takes it (hevc_frame.h helper_loop).
+// A pool launch is so old that a main-workgroup index which is still free belongs to a workgroup the dispatcher will hold back until another one leaves — seconds (launches that
+// fill every slot) — and a running helper takes it (hevc_frame.h helper_loop; `start_lo`: low word of the launch's earliest start, 100 MHz).  Not sooner: the first full launch on
+// a fresh queue starts a good part of its workgroups up to a second late (the private-segment ring grows), and a helper that takes over is a workgroup from the end of the
+// dispatch order, which runs a frame 1.1 - 1.9 x slower than the workgroup it stands in for would — with a limit of 2 ms the first host-pointer batch of a
+// process took 8.6 s instead of 5.6 s (profiles/r06fin2_bench_512f.json).
 #ifndef LATE_MAIN_TICKS
-#define LATE_MAIN_TICKS 200000u        // 2 ms
+#define LATE_MAIN_TICKS 150000000u     // 1.5 s
 #endif
 #ifdef IMCVT_HOSTEMU
 HD int pool_cu_key(int home) { return home; }            // (the emulated workgroups have no compute units: a queue shard stands in — two helpers of one shard do not both take the path)

@@ -2050,7 +2050,7 @@ HDN int helper_loop(const Tables *gT_, const ColdTables *gK_, const FrameJob *jo
                 // offered — per 32x32 CU), and with a strict order a busy pool never got to the 32x32 queue: main workgroups were
                 // seen waiting seconds for an answer that takes a millisecond (profiles/r03l_wd_probe.log).
                 const int first = (served & 3) == 3 ? SLOT_32 : SLOT_16;
-                // A main-workgroup index that is still free although the launch is milliseconds old: its workgroup is being held back by the dispatcher (launches that fill every
+                // A main-workgroup index that is still free although the launch is 1.5 s old (LATE_MAIN_TICKS): its workgroup is being held back by the dispatcher (launches that fill every
                 // workgroup slot: one or two of a thousand workgroups start only when another has left — seconds late, and a frame with it).  A running helper takes the index at
                 // once, busy or not (the idle take-over below waits for the pool to drain); the late workgroup finds every index taken and becomes a helper.
                 // One helper per compute unit at most (bits 16.. of the unit's arrival counter; a workgroup that arrives there later sees a count beyond every quota and becomes

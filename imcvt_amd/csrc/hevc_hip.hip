@@ -85,7 +85,7 @@ static bool have_device() {
     return true;
 }
 
-extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r5 (wg=192; 256 with a pipe wave when the launch leaves room; 512 - pipe wave + four partner wavefronts, trial coders and PU steps split over wavefronts - when every workgroup gets a compute unit; a frame per workgroup, or main workgroups + a pool of helper workgroups when the batch leaves room; N = 16 / 32 transforms on the matrix cores; trial coders leave the leads of their bytes, the winner's become bytes by a carry look-ahead over ballots)"; }
+extern "C" const char *imcvt_hevc_version(void) { return "imcvt_hevc gfx950 r6 (wg=192; 256 with a pipe wave when the launch leaves room; 512 - pipe wave + four partner wavefronts, trial coders and PU steps split over wavefronts - when every workgroup gets a compute unit; a frame per workgroup, or main workgroups + a pool of helper workgroups when the batch leaves room; N = 16 / 32 transforms on the matrix cores; trial coders leave the leads of their bytes, the winner's become bytes by a carry look-ahead over ballots)"; }
 extern "C" int imcvt_hevc_padded(int v) { return ((v < 8192 ? v : 8192) + 31) / 32 * 32; }
 extern "C" long long imcvt_hevc_stream_bound(int h, int w) { return 2LL * (w + 32) * (h + 32) + 65536; }
 
@@ -393,7 +393,7 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         if (m < 1) return 1;
         // (a sixteenth of the workgroup slots stays free.  Fuller pools are faster when they go well — 512 + 512 workgroups 4.60 s against 4.83 s for 512 + 448 — but one launch
         // in ten of 976 .. 1024 workgroups leaves a few compute units with a single workgroup for milliseconds: a main index stays free, and the workgroup that finally takes it —
-        // the late one after seconds in rounds 3 - 5, a running helper after 2 ms since round 6 (hevc_frame.h helper_loop, late_main_due) — is one the dispatcher placed last on
+        // the late one after seconds in rounds 3 - 5, a running helper once the launch is 1.5 s old since round 6 (hevc_frame.h helper_loop, late_main_due) — is one the dispatcher placed last on
         // its compute unit and runs its frame 1.1 - 1.9 x slower than the others: 5.2 - 8.9 s, profiles/r06u_pool_fill.log, r06x_outliers.log.  At 15/16 no launch of the round did that.)
         const int room = max_wg - max_wg / 16 - m;
         h = 2 * m < room ? 2 * m : room;

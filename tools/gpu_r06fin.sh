@@ -20,4 +20,4 @@ rm -rf $O/rocprof_${T} $O/pmc_${T}_*/
 ( timeout 300 python tools/jls_bench.py 1920 1080 1 0; timeout 300 python tools/jls_bench.py 1920 1080 64 0; timeout 300 python tools/jls_bench.py 3840 2160 1 0 ) 2>&1 | grep -v amdgpu.ids | tee $O/${T}_jls_bench.log
 timeout 1500 python tools/scale_predict.py --out $O/${T}_scale_prediction.json 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-1500
 timeout 900 python bench.py --scaling weak --frames 512 --no-cpu-baseline --no-latency-view > $O/${T}_bench_weak_512f_per_gpu.json 2> $O/${T}_bench_weak.err; echo "weak rc=$?"; cut -c1-600 $O/${T}_bench_weak_512f_per_gpu.json
-timeout 1500 python tools/r06_ab.py wide split partners streams --reps 2 > $O/${T}_ab.log 2>&1; echo "ab rc=$?" >> $O/${T}_ab.log; cat $O/${T}_ab.log | cut -c1-800
+timeout 1200 python tools/r06_ab.py wide split partners --reps 2 > $O/${T}_ab.log 2>&1; echo "ab rc=$?" >> $O/${T}_ab.log; cat $O/${T}_ab.log | cut -c1-800
