@@ -419,6 +419,9 @@ struct alignas(256) PoolQ {
 // a fresh queue starts a good part of its workgroups up to a second late (the private-segment ring grows), and a helper that takes over is a workgroup from the end of the
 // dispatch order, which runs a frame 1.1 - 1.9 x slower than the workgroup it stands in for would — with a limit of 2 ms the first host-pointer batch of a
 // process took 8.6 s instead of 5.6 s (profiles/r06fin2_bench_512f.json).
+#ifndef ROLE_GRACE_TICKS
+#define ROLE_GRACE_TICKS 30000u          // 300 us (100 MHz): how long a later block waits before it claims a main-workgroup index the first blocks have left (hevc_frame.h kernel_main) — the shader engines hand their blocks out independently over ~40 us; 30 us let late blocks of a fast engine claim before early blocks of a slow one (profiles/r06zd_roles_default.log)
+#endif
 #ifndef LATE_MAIN_TICKS
 #define LATE_MAIN_TICKS 150000000u     // 1.5 s
 #endif

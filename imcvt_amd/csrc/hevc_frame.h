@@ -2188,10 +2188,9 @@ HD void kernel_main(const KArgs &A, int block) {
     const int pool = A.team_size > 1 && A.nhelp > 0;
     const int nm = A.nteams > 0 ? A.nteams : 1, tot = nm + A.nhelp;
     (void)tot;
-    // Roles are chosen when a workgroup starts, by where it landed: the first `quota` workgroups of the launch on a compute unit
-    // become main workgroups (while indices last), the others helpers — so every compute unit carries the same mix whatever
-    // order the dispatcher fills them in, and if fewer workgroups are resident than were launched it is helpers that are
-    // missing.  Nothing depends on a workgroup that is not running: a main workgroup posts requests only once a helper has
+    // Roles are chosen when a workgroup starts, by where it landed: of the first blocks of the launch (they are placed first) the first `quota` on a compute unit
+    // become main workgroups, what is left goes to the first `quota` arrivals of a compute unit among the others — see below; every compute unit carries the same
+    // mix whatever order the dispatcher fills them in, and if fewer workgroups are resident than were launched it is helpers that are missing.  Nothing depends on a workgroup that is not running: a main workgroup posts requests only once a helper has
     // reported in (helpers stay until every frame is finished, so what is posted is served) and evaluates the CUs itself until
     // then; frames are pulled by whichever main workgroups run, and an idle helper takes a free main index when frames wait.
     int team = block;
@@ -2207,8 +2206,29 @@ HD void kernel_main(const KArgs &A, int block) {
 #endif
                 int mid = -1;
                 // (a launch of main workgroups only: every workgroup takes an index while they last; of helpers only: none does — an idle helper may still take one later, helper_loop)
-                const int arrival = (A.role == 1 || A.role == 2) ? 0 : (int)(m_add32(&A.pq->cu_count[key], 1u) & 0xFFFFu);      // which workgroup of this launch on its compute unit: 0, 1, ...
-                const int want = A.role == 1 ? 1 : A.role == 2 ? 0 : arrival < A.quota;
+                const int first_blocks = block < nm && A.quota > 0;       // one of the first nm blocks of the launch (counted separately in bits 8 .. 15 of the compute unit's arrival counter)
+                const u32 seen = (A.role == 1 || A.role == 2) ? 0u : m_add32(&A.pq->cu_count[key], first_blocks ? 0x101u : 1u);
+                const int arrival = (int)(seen & 0xFFu), arrival_first = (int)(seen >> 8 & 0xFFu);      // which workgroup of this launch on its compute unit (0, 1, ...), and which of the first blocks
+                // Who becomes a main workgroup (round 6).  Of the FIRST nm blocks of the launch, the first `quota` that land on a compute unit; then, a moment later — when those have
+                // made their claims — whatever indices are left go to later blocks, the first `quota` arrivals of a compute unit as in rounds 3 - 5.  Why the first blocks first: on
+                // some boxes a workgroup that the dispatcher places late on its compute unit runs a frame 1.1 - 1.9 x slower than one placed early, and "the first two arrivals of
+                // every compute unit" alone let late blocks that happened to start before a compute unit's second early block become main workgroups — the bench launch took 4.85 or
+                // 5.05 s by that luck, 4.80 s twenty times out of twenty with the first blocks as main workgroups (profiles/r06zb_roles_by_block.log).  Why not simply the first nm
+                // blocks: on other boxes the dispatcher puts three of them on some compute units and one on others in nearly every launch, and three main workgroups on a compute
+                // unit cost 4 - 6 % (profiles/r06ze_roles_default.log) where the first two arrivals ran 4.81 s flat.  (quota < 0: the rule of rounds 3 - 5 alone, A/B.)
+                const int q_ = A.quota < 0 ? -A.quota : A.quota;
+                int want;
+                if (A.role == 1) want = 1;
+                else if (A.role == 2) want = 0;
+                else if (A.quota < 0) want = arrival < q_;
+                else if (first_blocks) want = arrival_first < q_;
+                else {
+#ifndef IMCVT_HOSTEMU
+                    const unsigned long long t_in = wall_clock64();
+                    while (wall_clock64() - t_in < ROLE_GRACE_TICKS) __builtin_amdgcn_s_sleep(8);
+#endif
+                    want = arrival < q_;
+                }
                 SM.next_frame = arrival;                 // (a free word until the frame loop)
 #ifndef IMCVT_HOSTEMU
                 if (A.fclk) ((volatile u8 *)(A.fclk + 4 * A.njobs + 4 * block + 1))[7] = (u8)(0x80u | (u32)arrival);      // (debug buffer, beside the wavefronts' SIMDs)
@@ -2228,7 +2248,7 @@ HD void kernel_main(const KArgs &A, int block) {
         if (team < 0 && pid >= 0) { sc.trace = (i32 *)0; partner8_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, pid, A.njobs); return; }
         if (team < 0) {
             sc.trace = (i32 *)0;
-            team = helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, block % POOL_SHARDS, 1, A.counter, A.njobs, arrival <= A.quota);
+            team = helper_loop(A.gT, A.gK, A.jobs, sc, A.mail, A.pq, nm, block % POOL_SHARDS, 1, A.counter, A.njobs, arrival <= (A.quota < 0 ? -A.quota : A.quota));
             if (team < 0) return;
         }
     }

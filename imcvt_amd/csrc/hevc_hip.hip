@@ -121,7 +121,9 @@ static int pool_limit(int nmains, int nhelp, int kind) {
 static void launch(imcvt_hevc_ctx *c, int grid, hipStream_t stream, int njobs, int team_size, int nmains, int nhelp, int pipe = 0, int role = 0, int block0 = 0, int split16 = -1, int split32 = -1, int npart = 0) {
     const int p16 = c->post16 >= 0 ? c->post16 : split16 >= 0 ? split16 : pool_split(nmains, nhelp, 0), p32 = c->post32 >= 0 ? c->post32 : split32 >= 0 ? split32 : pool_split(nmains, nhelp, 1);
     const int l16 = c->lim16 >= 0 ? c->lim16 : pool_limit(nmains, nhelp, 0), l32 = c->lim32 >= 0 ? c->lim32 : pool_limit(nmains, nhelp, 1);
-    const int prio = c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0), quota = (nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1);
+    const int prio = c->prio >= 0 ? c->prio : (nhelp >= 2 * nmains ? 2 : 0);
+    static const int by_arrival = getenv("IMCVT_POOL_ROLES_BY_ARRIVAL") ? atoi(getenv("IMCVT_POOL_ROLES_BY_ARRIVAL")) : 0;      // (A/B: main workgroups = the first two arrivals of every compute unit, the rule of rounds 3 - 5)
+    const int quota = (by_arrival ? -1 : 1) * ((nmains + c->cus - 1) / (c->cus > 0 ? c->cus : 1));
     if (pipe >= 2 && c->wide_kernel) {
         imcvt_wide_kernel_launch(grid, (void *)stream, c->d_tables, c->d_cold, (const FrameJob *)c->d_jobs, (const u8 *)c->d_hdrs, njobs, (const Scratch *)c->d_scratch, c->d_counter, c->d_trace, c->trace_cap, c->d_prof,
                                  c->d_mail, c->d_pq, team_size, nmains, nhelp, p16, p32, l16, l32, prio, quota, c->d_fclk, role, block0, npart);
@@ -391,10 +393,10 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         if ((long long)n * 8 > (long long)max_wg * 5) return 1;
         m = n < max_wg / 2 ? n : max_wg / 2;
         if (m < 1) return 1;
-        // (a sixteenth of the workgroup slots stays free.  Fuller pools are faster when they go well — 512 + 512 workgroups 4.60 s against 4.83 s for 512 + 448 — but one launch
-        // in ten of 976 .. 1024 workgroups leaves a few compute units with a single workgroup for milliseconds: a main index stays free, and the workgroup that finally takes it —
-        // the late one after seconds in rounds 3 - 5, a running helper once the launch is 1.5 s old since round 6 (hevc_frame.h helper_loop, late_main_due) — is one the dispatcher placed last on
-        // its compute unit and runs its frame 1.1 - 1.9 x slower than the others: 5.2 - 8.9 s, profiles/r06u_pool_fill.log, r06x_outliers.log.  At 15/16 no launch of the round did that.)
+        // (a sixteenth of the workgroup slots stays free.  Fuller pools are faster when they go well — 512 + 512 workgroups 4.60 s, 512 + 480 4.70 s against 4.80 - 4.83 s for
+        // 512 + 448 — but what goes well depends on the box: with the main workgroups chosen by arrival one launch in ten of 976 .. 1024 workgroups took 5.2 - 8.9 s on some boxes,
+        // with the first blocks as main workgroups 512 + 480 ran 4.69 - 4.75 s twenty times out of twenty on one box and 4.7 - 5.1 s (once 7.6 s) on another
+        // (profiles/r06u_pool_fill.log, r06x_outliers.log, r06zc_roles_by_block_fill.log, r06ze_roles_default.log).  At 15/16 no launch of rounds 4 - 6 ran long.)
         const int room = max_wg - max_wg / 16 - m;
         h = 2 * m < room ? 2 * m : room;
         if (h < 1) return 1;
