@@ -497,6 +497,20 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         j.prog = c->prog ? c->prog + 2 * (size_t)i : nullptr;
         j.hdr_len = imcvt::build_headers(c->h_hdrs + (size_t)HDR_MAX * i, f.qpd6, j.hp, j.wp);
     }
+    {   // A launch of another workgroup size leaves the device in a state in which every full launch of 192-thread workgroups after it — of this context or any other of the
+        // process, on any stream — runs 6 - 7 % longer (the bench batch 5.11 - 5.17 s instead of 4.81 s, for as long as the process lives: profiles/r06zm_slow_process2.log; all
+        // 960 workgroups resident and started within 40 us either way; what the state is has not been found).  The launches a context is created with — empty ones, every workgroup
+        // leaves at once: one of wide workgroups, three full ones of 192 threads — bring the fast state back (profiles/r06zn_slow_process3.log); so they are repeated, on the
+        // launch's own stream, whenever a full 192-thread launch follows a launch of another kind on this device.  (IMCVT_HEVC_NO_REWARM=1: A/B.)
+        static std::atomic<int> last_kind[64];      // per device: 0 / 1 full-grid 192-thread launches last (a context's creation ends with them), 2 pipe-wave, 3 wide or split
+        const int kind = (use_wide || use_split) ? 3 : use_pipe ? 2 : 1, dv = c->device & 63;
+        if (kind == 1 && 2 * grid > c->max_wg && last_kind[dv].load() > 1 && !getenv("IMCVT_HEVC_NO_REWARM")) {
+            if (c->wide_kernel && c->wide_wg > 0) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->wide_wg, stream, 0, 1, 0, 0, 2); }
+            for (int i = 0; i < 3; i++) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->max_wg, stream, 0, 1, 0, 0); }
+            HIPCHK(hipGetLastError());
+        }
+        last_kind[dv].store(kind);
+    }
     HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(FrameJob) * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(c->d_hdrs, c->h_hdrs, (size_t)HDR_MAX * n, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(c->d_counter, 0, 4 * sizeof(int), stream));
