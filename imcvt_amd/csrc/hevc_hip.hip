@@ -370,7 +370,7 @@ extern "C" int imcvt_hevc_last_shape(imcvt_hevc_ctx *c, int *nmains, int *nhelp)
 // walks only the 8x8 CUs itself (~4.1 s); the helper work of a frame is about as long as the main workgroup's own, so a pool as
 // large as the mains keeps up with them, and more than two helpers per main cannot be used (a main workgroup has at most one
 // request of each kind outstanding).  Every workgroup of the launch must be resident (helpers poll, mains wait for answers).
-//   n <= max_wg / 2       n mains, min(2 n, max_wg - n) helpers: one round
+//   n <= max_wg / 2       n mains, min(2 n, 15/16 max_wg - n) helpers: one round
 //   n <= 5 max_wg / 8     max_wg / 2 mains and as many helpers; the mains pull the remaining frames as they finish
 //   beyond                a frame per workgroup, max_wg of them, no helpers (the device is full either way and the hand-offs cost)
 // pure: the launch shape for n frames on a device that holds max_wg workgroups (force_team 0: choose; 1: no helpers; 2 / 3: one / two
@@ -393,10 +393,11 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         if ((long long)n * 8 > (long long)max_wg * 5) return 1;
         m = n < max_wg / 2 ? n : max_wg / 2;
         if (m < 1) return 1;
-        // (Rounds 3 - 5 and most of round 6 kept a sixteenth of the workgroup slots free: beyond 15/16 one launch in ten ran long, whatever rule chose the main workgroups
-        // (profiles/r06u_pool_fill.log ... r06zj_fuller_pool_new_rule.log).  With the empty launches of the re-warm in front of every full launch (imcvt_hevc_encode_device) a pool of
-        // max_wg workgroups is resident at once and ran 4.57 - 4.62 s in 52 launches of 52 against 4.80 - 4.82 s for 512 + 448: every slot is used.)
-        const int room = max_wg - m;
+        // (a sixteenth of the workgroup slots stays free.  Fuller pools are faster when they go well — 512 + 512 workgroups 4.60 s, 512 + 480 4.70 s against 4.80 - 4.83 s for
+        // 512 + 448 — but what goes well depends on the box: with the main workgroups chosen by arrival one launch in ten of 976 .. 1024 workgroups took 5.2 - 8.9 s on some boxes,
+        // with the first blocks as main workgroups 512 + 480 ran 4.69 - 4.75 s twenty times out of twenty on one box and 4.7 - 5.1 s (once 7.6 s) on another
+        // (profiles/r06u_pool_fill.log, r06x_outliers.log, r06zc_roles_by_block_fill.log, r06ze_roles_default.log).  At 15/16 no launch of rounds 4 - 6 ran long.)
+        const int room = max_wg - max_wg / 16 - m;
         h = 2 * m < room ? 2 * m : room;
         if (h < 1) return 1;
     }
@@ -503,10 +504,7 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         // launch's own stream, whenever a full 192-thread launch follows a launch of another kind on this device.  (IMCVT_HEVC_NO_REWARM=1: A/B.)
         static std::atomic<int> last_kind[64];      // per device: 0 / 1 full-grid 192-thread launches last (a context's creation ends with them), 2 pipe-wave, 3 wide or split
         const int kind = (use_wide || use_split) ? 3 : use_pipe ? 2 : 1, dv = c->device & 63;
-        // ... and in front of EVERY such launch they do more: a pool that uses every workgroup slot — 512 + 512 — then lands with all 1024 workgroups resident within 40 us and ran
-        // 4.57 - 4.62 s in 52 launches of 52, where without them one launch in ten had workgroups that started only when others left or three main workgroups on a compute unit and took
-        // 5.0 - 5.6 s (profiles/r06zu_rewarm_always.log, r06zv_rewarm_always_1024.log).  So: always (< 0.3 ms), and the plan uses every slot (imcvt_hevc_plan).
-        if (kind == 1 && 2 * grid > c->max_wg && (last_kind[dv].load() > 1 || !getenv("IMCVT_HEVC_REWARM_ON_CHANGE_ONLY")) && !getenv("IMCVT_HEVC_NO_REWARM")) {
+        if (kind == 1 && 2 * grid > c->max_wg && last_kind[dv].load() > 1 && !getenv("IMCVT_HEVC_NO_REWARM")) {
             if (c->wide_kernel && c->wide_wg > 0) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->wide_wg, stream, 0, 1, 0, 0, 2); }
             for (int i = 0; i < 3; i++) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->max_wg, stream, 0, 1, 0, 0); }
             HIPCHK(hipGetLastError());
