@@ -256,6 +256,26 @@ extern "C" imcvt_hevc_ctx *imcvt_hevc_create(int max_workgroups) {
             // (the 256-thread census launch left the SECOND full 192-thread launch after it with ~940 of 1000 workgroups resident,
             // profiles/r04c_census_probe.log: the last launches the runtime sees before real work are full 192-thread ones again)
             if (!prewarm()) { fprintf(stderr, "imcvt_hevc: pre-warm launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
+            // ... and three SHORT real launches of the largest pool (max_wg / 2 frames of 64 x 64 zeros: 16 ms each): the first three full launches of a process do not get every
+            // workgroup of a pool that uses every slot resident — 1021 - 1023 of 1024, the others start when the first leave, 4.6 / 5.3 / 5.0 s for the bench batch — and neither the
+            // empty launches nor the census above change that; real ones do (profiles/r06zw_first_launches.log: 4.59 - 4.60 s with 1024 resident from the first long launch on).
+            if (!getenv("IMCVT_HEVC_NO_WARM_POOL") && c->max_wg >= 64) {
+                const int n = c->max_wg / 2, hw = 64;
+                const size_t per = align256((size_t)imcvt_hevc_stream_bound(hw, hw)) + 2 * align256((size_t)hw * hw) + 256;
+                u8 *buf = nullptr;
+                if (hipMalloc(&buf, per * (size_t)n) == hipSuccess) {
+                    bool good = hipMemset(buf, 0, per * (size_t)n) == hipSuccess;
+                    std::vector<imcvt_hevc_frame> fr((size_t)n);
+                    for (int i = 0; i < n; i++) {
+                        u8 *b0 = buf + per * (size_t)i;
+                        fr[(size_t)i].d_img = b0; fr[(size_t)i].d_rcon = b0 + align256((size_t)hw * hw); fr[(size_t)i].d_out = b0 + 2 * align256((size_t)hw * hw);
+                        fr[(size_t)i].d_len = (int *)(b0 + per - 256); fr[(size_t)i].h = hw; fr[(size_t)i].w = hw; fr[(size_t)i].qpd6 = 0;
+                    }
+                    for (int i = 0; i < 3 && good; i++) good = imcvt_hevc_encode_device(c, n, fr.data(), nullptr) == 0 && hipDeviceSynchronize() == hipSuccess;
+                    (void)hipFree(buf);
+                    if (!good) { (void)hipGetLastError(); fprintf(stderr, "imcvt_hevc: warm-up pool launch failed\n"); imcvt_hevc_destroy(c); return nullptr; }
+                }
+            }
         }
     }
     return c;
@@ -370,7 +390,7 @@ extern "C" int imcvt_hevc_last_shape(imcvt_hevc_ctx *c, int *nmains, int *nhelp)
 // walks only the 8x8 CUs itself (~4.1 s); the helper work of a frame is about as long as the main workgroup's own, so a pool as
 // large as the mains keeps up with them, and more than two helpers per main cannot be used (a main workgroup has at most one
 // request of each kind outstanding).  Every workgroup of the launch must be resident (helpers poll, mains wait for answers).
-//   n <= max_wg / 2       n mains, min(2 n, 15/16 max_wg - n) helpers: one round
+//   n <= max_wg / 2       n mains, min(2 n, max_wg - n) helpers: one round
 //   n <= 5 max_wg / 8     max_wg / 2 mains and as many helpers; the mains pull the remaining frames as they finish
 //   beyond                a frame per workgroup, max_wg of them, no helpers (the device is full either way and the hand-offs cost)
 // pure: the launch shape for n frames on a device that holds max_wg workgroups (force_team 0: choose; 1: no helpers; 2 / 3: one / two
@@ -393,11 +413,10 @@ extern "C" int imcvt_hevc_plan(int n, int max_wg, int force_team, int *nmains_ou
         if ((long long)n * 8 > (long long)max_wg * 5) return 1;
         m = n < max_wg / 2 ? n : max_wg / 2;
         if (m < 1) return 1;
-        // (a sixteenth of the workgroup slots stays free.  Fuller pools are faster when they go well — 512 + 512 workgroups 4.60 s, 512 + 480 4.70 s against 4.80 - 4.83 s for
-        // 512 + 448 — but what goes well depends on the box: with the main workgroups chosen by arrival one launch in ten of 976 .. 1024 workgroups took 5.2 - 8.9 s on some boxes,
-        // with the first blocks as main workgroups 512 + 480 ran 4.69 - 4.75 s twenty times out of twenty on one box and 4.7 - 5.1 s (once 7.6 s) on another
-        // (profiles/r06u_pool_fill.log, r06x_outliers.log, r06zc_roles_by_block_fill.log, r06ze_roles_default.log).  At 15/16 no launch of rounds 4 - 6 ran long.)
-        const int room = max_wg - max_wg / 16 - m;
+        // (Rounds 3 - 5 and most of round 6 kept a sixteenth of the workgroup slots free: beyond 15/16 one launch in ten ran long, whatever rule chose the main workgroups
+        // (profiles/r06u_pool_fill.log ... r06zj_fuller_pool_new_rule.log).  With the empty launches of the re-warm in front of every full launch (imcvt_hevc_encode_device) a pool of
+        // max_wg workgroups is resident at once and ran 4.57 - 4.62 s in 52 launches of 52 against 4.80 - 4.82 s for 512 + 448: every slot is used.)
+        const int room = max_wg - m;
         h = 2 * m < room ? 2 * m : room;
         if (h < 1) return 1;
     }
@@ -504,7 +523,10 @@ extern "C" int imcvt_hevc_encode_device(imcvt_hevc_ctx *c, int n, const imcvt_he
         // launch's own stream, whenever a full 192-thread launch follows a launch of another kind on this device.  (IMCVT_HEVC_NO_REWARM=1: A/B.)
         static std::atomic<int> last_kind[64];      // per device: 0 / 1 full-grid 192-thread launches last (a context's creation ends with them), 2 pipe-wave, 3 wide or split
         const int kind = (use_wide || use_split) ? 3 : use_pipe ? 2 : 1, dv = c->device & 63;
-        if (kind == 1 && 2 * grid > c->max_wg && last_kind[dv].load() > 1 && !getenv("IMCVT_HEVC_NO_REWARM")) {
+        // ... and in front of EVERY such launch they do more: a pool that uses every workgroup slot — 512 + 512 — then lands with all 1024 workgroups resident within 40 us and ran
+        // 4.57 - 4.62 s in 52 launches of 52, where without them one launch in ten had workgroups that started only when others left or three main workgroups on a compute unit and took
+        // 5.0 - 5.6 s (profiles/r06zu_rewarm_always.log, r06zv_rewarm_always_1024.log).  So: always (< 0.3 ms), and the plan uses every slot (imcvt_hevc_plan).
+        if (kind == 1 && 2 * grid > c->max_wg && (last_kind[dv].load() > 1 || !getenv("IMCVT_HEVC_REWARM_ON_CHANGE_ONLY")) && !getenv("IMCVT_HEVC_NO_REWARM")) {
             if (c->wide_kernel && c->wide_wg > 0) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->wide_wg, stream, 0, 1, 0, 0, 2); }
             for (int i = 0; i < 3; i++) { HIPCHK(hipMemsetAsync(c->d_counter, 0, 8 * sizeof(int), stream)); launch(c, c->max_wg, stream, 0, 1, 0, 0); }
             HIPCHK(hipGetLastError());

@@ -131,16 +131,16 @@ def test_launch_shape_policy(built):
         m, h = C.c_int(-1), C.c_int(-1)
         return lib.imcvt_hevc_plan(n, wg, force, C.byref(m), C.byref(h)), m.value, h.value
 
-    assert plan(1) == (2, 1, 2) and plan(64) == (2, 64, 128) and plan(320) == (2, 320, 640) and plan(342) == (2, 342, 618)
-    assert plan(512) == (2, 512, 448) and plan(640) == (2, 512, 448)      # the mains pull the remaining frames as they finish
+    assert plan(1) == (2, 1, 2) and plan(64) == (2, 64, 128) and plan(320) == (2, 320, 640) and plan(342) == (2, 342, 682)
+    assert plan(512) == (2, 512, 512) and plan(640) == (2, 512, 512)      # the mains pull the remaining frames as they finish
     assert plan(641) == (1, 641, 0) and plan(1000) == (1, 1000, 0) and plan(5000) == (1, 1024, 0)
     for n in range(1, 1400, 7):
         mode, m, h = plan(n)
         assert mode in (1, 2) and 1 <= m <= min(n, 1024) and m + h <= 1024
-        assert (h == 0) if mode == 1 else (0 < h <= 2 * m and m <= 512 and m + h <= 960)
+        assert (h == 0) if mode == 1 else (0 < h <= 2 * m and m <= 512 and m + h <= 1024)
     assert plan(100, force=1) == (1, 100, 0) and plan(100, force=2) == (2, 100, 100) and plan(100, force=3) == (2, 100, 200)
     assert plan(2000, force=3) == (2, 341, 682) and plan(2000, force=2) == (2, 512, 512)
-    assert plan(10, wg=16) == (2, 8, 7) and plan(11, wg=16) == (1, 11, 0) and plan(5, wg=16) == (2, 5, 10)
+    assert plan(10, wg=16) == (2, 8, 8) and plan(11, wg=16) == (1, 11, 0) and plan(5, wg=16) == (2, 5, 10)
     assert plan(0) == (1, 0, 0)
 
     # pipe wave (256-thread workgroups, three per CU): pure too — used when the planned launch fits 15/16 of 768 slots; a pool that just
@@ -152,7 +152,7 @@ def test_launch_shape_policy(built):
 
     assert pipe(1) == (1, 1, 2) and pipe(64) == (1, 64, 128) and pipe(240) == (1, 240, 480)
     assert pipe(256) == (1, 256, 464) and pipe(288) == (1, 288, 432)        # helpers cut to 720 - n
-    assert pipe(289) == (0, 289, 578) and pipe(512) == (0, 512, 448)        # (less than 1.5 helpers per main would be left: no pipe wave)
+    assert pipe(289) == (0, 289, 578) and pipe(512) == (0, 512, 512)        # (less than 1.5 helpers per main would be left: no pipe wave)
     assert pipe(700) == (1, 700, 0) and pipe(720) == (1, 720, 0) and pipe(721) == (0, 721, 0)      # a frame per workgroup
     assert pipe(5, wg=16) == (0, 5, 10) and pipe(3, wg=16) == (1, 3, 6)     # 12 slots of 256 threads, 11 usable... 9 workgroups fit
     for n in range(1, 1400, 5):

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=gpurun_out; mkdir -p $R/$O; cd $R
 T=${1:-r06fin}
 timeout 3000 python -m pytest tests -m gpu -x -q > $O/${T}_gpu_tests.log 2>&1; echo "gpu tests rc=$?" >> $O/${T}_gpu_tests.log; tail -3 $O/${T}_gpu_tests.log | cut -c1-200
 bash tools/gpu_pmc.sh ${T} 1920 1080 512 0 > $O/${T}_pmc.log 2>&1; tail -3 $O/${T}_pmc.log | cut -c1-300
-python tools/pmc_issue.py $O/${T}_pmc_sq.txt 512 1920 1080 0 "the bench's launch shape: 512 main + 448 helper workgroups" > $O/${T}_pmc_issue.json; cat $O/${T}_pmc_issue.json | cut -c1-300
+python tools/pmc_issue.py $O/${T}_pmc_sq.txt 512 1920 1080 0 "the bench's launch shape: 512 main + 512 helper workgroups" > $O/${T}_pmc_issue.json; cat $O/${T}_pmc_issue.json | cut -c1-300
 cp $O/${T}_pmc_issue.json profiles/pmc_issue.json; cp $O/${T}_pmc_traffic.json profiles/pmc_traffic.json
 timeout 900 python tools/valu_dyn_mix.py --frames 64 --out $O/${T}_valu_dyn_mix.json --save-counts $O/${T}_region_counts.json > $O/${T}_valu_dyn_mix.log 2>&1; grep -i "flushes\|share_in\|mix_weighted_cycles_simd" $O/${T}_valu_dyn_mix.log | cut -c1-200
 [ -s $O/${T}_valu_dyn_mix.json ] && cp $O/${T}_valu_dyn_mix.json profiles/valu_dyn_mix.json
